@@ -1,0 +1,213 @@
+"""TEST INFRASTRUCTURE ONLY -- generates tests/golden/*.pt by running the UNMODIFIED reference
+(/root/reference, imported through oracle/ref_import.py) on CPU in fp32.
+
+Run in the build container (the reference is not present on the GPU box):
+    python -m oracle.gen_golden            # writes tests/golden/*.pt
+
+Weights and inputs are *procedural* (oracle.procedural_weights / oracle.synthetic_batch): fixtures
+store only shapes, seeds and the reference's outputs, so they stay small enough to commit while
+still pinning full-size configurations (config 1 of BASELINE.json: TSF-B/16, 2 frames of 112^2,
+batch 4).
+"""
+import os
+import sys
+
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import oracle as O          # noqa: E402
+from oracle.ref_import import load_reference  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+CONFIGS = {
+    # name: dict(model kwargs..., batch)
+    'tiny_p16': dict(img=32, patch=16, frames=2, dim=128, depth=2, heads=2, t_width=128, t_heads=2,
+                     t_layers=2, vocab=512, embed=64, batch=3, gated=False),
+    'tiny_p14_gated': dict(img=42, patch=14, frames=3, dim=128, depth=2, heads=2, t_width=64, t_heads=1,
+                           t_layers=1, vocab=512, embed=32, batch=2, gated=True),
+    # BASELINE.json configs[0]: CLIP_OPENAI_TIMESFORMER_BASE shape, 2 frames 112^2, batch 4
+    'config1_tsfb_112': dict(img=112, patch=16, frames=2, dim=768, depth=12, heads=12, t_width=512,
+                             t_heads=8, t_layers=12, vocab=49408, embed=256, batch=4, gated=False),
+}
+
+
+def build_reference_model(ref, c):
+    vis = ref.timesformer.SpaceTimeTransformer(
+        img_size=c['img'], patch_size=c['patch'], embed_dim=c['dim'], depth=c['depth'],
+        num_heads=c['heads'], num_frames=c['frames'], time_init='zeros',
+        attention_style='frozen-in-time', ln_pre=True, act_layer=ref.openai_model.QuickGELU,
+        is_tanh_gating=c['gated'])
+    vis.head = nn.Identity()
+    vis.pre_logits = nn.Identity()
+    vis.fc = nn.Identity()
+    model = ref.models.CLIP(
+        embed_dim=c['embed'], vision_width=c['dim'], vision_model=vis, context_length=77,
+        vocab_size=c['vocab'], transformer_width=c['t_width'], transformer_heads=c['t_heads'],
+        transformer_layers=c['t_layers'], tempearture_init=0.07)
+    return model
+
+
+def synthetic_inputs(c, seed=1234):
+    video, tokens = O.synthetic_batch(c['batch'], c['frames'], c['img'], seed=seed)
+    if c['vocab'] < 49408:      # tiny vocab: remap ids, keep EOT as the maximum id
+        tokens = tokens.clone()
+        body = tokens[:, 1:31] % (c['vocab'] - 2) + 1
+        tokens[:, 1:31] = body
+        tokens[:, 0] = c['vocab'] - 2
+        tokens[:, 31] = c['vocab'] - 1
+    return video, tokens
+
+
+def run_model_golden(ref, name, c):
+    torch.manual_seed(0)
+    model = build_reference_model(ref, c)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    weights = O.procedural_weights(shapes, seed=7)
+    model.load_state_dict(weights, strict=True)
+    model.train()
+    video, tokens = synthetic_inputs(c)
+
+    acts = {}
+
+    def hook(tag):
+        def fn(mod, inp, out):
+            acts[tag] = out.detach().clone()
+        return fn
+    hs = [model.visual.blocks[0].timeattn.register_forward_hook(hook('blk0_timeattn_out')),
+          model.visual.blocks[0].attn.register_forward_hook(hook('blk0_spaceattn_out')),
+          model.visual.blocks[0].register_forward_hook(hook('blk0_out')),
+          model.visual.blocks[-1].register_forward_hook(hook('blk_last_out')),
+          model.transformer.resblocks[0].register_forward_hook(hook('txt_blk0_out_LND'))]
+
+    out = model(video, tokens, norm_embed=True)
+    crit = ref.loss.CLIPLoss(use_vissl=False, cache_labels=True, rank=0, world_size=1)
+    ld = crit(out)
+    ld['loss'].backward()
+    for h in hs:
+        h.remove()
+    li = (out['logit_scale'] * out['image_embed'] @ out['text_embed'].T).detach()
+
+    grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    fixture = {
+        'config': c, 'shapes': shapes, 'weight_seed': 7, 'input_seed': 1234,
+        'image_embed': out['image_embed'].detach(), 'text_embed': out['text_embed'].detach(),
+        'logit_scale': out['logit_scale'].detach(), 'logits_per_image': li,
+        'loss': ld['loss'].detach(), 'clip_acc': ld['clip_acc'].detach(),
+        'pred': li.argmax(-1), 'labels': torch.arange(li.shape[0]),
+        'state_dict_keys': list(model.state_dict().keys()),
+        'param_names': [k for k, _ in model.named_parameters()],
+    }
+    if c['dim'] <= 128:
+        fixture['acts'] = acts
+        fixture['grads'] = grads
+    else:      # full-size model: keep per-parameter grad norms + a few full small grads
+        fixture['grad_norms'] = {k: g.norm().item() for k, g in grads.items()}
+        keep = ['logit_scale', 'visual.cls_token', 'visual.temporal_embed', 'visual.norm.weight',
+                'visual.blocks.0.norm3.weight', 'visual.blocks.11.timeattn.qkv.bias',
+                'visual.blocks.5.attn.proj.bias', 'ln_final.bias',
+                'transformer.resblocks.3.attn.in_proj_bias', 'visual.ln_pre.weight']
+        fixture['grads'] = {k: grads[k] for k in keep}
+        fixture['acts'] = {k: v[:, :3].clone() if v.ndim == 3 else v for k, v in acts.items()}
+    torch.save(fixture, os.path.join(GOLDEN, f'model_{name}.pt'))
+    print(f'[golden] {name}: loss={ld["loss"].item():.6f} acc={ld["clip_acc"].item():.1f} '
+          f'params={sum(v.numel() for v in weights.values())/1e6:.2f}M')
+
+
+def run_var_attention_golden(ref):
+    """VarAttention (timesformer.py:87-144) on odd shapes, both einops modes, with grads."""
+    cases = []
+    for (B, Fr, N, H) in [(2, 3, 5, 2), (2, 4, 49, 2), (3, 1, 7, 2), (2, 16, 4, 3)]:
+        D = 64 * H
+        torch.manual_seed(100 + B + Fr + N)
+        m = ref.timesformer.VarAttention(D, num_heads=H, qkv_bias=True)
+        shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        w = O.procedural_weights(shapes, seed=11)
+        m.load_state_dict(w)
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(B, 1 + Fr * N, D, generator=g)
+        gout = torch.randn(B, 1 + Fr * N, D, generator=g)
+        rec = {'B': B, 'F': Fr, 'N': N, 'H': H, 'shapes': shapes, 'x': x, 'gout': gout}
+        for mode, (efrom, eto, dims) in {
+            'space': ('b (f n) d', '(b f) n d', {'f': Fr}),
+            'time': ('b (f n) d', '(b n) f d', {'n': N}),
+        }.items():
+            xi = x.clone().requires_grad_(True)
+            m.zero_grad()
+            y = m(xi, efrom, eto, dims)
+            y.backward(gout)
+            rec[mode] = {'y': y.detach(), 'dx': xi.grad.clone(),
+                         'dw': {k: p.grad.clone() for k, p in m.named_parameters()}}
+        cases.append(rec)
+    torch.save(cases, os.path.join(GOLDEN, 'var_attention.pt'))
+    print(f'[golden] var_attention: {len(cases)} cases')
+
+
+def _rank_worker(rank, world, port, use_vissl, q):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    ref = load_reference()
+    g = torch.Generator().manual_seed(77)
+    E, Bl = 16, 3
+    img = O.l2_normalize(torch.randn(world * Bl, E, generator=g))
+    txt = O.l2_normalize(torch.randn(world * Bl, E, generator=g))
+    li = img[rank * Bl:(rank + 1) * Bl].clone().requires_grad_(True)
+    lt = txt[rank * Bl:(rank + 1) * Bl].clone().requires_grad_(True)
+    scale = torch.tensor(14.285714).requires_grad_(True)
+    crit = ref.loss.CLIPLoss(use_vissl=use_vissl, cache_labels=True, rank=rank, world_size=world)
+    out = crit({'image_embed': li, 'text_embed': lt, 'logit_scale': scale})
+    out['loss'].backward()
+    q.put((rank, out['loss'].item(), out['clip_acc'].item(), li.grad.tolist(), lt.grad.tolist(),
+           scale.grad.item()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def run_multirank_loss_golden():
+    """CLIPLoss on 2 and 3 gloo ranks, vissl and non-vissl (loss.py:69-118, distributed_utils.py:51-89)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    results = {}
+    port = 29611
+    for world in (2, 3):
+        for use_vissl in (True, False):
+            q = ctx.Queue()
+            procs = [ctx.Process(target=_rank_worker, args=(r, world, port, use_vissl, q)) for r in range(world)]
+            port += 1
+            for p in procs:
+                p.start()
+            got = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+            for p in procs:
+                p.join()
+            results[(world, use_vissl)] = {
+                'loss': [g[1] for g in got], 'acc': [g[2] for g in got],
+                'dimg': torch.cat([torch.tensor(g[3]) for g in got]),
+                'dtxt': torch.cat([torch.tensor(g[4]) for g in got]),
+                'dscale': [g[5] for g in got]}
+            print(f'[golden] multirank world={world} vissl={use_vissl} loss={got[0][1]:.6f}')
+    torch.save({'E': 16, 'B_local': 3, 'seed': 77, 'scale': 14.285714, 'results': results},
+               os.path.join(GOLDEN, 'clip_loss_multirank.pt'))
+
+
+def main():
+    os.makedirs(GOLDEN, exist_ok=True)
+    torch.set_num_threads(8)
+    only = sys.argv[1:]
+    ref = load_reference()
+    if not only or 'attn' in only:
+        run_var_attention_golden(ref)
+    if not only or 'model' in only:
+        for name, c in CONFIGS.items():
+            run_model_golden(ref, name, c)
+    if not only or 'multirank' in only:
+        run_multirank_loss_golden()
+
+
+if __name__ == '__main__':
+    main()

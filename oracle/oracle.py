@@ -1,0 +1,289 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU (torch fp32/fp64) restatement of the LaViLa dual-encoder
+pretraining hot path. It is the checker for the HIP kernels; it is never the thing shipped or
+measured (only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import it).
+
+Parity status: PINNED. The reference repository has no tests or golden vectors of its own
+(SURVEY.md section 4), so the pins are outputs of the reference itself, generated in the build
+container by oracle/gen_golden.py (which imports /root/reference unmodified) and committed under
+tests/golden/. tests/test_oracle_golden.py checks every function here against them.
+
+Every function cites the reference lines it restates (paths relative to the reference root).
+The code is functional (explicit weight dicts with the reference's state_dict key names, explicit
+index arithmetic instead of einops patterns) so that each step is one checkable formula.
+"""
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+
+# --------------------------------------------------------------------------------------
+# elementwise / normalisation
+# --------------------------------------------------------------------------------------
+def quick_gelu(x: Tensor) -> Tensor:
+    """x * sigmoid(1.702 x)   -- lavila/models/openai_model.py:177-179"""
+    return x * torch.sigmoid(1.702 * x)
+
+
+def layer_norm(x: Tensor, weight: Tensor, bias: Tensor, eps: float) -> Tensor:
+    """Affine LayerNorm over the last dim, biased variance.
+    eps = 1e-5 for ln_pre / text ln_1, ln_2, ln_final (timesformer.py:263-264, openai_model.py:187,193,
+    models.py:106); eps = 1e-6 for norm1/2/3 and the final norm (timesformer.py:247)."""
+    mu = x.mean(-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(-1, keepdim=True)
+    return (x - mu) * torch.rsqrt(var + eps) * weight + bias
+
+
+def l2_normalize(x: Tensor, eps: float = 1e-12) -> Tensor:
+    """F.normalize(dim=-1): x / max(||x||_2, eps)   -- lavila/models/models.py:168-170"""
+    return x / x.norm(dim=-1, keepdim=True).clamp_min(eps)
+
+
+# --------------------------------------------------------------------------------------
+# patch embedding + positional / temporal embedding
+# --------------------------------------------------------------------------------------
+def patchify(video_bcthw: Tensor, patch: int) -> Tensor:
+    """[B,3,F,H,W] -> [B, F*N, 3*P*P] patch matrix; row order frame-major then (py,px); column
+    order (c, i, j) -- the flattening of Conv2d weight [D,3,P,P].
+    Restates permute(0,2,1,3,4) (timesformer.py:387) + Conv2d(k=stride=P) viewed as a GEMM
+    (timesformer.py:77,79-84) + flatten(2).transpose(2,1).reshape(b,-1,D) (timesformer.py:349-350)."""
+    B, C, Fr, H, W = video_bcthw.shape
+    gh, gw = H // patch, W // patch
+    x = video_bcthw.permute(0, 2, 1, 3, 4)                        # B F C H W
+    x = x.reshape(B, Fr, C, gh, patch, gw, patch)
+    x = x.permute(0, 1, 3, 5, 2, 4, 6)                            # B F gh gw C i j
+    return x.reshape(B, Fr * gh * gw, C * patch * patch)
+
+
+def patch_embed(video_bcthw: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
+    """VideoPatchEmbed (timesformer.py:61-84) as patch-matrix x weight^T (+ bias iff ln_pre=False)."""
+    D, C, P, _ = w.shape
+    y = patchify(video_bcthw, P) @ w.reshape(D, C * P * P).t()
+    return y if b is None else y + b
+
+
+def total_pos_embed(pos_embed: Tensor, temporal_embed: Tensor, n_per_frame: int, frames: int) -> Tensor:
+    """[1+frames*N, D]: row 0 = pos_embed[0]; row 1+f*N+n = pos_embed[1+n] + temporal_embed[f]
+    -- timesformer.py:356-364 (tile over frames, repeat_interleave over patches, truncated to the
+    current number of tokens)."""
+    pos = pos_embed[0]                       # [N+1, D]
+    tem = temporal_embed[0]                  # [num_frames, D]
+    body = pos[1:].unsqueeze(0) + tem[:frames].unsqueeze(1)       # [F, N, D]
+    return torch.cat([pos[:1], body.reshape(frames * n_per_frame, -1)], 0)
+
+
+# --------------------------------------------------------------------------------------
+# divided space-time attention (VarAttention)
+# --------------------------------------------------------------------------------------
+def _softmax_av(q: Tensor, k: Tensor, v: Tensor) -> Tensor:
+    """softmax(q k^T) v over the last two dims, no mask/dropout/extra scale -- timesformer.py:35-39"""
+    s = q @ k.transpose(-1, -2)
+    return torch.softmax(s, dim=-1) @ v
+
+
+def divided_attention_core(qkv: Tensor, heads: int, frames: int, n_per_frame: int, mode: str) -> Tensor:
+    """The part of VarAttention.forward between the qkv Linear and the proj Linear
+    (timesformer.py:110-140), on packed qkv [B, T, 3*D] with T = 1 + frames*n_per_frame.
+
+    * q is pre-scaled by dh^-0.5 (timesformer.py:113)
+    * CLS query (token 0) attends to all T keys (timesformer.py:116-119)
+    * patch queries are grouped: mode='space' -> per frame (N queries, keys = [cls] + N patches of
+      that frame; 'b (f n) d -> (b f) n d', timesformer.py:300-301); mode='time' -> per location
+      (F queries, keys = [cls] + F patches of that location; '(b n) f d', timesformer.py:302-303)
+    * output [B, T, D] with heads merged '(b h) n d -> b n (h d)' (timesformer.py:134-140)
+    """
+    B, T, D3 = qkv.shape
+    D = D3 // 3
+    dh = D // heads
+    Fr, N = frames, n_per_frame
+    assert T == 1 + Fr * N
+    q, k, v = qkv.reshape(B, T, 3, heads, dh).permute(2, 0, 3, 1, 4)      # each [B,H,T,dh]
+    q = q * (dh ** -0.5)
+    out = torch.empty(B, heads, T, dh, dtype=qkv.dtype)
+    out[:, :, 0:1] = _softmax_av(q[:, :, 0:1], k, v)
+    qp = q[:, :, 1:].reshape(B, heads, Fr, N, dh)
+    kp = k[:, :, 1:].reshape(B, heads, Fr, N, dh)
+    vp = v[:, :, 1:].reshape(B, heads, Fr, N, dh)
+    if mode == 'time':                                                      # groups = locations
+        qp, kp, vp = (t.transpose(2, 3) for t in (qp, kp, vp))             # [B,H,N,F,dh]
+    G = qp.shape[2]
+    kc = k[:, :, None, 0:1].expand(B, heads, G, 1, dh)
+    vc = v[:, :, None, 0:1].expand(B, heads, G, 1, dh)
+    og = _softmax_av(qp, torch.cat([kc, kp], 3), torch.cat([vc, vp], 3))
+    if mode == 'time':
+        og = og.transpose(2, 3)
+    out[:, :, 1:] = og.reshape(B, heads, Fr * N, dh)
+    return out.permute(0, 2, 1, 3).reshape(B, T, D)
+
+
+def var_attention(x: Tensor, w: Dict[str, Tensor], prefix: str, heads: int, frames: int,
+                  n_per_frame: int, mode: str) -> Tensor:
+    """VarAttention.forward (timesformer.py:107-144): qkv Linear -> core -> proj Linear (dropouts p=0)."""
+    qkv = F.linear(x, w[prefix + 'qkv.weight'], w.get(prefix + 'qkv.bias'))
+    o = divided_attention_core(qkv, heads, frames, n_per_frame, mode)
+    return F.linear(o, w[prefix + 'proj.weight'], w[prefix + 'proj.bias'])
+
+
+def space_time_block(x: Tensor, w: Dict[str, Tensor], prefix: str, heads: int, frames: int,
+                     n_per_frame: int, eps: float = 1e-6) -> Tensor:
+    """SpaceTimeBlock.forward, 'frozen-in-time' wiring (timesformer.py:173-198):
+        t  = x + [tanh(alpha)*] timeattn(norm3(x))
+        x1 = x + attn(norm1(t))              <- residual from x, NOT from t
+        x2 = x1 + mlp(norm2(x1)),  mlp = fc2(QuickGELU(fc1(.)))   (timesformer.py:52-58)"""
+    p = prefix
+    t_out = var_attention(layer_norm(x, w[p + 'norm3.weight'], w[p + 'norm3.bias'], eps),
+                          w, p + 'timeattn.', heads, frames, n_per_frame, 'time')
+    if p + 'alpha_timeattn' in w:
+        t_out = torch.tanh(w[p + 'alpha_timeattn']) * t_out
+    t = x + t_out
+    s_out = var_attention(layer_norm(t, w[p + 'norm1.weight'], w[p + 'norm1.bias'], eps),
+                          w, p + 'attn.', heads, frames, n_per_frame, 'space')
+    x1 = x + s_out
+    h = layer_norm(x1, w[p + 'norm2.weight'], w[p + 'norm2.bias'], eps)
+    h = quick_gelu(F.linear(h, w[p + 'mlp.fc1.weight'], w[p + 'mlp.fc1.bias']))
+    return x1 + F.linear(h, w[p + 'mlp.fc2.weight'], w[p + 'mlp.fc2.bias'])
+
+
+def vision_tower(video_bcthw: Tensor, w: Dict[str, Tensor], heads: int, prefix: str = 'visual.',
+                 cls_at_last: bool = True) -> Tensor:
+    """SpaceTimeTransformer.forward/forward_features (timesformer.py:345-390) for the CLIP_OPENAI_*
+    configuration (ln_pre=True, QuickGELU, head/pre_logits = Identity, models.py:347-349)."""
+    p = prefix
+    B, C, Fr, H, W = video_bcthw.shape
+    pw = w[p + 'patch_embed.proj.weight']
+    P = pw.shape[-1]
+    N = (H // P) * (W // P)
+    depth = 1 + max(int(k[len(p) + 7:].split('.')[0]) for k in w if k.startswith(p + 'blocks.'))
+    x = patch_embed(video_bcthw, pw, w.get(p + 'patch_embed.proj.bias'))
+    x = torch.cat([w[p + 'cls_token'].expand(B, -1, -1), x], 1)
+    x = x + total_pos_embed(w[p + 'pos_embed'], w[p + 'temporal_embed'], N, Fr)
+    if p + 'ln_pre.weight' in w:
+        x = layer_norm(x, w[p + 'ln_pre.weight'], w[p + 'ln_pre.bias'], 1e-5)
+    for i in range(depth):
+        x = space_time_block(x, w, f'{p}blocks.{i}.', heads, Fr, N)
+    x = layer_norm(x, w[p + 'norm.weight'], w[p + 'norm.bias'], 1e-6)
+    return x[:, 0] if cls_at_last else x
+
+
+# --------------------------------------------------------------------------------------
+# text tower (OpenAI-CLIP Transformer)
+# --------------------------------------------------------------------------------------
+def causal_attention_core(qkv: Tensor, heads: int) -> Tensor:
+    """nn.MultiheadAttention core with the additive causal mask of CLIP.build_attention_mask
+    (models.py:131-137; openai_model.py:196-198): softmax((q dh^-0.5) k^T + mask) v, packed
+    qkv [B, L, 3*W] -> [B, L, W]."""
+    B, L, W3 = qkv.shape
+    W = W3 // 3
+    dh = W // heads
+    q, k, v = qkv.reshape(B, L, 3, heads, dh).permute(2, 0, 3, 1, 4)
+    s = (q * dh ** -0.5) @ k.transpose(-1, -2)
+    mask = torch.full((L, L), float('-inf'), dtype=qkv.dtype).triu_(1)
+    o = torch.softmax(s + mask, -1) @ v
+    return o.permute(0, 2, 1, 3).reshape(B, L, W)
+
+
+def text_block(x: Tensor, w: Dict[str, Tensor], prefix: str, heads: int) -> Tensor:
+    """ResidualAttentionBlock.forward (openai_model.py:182-216): x + MHA(ln_1 x); x + MLP(ln_2 x)."""
+    p = prefix
+    h = layer_norm(x, w[p + 'ln_1.weight'], w[p + 'ln_1.bias'], 1e-5)
+    qkv = F.linear(h, w[p + 'attn.in_proj_weight'], w[p + 'attn.in_proj_bias'])
+    o = causal_attention_core(qkv, heads)
+    x = x + F.linear(o, w[p + 'attn.out_proj.weight'], w[p + 'attn.out_proj.bias'])
+    h = layer_norm(x, w[p + 'ln_2.weight'], w[p + 'ln_2.bias'], 1e-5)
+    h = quick_gelu(F.linear(h, w[p + 'mlp.c_fc.weight'], w[p + 'mlp.c_fc.bias']))
+    return x + F.linear(h, w[p + 'mlp.c_proj.weight'], w[p + 'mlp.c_proj.bias'])
+
+
+def text_tower(tokens: Tensor, w: Dict[str, Tensor], heads: int) -> Tensor:
+    """CLIP.encode_text (models.py:150-162): embed + pos -> blocks -> ln_final -> row at argmax(token
+    id) (EOT = highest id) -> @ text_projection."""
+    x = w['token_embedding.weight'][tokens] + w['positional_embedding']
+    depth = 1 + max(int(k.split('.')[2]) for k in w if k.startswith('transformer.resblocks.'))
+    for i in range(depth):
+        x = text_block(x, w, f'transformer.resblocks.{i}.', heads)
+    x = layer_norm(x, w['ln_final.weight'], w['ln_final.bias'], 1e-5)
+    eot = tokens.argmax(-1)
+    return x[torch.arange(x.shape[0]), eot] @ w['text_projection']
+
+
+# --------------------------------------------------------------------------------------
+# dual encoder + contrastive loss
+# --------------------------------------------------------------------------------------
+def clip_forward(video: Tensor, tokens: Tensor, w: Dict[str, Tensor], vision_heads: int,
+                 text_heads: int, norm_embed: bool = False) -> Dict[str, Tensor]:
+    """CLIP.forward (models.py:164-173) -> {'image_embed','text_embed','logit_scale'=exp(param)}"""
+    img = vision_tower(video, w, vision_heads) @ w['image_projection']     # models.py:139-148
+    txt = text_tower(tokens, w, text_heads)
+    if norm_embed:
+        img, txt = l2_normalize(img), l2_normalize(txt)
+    return {'image_embed': img, 'text_embed': txt, 'logit_scale': w['logit_scale'].exp()}
+
+
+def clip_logits(all_img: Tensor, all_txt: Tensor, logit_scale: Tensor) -> Tensor:
+    """logits_per_image = logit_scale * all_img @ all_txt.T  (left-to-right) -- loss.py:78"""
+    return (logit_scale * all_img) @ all_txt.t()
+
+
+def clip_loss(all_img: Tensor, all_txt: Tensor, logit_scale: Tensor) -> Dict[str, Tensor]:
+    """CLIPLoss.forward on the rank-ordered concatenation of all ranks' embeddings
+    (loss.py:69-118; world_size>1 + use_vissl gathers in rank order, distributed_utils.py:88).
+    labels = arange(G) int64; loss = (CE(Li)+CE(Li^T))/2; acc = 100*mean(argmax(Li,-1)==labels)."""
+    li = clip_logits(all_img, all_txt, logit_scale)
+    G = li.shape[0]
+    labels = torch.arange(G, dtype=torch.long)
+    loss = (F.cross_entropy(li, labels) + F.cross_entropy(li.t(), labels)) / 2
+    pred = li.argmax(-1)
+    acc = 100.0 * (pred == labels).sum() / G
+    return {'loss': loss, 'clip_loss': loss, 'clip_acc': acc, 'logits_per_image': li,
+            'labels': labels, 'pred': pred}
+
+
+# --------------------------------------------------------------------------------------
+# deterministic synthetic weights / inputs shared by the golden generator, tests and bench
+# --------------------------------------------------------------------------------------
+def synthetic_batch(batch: int, frames: int, img: int, seed: int = 1234, real_tokens: int = 32,
+                    ctx: int = 77):
+    """randn frames [B,3,F,H,W]; tokens [B,77] = SOT, 30 random ids, EOT at 31,
+    zero padding (EOT=49407 is the max id so argmax finds it, tokenizer.py:147-162)."""
+    g = torch.Generator().manual_seed(seed)
+    video = torch.randn(batch, 3, frames, img, img, generator=g)
+    tokens = torch.zeros(batch, ctx, dtype=torch.long)
+    tokens[:, 0] = 49406
+    tokens[:, 1:real_tokens - 1] = torch.randint(1, 49406, (batch, real_tokens - 2), generator=g)
+    tokens[:, real_tokens - 1] = 49407
+    return video, tokens
+
+
+def procedural_weights(shapes: Dict[str, tuple], seed: int = 0) -> Dict[str, Tensor]:
+    """Deterministic weights from (name -> shape): every tensor gets its own CPU generator seeded by
+    (seed, index in sorted-name order) so that the golden script, the tests and bench.py can rebuild
+    identical weights without shipping them. Scales are chosen so the temporal path is live
+    (the shipped zeros-init makes temporal attention a no-op)."""
+    out = {}
+    for idx, name in enumerate(sorted(shapes)):
+        shape = tuple(shapes[name])
+        g = torch.Generator().manual_seed(seed * 1000003 + idx)
+        leaf = name.split('.')[-1]
+        if name == 'logit_scale':
+            t = torch.tensor(math.log(1 / 0.07))
+        elif name.endswith('alpha_timeattn'):
+            t = torch.randn(shape, generator=g) * 0.5
+        elif leaf == 'weight' and len(shape) == 1:          # LayerNorm gains
+            t = 1.0 + 0.1 * torch.randn(shape, generator=g)
+        elif leaf in ('bias', 'in_proj_bias'):
+            t = 0.02 * torch.randn(shape, generator=g)
+        elif name in ('image_projection', 'text_projection'):
+            t = torch.randn(shape, generator=g) * shape[0] ** -0.5
+        elif leaf in ('cls_token', 'pos_embed', 'temporal_embed', 'positional_embedding'):
+            t = 0.02 * torch.randn(shape, generator=g)
+        elif name == 'token_embedding.weight':
+            t = 0.02 * torch.randn(shape, generator=g)
+        elif 'patch_embed' in name:
+            t = torch.randn(shape, generator=g) * (shape[1] * shape[2] * shape[3]) ** -0.5
+        else:                                               # Linear / in_proj weights [out, in]
+            t = torch.randn(shape, generator=g) * shape[-1] ** -0.5
+        out[name] = t
+    return out

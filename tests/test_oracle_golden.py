@@ -1,0 +1,70 @@
+"""CPU: pins oracle/oracle.py (the restatement) against the committed outputs of the real
+reference (tests/golden/*.pt, made by oracle/gen_golden.py). Tolerances are fp32 round-off."""
+import pytest
+import torch
+
+from oracle import oracle as O
+from oracle.gen_golden import synthetic_inputs
+from conftest import load_golden
+
+MODELS = ['tiny_p16', 'tiny_p14_gated', 'config1_tsfb_112']
+
+
+@pytest.mark.parametrize('case', range(4))
+@pytest.mark.parametrize('mode', ['space', 'time'])
+def test_var_attention_matches_reference(case, mode):
+    rec = load_golden('var_attention.pt')[case]
+    w = O.procedural_weights(rec['shapes'], seed=11)
+    x = rec['x'].clone().requires_grad_(True)
+    ws = {k: v.clone().requires_grad_(True) for k, v in w.items()}
+    y = O.var_attention(x, ws, '', rec['H'], rec['F'], rec['N'], mode)
+    y.backward(rec['gout'])
+    torch.testing.assert_close(y.detach(), rec[mode]['y'], atol=2e-5, rtol=1e-4)
+    torch.testing.assert_close(x.grad, rec[mode]['dx'], atol=2e-5, rtol=1e-4)
+    for k, g in rec[mode]['dw'].items():
+        torch.testing.assert_close(ws[k].grad, g, atol=5e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize('name', MODELS)
+def test_full_model_matches_reference(name):
+    fx = load_golden(f'model_{name}.pt')
+    c = fx['config']
+    w = {k: v.requires_grad_(v.is_floating_point())
+         for k, v in O.procedural_weights(fx['shapes'], seed=fx['weight_seed']).items()}
+    video, tokens = synthetic_inputs(c, seed=fx['input_seed'])
+    out = O.clip_forward(video, tokens, w, c['heads'], c['t_heads'], norm_embed=True)
+    torch.testing.assert_close(out['image_embed'], fx['image_embed'], atol=1e-5, rtol=1e-4)
+    torch.testing.assert_close(out['text_embed'], fx['text_embed'], atol=1e-5, rtol=1e-4)
+    ld = O.clip_loss(out['image_embed'], out['text_embed'], out['logit_scale'])
+    torch.testing.assert_close(ld['logits_per_image'], fx['logits_per_image'], atol=1e-4, rtol=1e-4)
+    torch.testing.assert_close(ld['loss'], fx['loss'], atol=1e-5, rtol=1e-5)
+    assert torch.equal(ld['labels'], fx['labels'])          # int64, bit-exact
+    assert torch.equal(ld['pred'], fx['pred'])
+    torch.testing.assert_close(ld['clip_acc'], fx['clip_acc'])
+    ld['loss'].backward()
+    for k, g in fx['grads'].items():
+        torch.testing.assert_close(w[k].grad, g, atol=2e-5, rtol=2e-3, msg=lambda m: f'{k}: {m}')
+    if 'grad_norms' in fx:
+        for k, n in fx['grad_norms'].items():
+            assert abs(w[k].grad.norm().item() - n) <= 2e-3 * n + 1e-7, k
+
+
+def test_multirank_loss_equals_single_process_on_concatenation():
+    """every rank's CLIPLoss equals the single-process loss on the rank-ordered
+    concatenation; vissl local grads = W x the global-loss gradient slice, non-vissl = 1 x."""
+    fx = load_golden('clip_loss_multirank.pt')
+    for (world, use_vissl), r in fx['results'].items():
+        g = torch.Generator().manual_seed(fx['seed'])
+        G = world * fx['B_local']
+        img = O.l2_normalize(torch.randn(G, fx['E'], generator=g)).requires_grad_(True)
+        txt = O.l2_normalize(torch.randn(G, fx['E'], generator=g)).requires_grad_(True)
+        scale = torch.tensor(fx['scale']).requires_grad_(True)
+        ld = O.clip_loss(img, txt, scale)
+        ld['loss'].backward()
+        for rank in range(world):
+            assert abs(r['loss'][rank] - ld['loss'].item()) < 1e-6
+            assert abs(r['acc'][rank] - ld['clip_acc'].item()) < 1e-4
+            assert abs(r['dscale'][rank] - scale.grad.item()) < 1e-6
+        mult = world if use_vissl else 1
+        torch.testing.assert_close(r['dimg'], mult * img.grad, atol=1e-6, rtol=1e-5)
+        torch.testing.assert_close(r['dtxt'], mult * txt.grad, atol=1e-6, rtol=1e-5)
