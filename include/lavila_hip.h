@@ -1,0 +1,138 @@
+/*
+ * lavila_hip.h -- C ABI of liblavila_hip.so: the MI355X (gfx950) hot kernels of the LaViLa
+ * dual-encoder pretraining path.
+ *
+ * The reference (facebookresearch/LaViLa) has no native layer: every entry point below replaces a
+ * span of stock torch ops inside a reference Python function (cited per function, paths relative
+ * to the reference root). The host-side mirror of the reference API (the lavila_amd python package) binds these
+ * through ctypes; INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers + sizes; all pointers are DEVICE pointers (HBM) unless stated otherwise
+ *   - `dtype` selects the activation element type: LVL_F32 (parity path) or LVL_BF16 (perf path);
+ *     statistics, parameters (gamma/beta/bias/pos-embeds) and workspaces are always float32
+ *   - row-major, innermost dimension contiguous, base pointers 16-byte aligned
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous and stream-ordered,
+ *     never allocates, never synchronises, and is hipGraph-capturable
+ *   - return value: 0 on success, negative LVL_E* otherwise (lvl_last_error() gives the text);
+ *     nothing is thrown across the boundary
+ *   - head dimension is fixed at 64 (all CLIP_OPENAI_TIMESFORMER_* configs: 768/12 = 1024/16 = 64)
+ */
+#ifndef LAVILA_HIP_H
+#define LAVILA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { LVL_F32 = 0, LVL_BF16 = 1 };
+enum { LVL_OK = 0, LVL_EINVAL = -22, LVL_ENOSYS = -38, LVL_EHIP = -5 };
+enum { LVL_ATTN_SPACE = 0, LVL_ATTN_TIME = 1 };
+
+/* library identification / diagnostics (host pointers) */
+const char* lvl_version(void);
+const char* lvl_last_error(void);
+/* number of float32 workspace elements a call needs (host-side query, no device work) */
+int64_t lvl_workspace_floats(const char* op, int64_t rows, int64_t cols);
+
+/* ---- LayerNorm (optionally fused with the residual add that feeds it) ------------------------------
+ * replaces F.layer_norm in ln_pre (timesformer.py:263-264,365-366; eps 1e-5), norm1/2/3 + norm
+ * (timesformer.py:247,153,166,169,277,377; eps 1e-6), text ln_1/ln_2/ln_final
+ * (openai_model.py:187,193; models.py:106,156; eps 1e-5), and -- when x2/xbias are given -- the
+ * residual adds of SpaceTimeBlock.forward (timesformer.py:183,192,196) and
+ * ResidualAttentionBlock.forward (openai_model.py:206-216) that produce the LayerNorm input.
+ *
+ * forward:  s = x (+ x2) (+ xbias);  y = (s - mean(s)) * rstd(s) * gamma + beta
+ *   x, x2 (nullable), y: [rows, cols] dtype; xbias (nullable), gamma, beta: [cols] f32;
+ *   s_out (nullable): [rows, cols] dtype, receives s (rounded to dtype; the statistics then use the
+ *   rounded value so forward and backward agree); mean, rstd (nullable): [rows] f32.
+ * backward: with s recomputed as x (+ x2) (+ xbias) exactly as in forward (pass the saved s_out as x
+ *   and x2 = xbias = NULL when it was kept):
+ *   dx = rstd * (dy*gamma - mean(dy*gamma) - shat * mean(dy*gamma*shat)) (+ dadd)
+ *   dgamma = sum_rows dy*shat, dbeta = sum_rows dy, dxsum (nullable) = sum_rows dx (= d xbias).
+ *   dadd (nullable): [rows, cols] dtype, extra gradient arriving at s through s_out.
+ * cols % 8 == 0, cols <= 4096. bwd workspace: lvl_workspace_floats("layernorm_bwd", rows, cols). */
+int lvl_layernorm_fwd(const void* x, const void* x2, const float* xbias, const float* gamma,
+                      const float* beta, void* s_out, void* y, float* mean, float* rstd,
+                      int64_t rows, int cols, float eps, int dtype, void* stream);
+int lvl_layernorm_bwd(const void* dy, const void* x, const void* x2, const float* xbias,
+                      const float* gamma, const float* mean, const float* rstd, const void* dadd,
+                      void* dx, float* dgamma, float* dbeta, float* dxsum, float* ws, int64_t rows,
+                      int cols, int dtype, void* stream);
+
+/* ---- bias + QuickGELU --------------------------------------------------------------------------
+ * a = (u + bias) * sigmoid(1.702 (u + bias)); replaces the bias add of Mlp.fc1 / mlp.c_fc and
+ * QuickGELU.forward (openai_model.py:177-179; timesformer.py:52-54). u,a,da,du: [rows, cols] dtype;
+ * bias,dbias: [cols] f32 (bias may be NULL -> treated as 0, dbias may be NULL). cols % 8 == 0.
+ * bwd workspace: lvl_workspace_floats("bias_quickgelu_bwd", rows, cols). */
+int lvl_bias_quickgelu_fwd(const void* u, const float* bias, void* a, int64_t rows, int cols,
+                           int dtype, void* stream);
+int lvl_bias_quickgelu_bwd(const void* da, const void* u, const float* bias, void* du, float* dbias,
+                           float* ws, int64_t rows, int cols, int dtype, void* stream);
+
+/* ---- patch embedding, gather side ----------------------------------------------------------------
+ * video [B,C,F,H,W] f32 (the batch contract of datasets.py:360-387) -> patch matrix
+ * [B*F*N, C*P*P] dtype, rows frame-major then (py,px), columns (c,i,j) = Conv2d weight flattening.
+ * Replaces permute(0,2,1,3,4).contiguous() (timesformer.py:387) and the im2col half of
+ * nn.Conv2d(k=stride=P) (timesformer.py:77,79-84); the contraction with the [D, C*P*P] weight is a
+ * plain GEMM. H % P == 0, W % P == 0. */
+int lvl_patchify(const float* video, void* patches, int B, int C, int F, int H, int W, int P,
+                 int dtype, void* stream);
+
+/* ---- token assembly: cls concat + positional/temporal embedding add --------------------------------
+ * x[b,0,:] = cls + pos[0];  x[b,1+f*N+n,:] = pe[b,f*N+n,:] + pos[1+n] + temporal[f]
+ * (timesformer.py:353-364). pe: [B,F*N,D] dtype; cls: [D], pos: [N+1,D], temporal: [>=F,D] f32;
+ * x: [B,1+F*N,D] dtype. D % 8 == 0. */
+int lvl_embed_tokens_fwd(const void* pe, const float* cls, const float* pos, const float* temporal,
+                         void* x, int B, int F, int N, int D, int dtype, void* stream);
+
+/* ---- divided space-time attention core ---------------------------------------------------------------
+ * Everything in VarAttention.forward between the qkv Linear and the proj Linear
+ * (timesformer.py:110-140 incl. attn() :35-39): head split, q *= 64^-0.5, CLS query over all T
+ * keys, patch queries grouped per frame (LVL_ATTN_SPACE: N queries x [cls + N] keys) or per
+ * location (LVL_ATTN_TIME: F queries x [cls + F] keys), softmax in f32, heads merged.
+ * qkv: [B,T,3*H*64] dtype (T = 1+F*N; q|k|v thirds, head-major inside each third);
+ * out/dout: [B,T,H*64] dtype; lse: [B,H,T] f32 (log-sum-exp of every query row, saved for backward);
+ * dqkv: [B,T,3*H*64] dtype. bwd workspace: lvl_workspace_floats("divided_attn_bwd", B*H, T). */
+int lvl_divided_attn_fwd(const void* qkv, void* out, float* lse, int B, int F, int N, int H,
+                         int mode, int dtype, void* stream);
+int lvl_divided_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
+                         void* dqkv, float* ws, int B, int F, int N, int H, int mode, int dtype,
+                         void* stream);
+
+/* ---- causal self-attention core of the text tower -------------------------------------------------------
+ * nn.MultiheadAttention core with the additive causal mask (openai_model.py:196-198,
+ * models.py:131-137) on packed qkv [B,L,3*H*64] (batch-major; the reference's LND permutes
+ * models.py:153,155 are folded away). out: [B,L,H*64]; lse: [B,H,L].
+ * bwd workspace: lvl_workspace_floats("causal_attn_bwd", B*H, L). */
+int lvl_causal_attn_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, int dtype,
+                        void* stream);
+int lvl_causal_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
+                        void* dqkv, float* ws, int B, int L, int H, int dtype, void* stream);
+
+/* ---- contrastive (InfoNCE) head ------------------------------------------------------------------------------
+ * Slab formulation of CLIPLoss.forward (loss.py:69-118): this rank owns global rows
+ * [row0, row0+B). Direction 0: logits_per_image rows = (scale*img_local) @ txt_all^T; direction 1:
+ * logits_per_text rows = (scale*txt_local) @ img_all^T (loss.py:78-79,92-93).
+ * img_all/txt_all: [G,E] dtype (rank-ordered all-gather, distributed_utils.py:88); the local slabs
+ * are rows [row0,row0+B) of them. E % 8 == 0. scale: DEVICE pointer to exp(logit_scale) (1 float, so
+ * the host never synchronises on it).
+ * stats: [2,B,4] f32 = {lse, diag logit, sum_j softmax_j * logit_j, max logit};
+ * argmax: [2,B] int32 (first maximal column -- torch.argmax tie rule; loss.py:113);
+ * logits (optional, may be NULL): [2,B,G] f32 slab of the scaled logits (for parity checks).
+ * bwd: lse_all [2,G] f32 = gathered row LSEs of both directions; upstream (nullable): DEVICE pointer
+ * to d(objective)/d(loss); coef: host factor mult/(2G). Writes coef*upstream*d(sum of both CE
+ * sums)/d(img_local | txt_local): [B,E] f32. No gradient collective is needed. */
+int lvl_clip_loss_fwd(const void* img_all, const void* txt_all, const float* scale, int B, int G,
+                      int E, int row0, float* stats, int32_t* argmax, float* logits, int dtype,
+                      void* stream);
+int lvl_clip_loss_bwd(const void* img_all, const void* txt_all, const float* lse_all,
+                      const float* scale, const float* upstream, float coef, int B, int G, int E,
+                      int row0, float* dimg, float* dtxt, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LAVILA_HIP_H */

@@ -1,0 +1,77 @@
+"""Builds lavila_amd/lib/liblavila_hip.so from lavila_amd/csrc/*.hip with hipcc for gfx950.
+
+The library depends only on the HIP runtime (no torch, no python): it is the C-ABI drop-in boundary
+declared in include/lavila_hip.h. hipcc cross-compiles without a GPU, so this runs in the build
+container; the resulting .so travels to the GPU box with the source tree.
+"""
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+LIBDIR = os.path.join(HERE, 'lib')
+LIB = os.path.join(LIBDIR, 'liblavila_hip.so')
+ARCH = 'gfx950'
+
+
+def _hipcc():
+    for cand in (os.environ.get('HIPCC'), shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError('hipcc not found (needed to build liblavila_hip.so)')
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hip'))
+
+
+def _digest():
+    h = hashlib.sha256()
+    for p in sources() + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')) + \
+            [os.path.join(HERE, '..', 'include', 'lavila_hip.h')]:
+        with open(p, 'rb') as f:
+            h.update(p.encode() + b'\0' + f.read())
+    return h.hexdigest()
+
+
+def build(force=False, verbose=True):
+    os.makedirs(LIBDIR, exist_ok=True)
+    stamp = os.path.join(LIBDIR, 'build.stamp')
+    dig = _digest()
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
+        return LIB
+    hipcc = _hipcc()
+    objs = []
+    procs = []
+    for src in sources():
+        obj = os.path.join(LIBDIR, os.path.basename(src)[:-4] + '.o')
+        cmd = [hipcc, f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wall',
+               '-Wno-unused-function', '-c', src, '-o', obj]
+        if verbose:
+            print('[lavila_amd.build]', ' '.join(cmd), flush=True)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        objs.append(obj)
+    failed = False
+    for src, p in procs:
+        out, _ = p.communicate()
+        if out.strip() and (verbose or p.returncode):
+            print(out)
+        if p.returncode:
+            failed = True
+            print(f'[lavila_amd.build] FAILED: {src}', file=sys.stderr)
+    if failed:
+        raise RuntimeError('hipcc failed')
+    cmd = [hipcc, f'--offload-arch={ARCH}', '-shared', '-fPIC', '-o', LIB] + objs
+    if verbose:
+        print('[lavila_amd.build]', ' '.join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    with open(stamp, 'w') as f:
+        f.write(dig)
+    return LIB
+
+
+if __name__ == '__main__':
+    print(build(force='--force' in sys.argv))

@@ -1,0 +1,57 @@
+// C-ABI dispatch for the attention entry points: picks the MFMA / register-tiled fast kernels when
+// the shape and dtype allow, otherwise the shape-generic f32-arithmetic kernels (attn_generic.hip).
+#include "common.h"
+
+int lvl_generic_divided_fwd(const void* qkv, void* out, float* lse, int B, int F, int N, int H, int mode, int dtype,
+                            hipStream_t st, bool do_groups, bool do_cls);
+int lvl_generic_divided_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
+                            float* ws, int B, int F, int N, int H, int mode, int dtype, hipStream_t st);
+int lvl_generic_causal_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, int dtype, hipStream_t st);
+int lvl_generic_causal_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
+                           float* ws, int B, int L, int H, int dtype, hipStream_t st);
+
+static int check_divided(const char* name, const void* qkv, const void* out, int B, int F, int N, int H, int mode,
+                         int dtype) {
+  LVL_REQUIRE(qkv && out, "%s: null pointer", name);
+  LVL_REQUIRE(B >= 0 && F > 0 && N > 0 && H > 0, "%s: bad shape B=%d F=%d N=%d H=%d", name, B, F, N, H);
+  LVL_REQUIRE(mode == LVL_ATTN_SPACE || mode == LVL_ATTN_TIME, "%s: unknown mode %d", name, mode);
+  LVL_REQUIRE(dtype == LVL_F32 || dtype == LVL_BF16, "%s: unknown dtype %d", name, dtype);
+  LVL_REQUIRE(lvl_aligned16(qkv) && lvl_aligned16(out), "%s: pointers must be 16-byte aligned", name);
+  return LVL_OK;
+}
+
+extern "C" int lvl_divided_attn_fwd(const void* qkv, void* out, float* lse, int B, int F, int N, int H, int mode,
+                                    int dtype, void* stream) {
+  if (int rc = check_divided("divided_attn_fwd", qkv, out, B, F, N, H, mode, dtype)) return rc;
+  LVL_REQUIRE(lse, "divided_attn_fwd: null lse");
+  if (B == 0) return LVL_OK;
+  return lvl_generic_divided_fwd(qkv, out, lse, B, F, N, H, mode, dtype, (hipStream_t)stream, true, true);
+}
+
+extern "C" int lvl_divided_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
+                                    float* ws, int B, int F, int N, int H, int mode, int dtype, void* stream) {
+  if (int rc = check_divided("divided_attn_bwd", qkv, out, B, F, N, H, mode, dtype)) return rc;
+  LVL_REQUIRE(dout && lse && dqkv && ws, "divided_attn_bwd: null pointer");
+  LVL_REQUIRE(lvl_aligned16(dout) && lvl_aligned16(dqkv), "divided_attn_bwd: pointers must be 16-byte aligned");
+  if (B == 0) return LVL_OK;
+  return lvl_generic_divided_bwd(qkv, out, dout, lse, dqkv, ws, B, F, N, H, mode, dtype, (hipStream_t)stream);
+}
+
+extern "C" int lvl_causal_attn_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, int dtype,
+                                   void* stream) {
+  LVL_REQUIRE(qkv && out && lse, "causal_attn_fwd: null pointer");
+  LVL_REQUIRE(B >= 0 && L > 0 && H > 0, "causal_attn_fwd: bad shape B=%d L=%d H=%d", B, L, H);
+  LVL_REQUIRE(lvl_aligned16(qkv) && lvl_aligned16(out), "causal_attn_fwd: pointers must be 16-byte aligned");
+  if (B == 0) return LVL_OK;
+  return lvl_generic_causal_fwd(qkv, out, lse, B, L, H, dtype, (hipStream_t)stream);
+}
+
+extern "C" int lvl_causal_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
+                                   float* ws, int B, int L, int H, int dtype, void* stream) {
+  LVL_REQUIRE(qkv && out && dout && lse && dqkv && ws, "causal_attn_bwd: null pointer");
+  LVL_REQUIRE(B >= 0 && L > 0 && H > 0, "causal_attn_bwd: bad shape B=%d L=%d H=%d", B, L, H);
+  LVL_REQUIRE(lvl_aligned16(qkv) && lvl_aligned16(out) && lvl_aligned16(dout) && lvl_aligned16(dqkv),
+              "causal_attn_bwd: pointers must be 16-byte aligned");
+  if (B == 0) return LVL_OK;
+  return lvl_generic_causal_bwd(qkv, out, dout, lse, dqkv, ws, B, L, H, dtype, (hipStream_t)stream);
+}

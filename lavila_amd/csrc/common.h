@@ -1,0 +1,103 @@
+// Shared device/host helpers for the gfx950 kernels. CDNA4 only: wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/lavila_hip.h"
+
+#define LVL_WAVE 64
+
+// ---------------------------------------------------------------------------------------------
+// host-side status plumbing
+// ---------------------------------------------------------------------------------------------
+extern thread_local char lvl_err_buf[512];
+int lvl_fail(int code, const char* fmt, ...);
+
+#define LVL_REQUIRE(cond, ...)                                   \
+  do {                                                           \
+    if (!(cond)) return lvl_fail(LVL_EINVAL, __VA_ARGS__);       \
+  } while (0)
+
+#define LVL_CHECK_LAUNCH(name)                                                       \
+  do {                                                                               \
+    hipError_t e__ = hipGetLastError();                                              \
+    if (e__ != hipSuccess) return lvl_fail(LVL_EHIP, "%s: %s", name, hipGetErrorString(e__)); \
+  } while (0)
+
+static inline bool lvl_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// ---------------------------------------------------------------------------------------------
+// element types. bf16 is carried as raw uint16 bits; arithmetic is always f32.
+// ---------------------------------------------------------------------------------------------
+struct bf16_t { uint16_t bits; };
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {   // round-to-nearest-even, NaN preserved
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static __device__ __forceinline__ float load(const float* p) { return *p; }
+  static __device__ __forceinline__ void store(float* p, float v) { *p = v; }
+  static __device__ __forceinline__ float round(float v) { return v; }
+  // 8 consecutive elements, 16-byte aligned pairs
+  static __device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    const float4 b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  }
+  static __device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  }
+};
+template <> struct Elem<bf16_t> {
+  static __device__ __forceinline__ float load(const bf16_t* p) { return bf16_to_f32(p->bits); }
+  static __device__ __forceinline__ void store(bf16_t* p, float v) { p->bits = f32_to_bf16(v); }
+  static __device__ __forceinline__ float round(float v) { return bf16_to_f32(f32_to_bf16(v)); }
+  static __device__ __forceinline__ void load8(const bf16_t* p, float (&v)[8]) {
+    const uint4 a = *reinterpret_cast<const uint4*>(p);
+    v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xffff0000u);
+    v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xffff0000u);
+    v[4] = __uint_as_float(a.z << 16); v[5] = __uint_as_float(a.z & 0xffff0000u);
+    v[6] = __uint_as_float(a.w << 16); v[7] = __uint_as_float(a.w & 0xffff0000u);
+  }
+  static __device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
+    uint4 a;
+    a.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+    a.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+    a.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
+    a.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+    *reinterpret_cast<uint4*>(p) = a;
+  }
+};
+
+__device__ __forceinline__ void load8_f32(const float* p, float (&v)[8]) { Elem<float>::load8(p, v); }
+
+// ---------------------------------------------------------------------------------------------
+// wave-level (64-lane) reductions; every lane receives the result
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// dispatch on the runtime dtype tag
+#define LVL_DISPATCH_DTYPE(dtype, ...)                                   \
+  do {                                                                   \
+    if ((dtype) == LVL_F32) { using T = float; __VA_ARGS__; }            \
+    else if ((dtype) == LVL_BF16) { using T = bf16_t; __VA_ARGS__; }     \
+    else return lvl_fail(LVL_EINVAL, "unknown dtype %d", (int)(dtype));  \
+  } while (0)

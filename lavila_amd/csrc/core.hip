@@ -1,0 +1,29 @@
+// Library identification, error text and workspace sizing (host-only code).
+#include <stdarg.h>
+
+#include "common.h"
+
+thread_local char lvl_err_buf[512] = "";
+
+int lvl_fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(lvl_err_buf, sizeof(lvl_err_buf), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+int lvl_ln_bwd_parts();
+int lvl_gelu_bwd_row_blocks();
+
+extern "C" const char* lvl_version(void) { return "lavila_hip 0.1 (gfx950)"; }
+extern "C" const char* lvl_last_error(void) { return lvl_err_buf; }
+
+extern "C" int64_t lvl_workspace_floats(const char* op, int64_t rows, int64_t cols) {
+  if (!op) return -1;
+  if (!strcmp(op, "layernorm_bwd")) return (int64_t)lvl_ln_bwd_parts() * 3 * cols;
+  if (!strcmp(op, "bias_quickgelu_bwd")) return (int64_t)lvl_gelu_bwd_row_blocks() * cols;
+  if (!strcmp(op, "divided_attn_bwd")) return rows * cols;   // delta [B*H, T]
+  if (!strcmp(op, "causal_attn_bwd")) return rows * cols;    // delta [B*H, L]
+  return -1;
+}

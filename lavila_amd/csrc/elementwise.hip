@@ -1,0 +1,238 @@
+// bias+QuickGELU (fwd/bwd), patch gather (patchify) and token assembly, gfx950.
+// All HBM-bound single-pass kernels: 16 B per lane, consecutive lanes on consecutive vectors.
+#include "common.h"
+
+int lvl_launch_column_reduce(const float* part, int nparts, int width, int seg, float* out0, float* out1,
+                             float* out2, hipStream_t st);
+
+namespace {
+
+constexpr int kGeluBwdRowBlocks = 256;   // partial dbias slabs
+
+__device__ __forceinline__ float sigmoidf_fast(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+// ---- a = (u+b) * sigmoid(1.702 (u+b)) -----------------------------------------------------------
+// 2-D mapping: thread owns one 8-wide vector column, walks rows with stride gridDim.y, so the bias
+// vector is loaded once and (in bwd) the per-column dbias partial stays in registers.
+template <typename T>
+__global__ __launch_bounds__(128) void bias_gelu_fwd_kernel(const T* __restrict__ u, const float* __restrict__ bias,
+                                                            T* __restrict__ a, int64_t rows, int cols) {
+  const int vc = blockIdx.x * blockDim.x + threadIdx.x;
+  if (vc * 8 >= cols) return;
+  float b[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (bias) load8_f32(bias + vc * 8, b);
+  for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
+    float x[8], o[8];
+    Elem<T>::load8(u + r * cols + vc * 8, x);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float y = x[j] + b[j];
+      o[j] = y * sigmoidf_fast(1.702f * y);
+    }
+    Elem<T>::store8(a + r * cols + vc * 8, o);
+  }
+}
+
+// du = da * (s + 1.702 y s (1-s)),  s = sigmoid(1.702 y), y = u+b;  dbias = column sums of du
+template <typename T>
+__global__ __launch_bounds__(128) void bias_gelu_bwd_kernel(const T* __restrict__ da, const T* __restrict__ u,
+                                                            const float* __restrict__ bias, T* __restrict__ du,
+                                                            float* __restrict__ part, int64_t rows, int cols) {
+  const int vc = blockIdx.x * blockDim.x + threadIdx.x;
+  if (vc * 8 >= cols) return;
+  float b[8] = {0, 0, 0, 0, 0, 0, 0, 0}, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (bias) load8_f32(bias + vc * 8, b);
+  for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
+    float x[8], g[8], o[8];
+    Elem<T>::load8(u + r * cols + vc * 8, x);
+    Elem<T>::load8(da + r * cols + vc * 8, g);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float y = x[j] + b[j];
+      const float s = sigmoidf_fast(1.702f * y);
+      o[j] = g[j] * (s + 1.702f * y * s * (1.0f - s));
+      acc[j] += Elem<T>::round(o[j]);      // dbias sums what the weight-grad GEMM will see
+    }
+    Elem<T>::store8(du + r * cols + vc * 8, o);
+  }
+  if (part) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) part[(size_t)blockIdx.y * cols + vc * 8 + j] = acc[j];
+  }
+}
+
+// ---- patchify: [B,C,F,H,W] f32 -> [B*F*gh*gw, C*P*P] -------------------------------------------------
+// thread = one patch row (P pixels). Thread order follows the INPUT (.., y, px) so reads of a full
+// image row are contiguous across the wave; each thread writes P contiguous output elements.
+template <typename T, int P>
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ video, T* __restrict__ out, int B,
+                                                       int C, int F, int H, int W) {
+  const int gw = W / P, gh = H / P;
+  const int64_t total = (int64_t)B * C * F * H * gw;
+  for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total;
+       id += (int64_t)gridDim.x * blockDim.x) {
+    int64_t t = id;
+    const int px = (int)(t % gw); t /= gw;
+    const int y = (int)(t % H); t /= H;
+    const int f = (int)(t % F); t /= F;
+    const int c = (int)(t % C); t /= C;
+    const int b = (int)t;
+    const int py = y / P, i = y - py * P;
+    const float* src = video + ((((int64_t)b * C + c) * F + f) * H + y) * W + (int64_t)px * P;
+    const int64_t m = (((int64_t)b * F + f) * gh + py) * gw + px;
+    T* dst = out + m * ((int64_t)C * P * P) + ((int64_t)c * P + i) * P;
+    if constexpr (P % 8 == 0) {
+#pragma unroll
+      for (int j = 0; j < P; j += 8) {
+        float v[8];
+        load8_f32(src + j, v);
+        Elem<T>::store8(dst + j, v);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < P; j += 2) {   // P even: 8-byte reads (14 px * 4 B = 56 B rows are 8-B aligned)
+        const float2 v = *reinterpret_cast<const float2*>(src + j);
+        Elem<T>::store(dst + j, v.x);
+        Elem<T>::store(dst + j + 1, v.y);
+      }
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void patchify_generic_kernel(const float* __restrict__ video, T* __restrict__ out,
+                                                               int B, int C, int F, int H, int W, int P) {
+  const int gw = W / P, gh = H / P;
+  const int64_t total = (int64_t)B * C * F * H * W;
+  for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total;
+       id += (int64_t)gridDim.x * blockDim.x) {
+    int64_t t = id;
+    const int x = (int)(t % W); t /= W;
+    const int y = (int)(t % H); t /= H;
+    const int f = (int)(t % F); t /= F;
+    const int c = (int)(t % C); t /= C;
+    const int b = (int)t;
+    const int py = y / P, i = y - py * P, px = x / P, j = x - px * P;
+    const int64_t m = (((int64_t)b * F + f) * gh + py) * gw + px;
+    Elem<T>::store(out + m * ((int64_t)C * P * P) + ((int64_t)c * P + i) * P + j, video[id]);
+  }
+}
+
+// ---- token assembly --------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void embed_tokens_kernel(const T* __restrict__ pe, const float* __restrict__ cls,
+                                                           const float* __restrict__ pos,
+                                                           const float* __restrict__ temporal, T* __restrict__ x,
+                                                           int B, int F, int N, int D) {
+  const int nvec = D >> 3;
+  const int T_ = 1 + F * N;
+  const int64_t total = (int64_t)B * T_ * nvec;
+  for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total;
+       id += (int64_t)gridDim.x * blockDim.x) {
+    const int vc = (int)(id % nvec);
+    const int64_t bt = id / nvec;
+    const int t = (int)(bt % T_);
+    const int b = (int)(bt / T_);
+    float v[8], p[8];
+    if (t == 0) {
+      load8_f32(cls + vc * 8, v);
+      load8_f32(pos + vc * 8, p);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += p[j];
+    } else {
+      const int f = (t - 1) / N, n = (t - 1) - f * N;
+      float q[8];
+      Elem<T>::load8(pe + ((int64_t)b * F * N + (t - 1)) * D + vc * 8, v);
+      load8_f32(pos + (int64_t)(1 + n) * D + vc * 8, p);
+      load8_f32(temporal + (int64_t)f * D + vc * 8, q);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += p[j] + q[j];   // pos+temporal first, as timesformer.py:361
+    }
+    Elem<T>::store8(x + bt * D + vc * 8, v);
+  }
+}
+
+inline unsigned grid_for(int64_t total, int block) {
+  int64_t g = (total + block - 1) / block;
+  if (g > 16384) g = 16384;
+  if (g < 1) g = 1;
+  return (unsigned)g;
+}
+
+}  // namespace
+
+extern "C" int lvl_bias_quickgelu_fwd(const void* u, const float* bias, void* a, int64_t rows, int cols, int dtype,
+                                      void* stream) {
+  LVL_REQUIRE(u && a, "bias_quickgelu_fwd: null pointer");
+  LVL_REQUIRE(rows >= 0 && cols > 0 && cols % 8 == 0, "bias_quickgelu_fwd: cols=%d must be a multiple of 8", cols);
+  LVL_REQUIRE(lvl_aligned16(u) && lvl_aligned16(a) && lvl_aligned16(bias), "bias_quickgelu_fwd: pointers must be 16-byte aligned");
+  if (rows == 0) return LVL_OK;
+  const int vcols = cols / 8;
+  const unsigned gx = (vcols + 127) / 128;
+  int64_t gy = rows < 4096 / gx ? rows : 4096 / gx;
+  if (gy < 1) gy = 1;
+  LVL_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bias_gelu_fwd_kernel<T>), dim3(gx, (unsigned)gy), dim3(128), 0,
+                                               (hipStream_t)stream, (const T*)u, bias, (T*)a, rows, cols));
+  LVL_CHECK_LAUNCH("bias_quickgelu_fwd");
+  return LVL_OK;
+}
+
+extern "C" int lvl_bias_quickgelu_bwd(const void* da, const void* u, const float* bias, void* du, float* dbias,
+                                      float* ws, int64_t rows, int cols, int dtype, void* stream) {
+  LVL_REQUIRE(da && u && du, "bias_quickgelu_bwd: null pointer");
+  LVL_REQUIRE(dbias == nullptr || ws != nullptr, "bias_quickgelu_bwd: dbias needs a workspace");
+  LVL_REQUIRE(rows >= 0 && cols > 0 && cols % 8 == 0, "bias_quickgelu_bwd: cols=%d must be a multiple of 8", cols);
+  LVL_REQUIRE(lvl_aligned16(da) && lvl_aligned16(u) && lvl_aligned16(du) && lvl_aligned16(bias), "bias_quickgelu_bwd: pointers must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int vcols = cols / 8;
+  const unsigned gx = (vcols + 127) / 128;
+  int64_t gy = rows < kGeluBwdRowBlocks ? rows : kGeluBwdRowBlocks;
+  if (gy < 1) gy = 1;
+  LVL_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((bias_gelu_bwd_kernel<T>), dim3(gx, (unsigned)gy), dim3(128), 0, st,
+                                               (const T*)da, (const T*)u, bias, (T*)du, dbias ? ws : nullptr, rows,
+                                               cols));
+  LVL_CHECK_LAUNCH("bias_quickgelu_bwd");
+  if (dbias) return lvl_launch_column_reduce(ws, (int)gy, cols, cols, dbias, nullptr, nullptr, st);
+  return LVL_OK;
+}
+
+int lvl_gelu_bwd_row_blocks() { return kGeluBwdRowBlocks; }
+
+extern "C" int lvl_patchify(const float* video, void* patches, int B, int C, int F, int H, int W, int P, int dtype,
+                            void* stream) {
+  LVL_REQUIRE(video && patches, "patchify: null pointer");
+  LVL_REQUIRE(B >= 0 && C > 0 && F > 0 && H > 0 && W > 0 && P > 0 && H % P == 0 && W % P == 0,
+              "patchify: bad shape B=%d C=%d F=%d H=%d W=%d P=%d", B, C, F, H, W, P);
+  LVL_REQUIRE(lvl_aligned16(video) && lvl_aligned16(patches), "patchify: pointers must be 16-byte aligned");
+  if (B == 0) return LVL_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t rows_total = (int64_t)B * C * F * H * (W / P);
+  if (P == 16 && W % 4 == 0) {
+    LVL_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((patchify_kernel<T, 16>), dim3(grid_for(rows_total, 256)), dim3(256),
+                                                 0, st, video, (T*)patches, B, C, F, H, W));
+  } else if (P == 14 && W % 2 == 0 && dtype == LVL_BF16) {
+    hipLaunchKernelGGL((patchify_kernel<bf16_t, 14>), dim3(grid_for(rows_total, 256)), dim3(256), 0, st, video,
+                       (bf16_t*)patches, B, C, F, H, W);
+  } else {
+    LVL_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((patchify_generic_kernel<T>),
+                                                 dim3(grid_for((int64_t)B * C * F * H * W, 256)), dim3(256), 0, st,
+                                                 video, (T*)patches, B, C, F, H, W, P));
+  }
+  LVL_CHECK_LAUNCH("patchify");
+  return LVL_OK;
+}
+
+extern "C" int lvl_embed_tokens_fwd(const void* pe, const float* cls, const float* pos, const float* temporal,
+                                    void* x, int B, int F, int N, int D, int dtype, void* stream) {
+  LVL_REQUIRE(pe && cls && pos && temporal && x, "embed_tokens_fwd: null pointer");
+  LVL_REQUIRE(B >= 0 && F > 0 && N > 0 && D > 0 && D % 8 == 0, "embed_tokens_fwd: bad shape B=%d F=%d N=%d D=%d", B, F, N, D);
+  LVL_REQUIRE(lvl_aligned16(pe) && lvl_aligned16(cls) && lvl_aligned16(pos) && lvl_aligned16(temporal) && lvl_aligned16(x),
+              "embed_tokens_fwd: pointers must be 16-byte aligned");
+  if (B == 0) return LVL_OK;
+  const int64_t total = (int64_t)B * (1 + F * N) * (D / 8);
+  LVL_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((embed_tokens_kernel<T>), dim3(grid_for(total, 256)), dim3(256), 0,
+                                               (hipStream_t)stream, (const T*)pe, cls, pos, temporal, (T*)x, B, F, N,
+                                               D));
+  LVL_CHECK_LAUNCH("embed_tokens_fwd");
+  return LVL_OK;
+}

@@ -1,0 +1,279 @@
+// LayerNorm forward/backward, optionally fused with the residual(+bias) add that feeds it. gfx950.
+//
+// HBM-bound: one pass over [rows, cols]. One 64-lane wave owns one row at a time and keeps the
+// whole row in registers (cols <= 4096 -> <= 8 x 16-byte vectors per lane), so every operand is
+// read exactly once; statistics are the two-pass (mean, then centred variance) form in f32, matching
+// F.layer_norm. Loads/stores are 16 B per lane, consecutive lanes on consecutive vectors.
+// Algorithmic bytes per row (E = element size): fwd cols*E*(n_in + n_out), bwd cols*E*(1 + n_in + 1).
+#include "common.h"
+
+namespace {
+
+constexpr int kRowsPerBlock = 4;          // 4 waves per 256-thread workgroup
+constexpr int kLnBwdParts = 1024;         // partial dgamma/dbeta/dxsum slabs (one per workgroup)
+
+// s = x (+ x2) (+ bias), rounded to T when it is materialised
+template <typename T>
+__device__ __forceinline__ void load_sum8(const T* __restrict__ x, const T* __restrict__ x2,
+                                          const float* __restrict__ bias, int64_t off, int c8, float (&v)[8]) {
+  Elem<T>::load8(x + off, v);
+  if (x2 != nullptr) {
+    float w[8];
+    Elem<T>::load8(x2 + off, w);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] += w[j];
+  }
+  if (bias != nullptr) {
+    float bb[8];
+    load8_f32(bias + c8, bb);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] += bb[j];
+  }
+}
+
+template <typename T, int VPL>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(
+    const T* __restrict__ x, const T* __restrict__ x2, const float* __restrict__ bias,
+    const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ s_out,
+    T* __restrict__ out, float* __restrict__ mean, float* __restrict__ rstd, int64_t rows, int cols,
+    float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nvec = cols >> 3;
+  const float inv_cols = 1.0f / (float)cols;
+  for (int64_t row = (int64_t)blockIdx.x * kRowsPerBlock + wave; row < rows;
+       row += (int64_t)gridDim.x * kRowsPerBlock) {
+    float v[VPL][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int c = lane + i * 64;
+      if (c < nvec) {
+        load_sum8<T>(x, x2, bias, row * cols + c * 8, c * 8, v[i]);
+        if (s_out != nullptr) {
+          Elem<T>::store8(s_out + row * cols + c * 8, v[i]);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[i][j] = Elem<T>::round(v[i][j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum += v[i][j];
+      }
+    }
+    const float mu = wave_sum(sum) * inv_cols;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      if (lane + i * 64 < nvec) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mu; sq += d * d; }
+      }
+    }
+    const float rs = rsqrtf(wave_sum(sq) * inv_cols + eps);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int c = lane + i * 64;
+      if (c < nvec) {
+        float g[8], b[8], o[8];
+        load8_f32(gamma + c * 8, g);
+        load8_f32(beta + c * 8, b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mu) * rs * g[j] + b[j];
+        Elem<T>::store8(out + row * cols + c * 8, o);
+      }
+    }
+    if (lane == 0) {
+      if (mean) mean[row] = mu;
+      if (rstd) rstd[row] = rs;
+    }
+  }
+}
+
+// dx = rstd * (dy*g - mean(dy*g) - shat * mean(dy*g*shat)) (+ dadd);
+// per-workgroup partial slabs [3][cols] = {sum dy*shat, sum dy, sum dx}
+template <typename T, int VPL>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(
+    const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ x2,
+    const float* __restrict__ bias, const float* __restrict__ gamma, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const T* __restrict__ dadd, T* __restrict__ dx,
+    float* __restrict__ part, int64_t rows, int cols) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [3 waves][3][cols]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nvec = cols >> 3;
+  const float inv_cols = 1.0f / (float)cols;
+  float g[VPL][8], ag[VPL][8], ab[VPL][8], ax[VPL][8];
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int c = lane + i * 64;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ag[i][j] = 0.f; ab[i][j] = 0.f; ax[i][j] = 0.f; g[i][j] = 0.f; }
+    if (c < nvec) load8_f32(gamma + c * 8, g[i]);
+  }
+  for (int64_t row = (int64_t)blockIdx.x * kRowsPerBlock + wave; row < rows;
+       row += (int64_t)gridDim.x * kRowsPerBlock) {
+    const float mu = mean[row], rs = rstd[row];
+    float xh[VPL][8], dg[VPL][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int c = lane + i * 64;
+      if (c < nvec) {
+        float xv[8], dv[8];
+        load_sum8<T>(x, x2, bias, row * cols + c * 8, c * 8, xv);
+        Elem<T>::load8(dy + row * cols + c * 8, dv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          xh[i][j] = (xv[j] - mu) * rs;
+          dg[i][j] = dv[j] * g[i][j];
+          s1 += dg[i][j];
+          s2 += dg[i][j] * xh[i][j];
+          ag[i][j] += dv[j] * xh[i][j];
+          ab[i][j] += dv[j];
+        }
+      }
+    }
+    const float c1 = wave_sum(s1) * inv_cols, c2 = wave_sum(s2) * inv_cols;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int c = lane + i * 64;
+      if (c < nvec) {
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = rs * (dg[i][j] - c1 - xh[i][j] * c2);
+        if (dadd != nullptr) {
+          float e[8];
+          Elem<T>::load8(dadd + row * cols + c * 8, e);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] += e[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ax[i][j] += Elem<T>::round(o[j]);
+        Elem<T>::store8(dx + row * cols + c * 8, o);
+      }
+    }
+  }
+  // combine the 4 waves of this workgroup, then one partial slab per workgroup
+  if (wave > 0) {
+    float* dst = smem + (size_t)(wave - 1) * 3 * cols;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int c = lane + i * 64;
+      if (c < nvec) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          dst[c * 8 + j] = ag[i][j];
+          dst[cols + c * 8 + j] = ab[i][j];
+          dst[2 * cols + c * 8 + j] = ax[i][j];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float* pg = part + (size_t)blockIdx.x * 3 * cols;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int c = lane + i * 64;
+      if (c < nvec) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float a = ag[i][j], b = ab[i][j], e = ax[i][j];
+          for (int w = 0; w < 3; ++w) {
+            a += smem[(size_t)w * 3 * cols + c * 8 + j];
+            b += smem[(size_t)w * 3 * cols + cols + c * 8 + j];
+            e += smem[(size_t)w * 3 * cols + 2 * cols + c * 8 + j];
+          }
+          pg[c * 8 + j] = a;
+          pg[cols + c * 8 + j] = b;
+          pg[2 * cols + c * 8 + j] = e;
+        }
+      }
+    }
+  }
+}
+
+// out_s[k - s*seg] = sum_p part[p][k] for k in segment s of width seg; thread per column.
+__global__ void column_reduce_kernel(const float* __restrict__ part, int nparts, int width, int seg,
+                                     float* __restrict__ out0, float* __restrict__ out1,
+                                     float* __restrict__ out2) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= width) return;
+  float acc = 0.f;
+  for (int p = 0; p < nparts; ++p) acc += part[(size_t)p * width + k];
+  const int s = k / seg;
+  float* o = s == 0 ? out0 : (s == 1 ? out1 : out2);
+  if (o) o[k - s * seg] = acc;
+}
+
+}  // namespace
+
+int lvl_ln_bwd_parts() { return kLnBwdParts; }
+
+// out0/out1/out2 receive consecutive `seg`-wide segments of the column sums of part[nparts][width]
+int lvl_launch_column_reduce(const float* part, int nparts, int width, int seg, float* out0, float* out1,
+                             float* out2, hipStream_t st) {
+  hipLaunchKernelGGL(column_reduce_kernel, dim3((width + 255) / 256), dim3(256), 0, st, part, nparts, width, seg,
+                     out0, out1, out2);
+  LVL_CHECK_LAUNCH("column_reduce");
+  return LVL_OK;
+}
+
+extern "C" int lvl_layernorm_fwd(const void* x, const void* x2, const float* xbias, const float* gamma,
+                                 const float* beta, void* s_out, void* y, float* mean, float* rstd, int64_t rows,
+                                 int cols, float eps, int dtype, void* stream) {
+  LVL_REQUIRE(x && gamma && beta && y, "layernorm_fwd: null pointer");
+  LVL_REQUIRE(rows >= 0 && cols > 0 && cols % 8 == 0 && cols <= 4096,
+              "layernorm_fwd: cols=%d must be a multiple of 8, <= 4096", cols);
+  LVL_REQUIRE(lvl_aligned16(x) && lvl_aligned16(x2) && lvl_aligned16(xbias) && lvl_aligned16(y) &&
+                  lvl_aligned16(s_out) && lvl_aligned16(gamma) && lvl_aligned16(beta),
+              "layernorm_fwd: pointers must be 16-byte aligned");
+  if (rows == 0) return LVL_OK;
+  int64_t blocks = (rows + kRowsPerBlock - 1) / kRowsPerBlock;
+  if (blocks > 8192) blocks = 8192;
+  const int nvec = cols / 8;
+#define LN_FWD(TT, VPL)                                                                                  \
+  hipLaunchKernelGGL((ln_fwd_kernel<TT, VPL>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, \
+                     (const TT*)x, (const TT*)x2, xbias, gamma, beta, (TT*)s_out, (TT*)y, mean, rstd, rows, \
+                     cols, eps)
+  LVL_DISPATCH_DTYPE(dtype, {
+    if (nvec <= 128) LN_FWD(T, 2);
+    else if (nvec <= 256) LN_FWD(T, 4);
+    else LN_FWD(T, 8);
+  });
+#undef LN_FWD
+  LVL_CHECK_LAUNCH("layernorm_fwd");
+  return LVL_OK;
+}
+
+extern "C" int lvl_layernorm_bwd(const void* dy, const void* x, const void* x2, const float* xbias,
+                                 const float* gamma, const float* mean, const float* rstd, const void* dadd,
+                                 void* dx, float* dgamma, float* dbeta, float* dxsum, float* ws, int64_t rows,
+                                 int cols, int dtype, void* stream) {
+  LVL_REQUIRE(dy && x && gamma && mean && rstd && dx && ws, "layernorm_bwd: null pointer");
+  LVL_REQUIRE(rows >= 0 && cols > 0 && cols % 8 == 0 && cols <= 4096,
+              "layernorm_bwd: cols=%d must be a multiple of 8, <= 4096", cols);
+  LVL_REQUIRE(lvl_aligned16(dy) && lvl_aligned16(x) && lvl_aligned16(x2) && lvl_aligned16(xbias) &&
+                  lvl_aligned16(dadd) && lvl_aligned16(dx) && lvl_aligned16(gamma),
+              "layernorm_bwd: pointers must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  int64_t blocks = (rows + kRowsPerBlock - 1) / kRowsPerBlock;
+  if (blocks > kLnBwdParts) blocks = kLnBwdParts;
+  if (blocks < 1) blocks = 1;
+  const int nvec = cols / 8;
+  const size_t shmem = (size_t)3 * 3 * cols * sizeof(float);
+#define LN_BWD(TT, VPL)                                                                                     \
+  do {                                                                                                      \
+    if (shmem > 64 * 1024)                                                                                  \
+      (void)hipFuncSetAttribute((const void*)ln_bwd_kernel<TT, VPL>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)shmem);                                                                \
+    hipLaunchKernelGGL((ln_bwd_kernel<TT, VPL>), dim3((unsigned)blocks), dim3(256), shmem, st, (const TT*)dy, \
+                       (const TT*)x, (const TT*)x2, xbias, gamma, mean, rstd, (const TT*)dadd, (TT*)dx, ws, rows, \
+                       cols);                                                                               \
+  } while (0)
+  LVL_DISPATCH_DTYPE(dtype, {
+    if (nvec <= 128) LN_BWD(T, 2);
+    else if (nvec <= 256) LN_BWD(T, 4);
+    else LN_BWD(T, 8);
+  });
+#undef LN_BWD
+  LVL_CHECK_LAUNCH("layernorm_bwd");
+  return lvl_launch_column_reduce(ws, (int)blocks, 3 * cols, cols, dgamma, dbeta, dxsum, st);
+}

@@ -1,0 +1,225 @@
+"""Model zoo / API of the dual encoder, mirroring `lavila/models/models.py` of the reference:
+`CLIP` (:75-173), `get_loss` (:293-304), `get_metric_names` (:307-313) and the named constructors
+`CLIP_OPENAI_TIMESFORMER_{BASE,LARGE,LARGE_336PX}` (:316-491) -- same names, kwargs (unknown kwargs are
+swallowed exactly as the reference's **kwargs do), output dict keys and state_dict keys, so that
+main_pretrain.py / eval_zeroshot.py drive it unchanged. Only the dual-encoder pretraining path is built
+(SURVEY.md section 8); narrator (VCLM_*), DistilBERT and fine-tuning heads are out of scope and absent.
+"""
+import contextlib
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import loss
+from .openai_model import QuickGELU, Transformer
+from .timesformer import LayerNorm, SpaceTimeTransformer
+from .utils import remap_keys, rsetattr  # noqa: F401  (re-exported like the reference)
+
+
+@contextlib.contextmanager
+def _amp_region():
+    """The reference drivers wrap forward+loss in torch.cuda.amp.autocast() = fp16 (main_pretrain.py:490).
+    The kernels are f32/bf16: an active fp16 autocast region is re-entered as bf16 (GradScaler stays
+    harmless: bf16 has f32's exponent range)."""
+    if torch.is_autocast_enabled() and torch.get_autocast_dtype('cuda') == torch.float16:
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            yield
+    else:
+        yield
+
+
+class CLIP(nn.Module):
+    def __init__(self,
+                 embed_dim: int,
+                 vision_width: int,
+                 vision_model: nn.Module,
+                 context_length: int,
+                 vocab_size: int,
+                 transformer_width: int,
+                 transformer_heads: int,
+                 transformer_layers: int,
+                 tempearture_init=0.07,      # [sic] the reference spells it this way (models.py:86)
+                 **kwargs):
+        super().__init__()
+        self.context_length = context_length
+        self.vision_width = vision_width
+        self.visual = vision_model
+        self.transformer = Transformer(width=transformer_width, layers=transformer_layers, heads=transformer_heads,
+                                       attn_mask=self.build_attention_mask())
+        self.vocab_size = vocab_size
+        self.token_embedding = nn.Embedding(vocab_size, transformer_width)
+        self.positional_embedding = nn.Parameter(torch.empty(self.context_length, transformer_width))
+        self.ln_final = LayerNorm(transformer_width)
+        self.image_projection = nn.Parameter(torch.empty(vision_width, embed_dim))
+        self.text_projection = nn.Parameter(torch.empty(transformer_width, embed_dim))
+        print("=> initialize initial temperature with {}".format(tempearture_init))
+        self.logit_scale = nn.Parameter(torch.ones([]) * np.log(1 / tempearture_init))
+        self.initialize_parameters()
+
+    def initialize_parameters(self):
+        """models.py:115-129"""
+        nn.init.normal_(self.token_embedding.weight, std=0.02)
+        nn.init.normal_(self.positional_embedding, std=0.01)
+        width, layers = self.transformer.width, self.transformer.layers
+        proj_std = (width ** -0.5) * ((2 * layers) ** -0.5)
+        for block in self.transformer.resblocks:
+            nn.init.normal_(block.attn.in_proj_weight, std=width ** -0.5)
+            nn.init.normal_(block.attn.out_proj.weight, std=proj_std)
+            nn.init.normal_(block.mlp.c_fc.weight, std=(2 * width) ** -0.5)
+            nn.init.normal_(block.mlp.c_proj.weight, std=proj_std)
+        nn.init.normal_(self.image_projection, std=self.vision_width ** -0.5)
+        nn.init.normal_(self.text_projection, std=width ** -0.5)
+
+    def build_attention_mask(self):
+        """Additive causal mask (models.py:131-137); the HIP kernel applies it analytically."""
+        mask = torch.empty(self.context_length, self.context_length)
+        mask.fill_(float("-inf"))
+        mask.triu_(1)
+        return mask
+
+    def encode_image(self, image, use_checkpoint=False, apply_project=True):
+        with _amp_region():
+            x = self.visual(image, use_checkpoint=use_checkpoint)
+            if isinstance(x, list):
+                assert len(x) == 1
+                x = x[0]
+            if not apply_project:
+                return x
+            return x @ self.image_projection
+
+    def encode_text(self, text, use_checkpoint=False):
+        with _amp_region():
+            x = self.token_embedding(text) + self.positional_embedding          # [B, L, W]
+            if torch.is_autocast_enabled():
+                x = x.to(torch.get_autocast_dtype('cuda'))
+            # only the EOT row (highest token id, models.py:158-160) of the last layer feeds the output
+            x = self.transformer.forward_batch_major(x, self.ln_final, use_checkpoint=use_checkpoint,
+                                                     rows=text.argmax(dim=-1))
+            return x @ self.text_projection
+
+    def forward(self, image, text, use_checkpoint=False, norm_embed=False):
+        image_embed = self.encode_image(image, use_checkpoint=use_checkpoint)
+        text_embed = self.encode_text(text, use_checkpoint=use_checkpoint)
+        if norm_embed:
+            image_embed = F.normalize(image_embed.float(), dim=-1)
+            text_embed = F.normalize(text_embed.float(), dim=-1)
+        return {'image_embed': image_embed,
+                'text_embed': text_embed,
+                'logit_scale': self.logit_scale.exp()}
+
+
+def get_loss(model, args, tokenizer=None):
+    if model.startswith('CLIP'):
+        return loss.CLIPLoss(use_vissl=args.contrastive_use_vissl, cache_labels=True, rank=args.rank,
+                             world_size=args.world_size)
+    raise NotImplementedError(f'{model}: only the CLIP_* dual-encoder path is built (SURVEY.md section 8)')
+
+
+def get_metric_names(model):
+    if model.startswith('CLIP'):
+        return ['loss', 'clip_loss', 'clip_acc']
+    raise NotImplementedError(f'{model}: only the CLIP_* dual-encoder path is built (SURVEY.md section 8)')
+
+
+# ------------------------------------------------------------------------------------------------------
+# named constructors
+# ------------------------------------------------------------------------------------------------------
+def load_openai_clip(name, device='cpu'):
+    """The reference downloads OpenAI CLIP weights here (openai_clip.py:104-146). Offline there is nothing to
+    download: a local TorchScript/state_dict file can be given through LAVILA_CLIP_WEIGHTS_DIR; otherwise the
+    caller keeps its (seeded) initialisation."""
+    root = os.environ.get('LAVILA_CLIP_WEIGHTS_DIR')
+    if not root:
+        return None
+    path = os.path.join(root, name.replace('/', '-') + '.pt')
+    if not os.path.isfile(path):
+        raise RuntimeError(f'Model {name} not found at {path}')
+    obj = torch.load(path, map_location=device, weights_only=False)
+    return obj.state_dict() if hasattr(obj, 'state_dict') else obj
+
+
+def _load_clip_weights(model, vision_model, clip_sd, layers, project_embed_dim):
+    """Copies OpenAI-CLIP weights the way models.py:329-370 does (vision via remap_keys, strict=False)."""
+    vis = {k[len('visual.'):]: v for k, v in clip_sd.items() if k.startswith('visual.')}
+    print(vision_model.load_state_dict(remap_keys(vis, transformer_layers=layers), strict=False))
+    model.transformer.load_state_dict({k[len('transformer.'):]: v for k, v in clip_sd.items()
+                                       if k.startswith('transformer.')})
+    model.token_embedding.load_state_dict({'weight': clip_sd['token_embedding.weight']})
+    model.positional_embedding.data.copy_(clip_sd['positional_embedding'])
+    model.ln_final.load_state_dict({'weight': clip_sd['ln_final.weight'], 'bias': clip_sd['ln_final.bias']})
+    if project_embed_dim == clip_sd['text_projection'].shape[1]:
+        print("=> Loading CLIP's text_projection, image_projection and logit_scale directly")
+        model.image_projection.data.copy_(clip_sd['visual.proj'])
+        model.text_projection.data.copy_(clip_sd['text_projection'])
+        model.logit_scale.data.copy_(clip_sd['logit_scale'])
+
+
+def _clip_openai_timesformer(clip_name, vision_kwargs, vision_width, text_width, text_heads, vision_layers,
+                             num_frames, timesformer_gated_xattn, drop_path_rate, timesformer_freeze_space,
+                             temperature_init, project_embed_dim, kwargs):
+    vision_model = SpaceTimeTransformer(
+        num_frames=num_frames, time_init='zeros', attention_style='frozen-in-time', ln_pre=True,
+        act_layer=QuickGELU, is_tanh_gating=timesformer_gated_xattn, drop_path_rate=drop_path_rate,
+        **vision_kwargs)
+    clip_sd = load_openai_clip(clip_name, 'cpu')
+    pretrained_names = set()
+    if clip_sd is not None:
+        print(f"=> Loading CLIP ({clip_name}) weights")
+        vis = {k[len('visual.'):]: v for k, v in clip_sd.items() if k.startswith('visual.')}
+        pretrained_names = set(remap_keys(dict(vis), transformer_layers=vision_layers).keys())
+    if timesformer_freeze_space:
+        print("=> Freeze the space part in TimeSformer")
+        freeze_list, unfreeze_list = [], []
+        for n, p in vision_model.named_parameters():
+            if n not in pretrained_names or n == 'cls_token':
+                p.requires_grad = True
+                unfreeze_list.append(n)
+            else:
+                p.requires_grad = False
+                freeze_list.append(n)
+        print("Freeze the pretrained parts in TimeSformer: {}".format(freeze_list))
+        print(" Learn the rest parts in TimeSformer: {}".format(unfreeze_list))
+    vision_model.head = nn.Identity()
+    vision_model.pre_logits = nn.Identity()
+    vision_model.fc = nn.Identity()
+    model = CLIP(embed_dim=project_embed_dim, vision_width=vision_width, vision_model=vision_model,
+                 context_length=77, vocab_size=49408, transformer_width=text_width,
+                 transformer_heads=text_heads, transformer_layers=12, tempearture_init=temperature_init, **kwargs)
+    if clip_sd is not None:
+        _load_clip_weights(model, vision_model, clip_sd, vision_layers, project_embed_dim)
+    return model
+
+
+def CLIP_OPENAI_TIMESFORMER_BASE(
+    num_frames=4, timesformer_gated_xattn=False, drop_path_rate=0, timesformer_freeze_space=False,
+    temperature_init=0.07, project_embed_dim=256, **kwargs,
+):
+    """models.py:316-371: TSF-B/16 @224 (D=768, depth 12, 12 heads) + CLIP text (512 wide, 8 heads, 12 layers)."""
+    return _clip_openai_timesformer('ViT-B/16', {}, 768, 512, 8, 12, num_frames, timesformer_gated_xattn,
+                                    drop_path_rate, timesformer_freeze_space, temperature_init, project_embed_dim,
+                                    kwargs)
+
+
+def CLIP_OPENAI_TIMESFORMER_LARGE(
+    num_frames=4, timesformer_gated_xattn=False, drop_path_rate=0, timesformer_freeze_space=False,
+    temperature_init=0.07, project_embed_dim=256, **kwargs,
+):
+    """models.py:374-431: TSF-L/14 @224 (D=1024, depth 24, 16 heads) + CLIP text (768 wide, 12 heads)."""
+    vk = dict(img_size=224, patch_size=14, embed_dim=1024, depth=24, num_heads=16)
+    return _clip_openai_timesformer('ViT-L/14', vk, 1024, 768, 12, 24, num_frames, timesformer_gated_xattn,
+                                    drop_path_rate, timesformer_freeze_space, temperature_init, project_embed_dim,
+                                    kwargs)
+
+
+def CLIP_OPENAI_TIMESFORMER_LARGE_336PX(
+    num_frames=4, timesformer_gated_xattn=False, drop_path_rate=0, timesformer_freeze_space=False,
+    temperature_init=0.07, project_embed_dim=256, **kwargs,
+):
+    """models.py:434-491: TSF-L/14 @336."""
+    vk = dict(img_size=336, patch_size=14, embed_dim=1024, depth=24, num_heads=16)
+    return _clip_openai_timesformer('ViT-L/14@336px', vk, 1024, 768, 12, 24, num_frames, timesformer_gated_xattn,
+                                    drop_path_rate, timesformer_freeze_space, temperature_init, project_embed_dim,
+                                    kwargs)

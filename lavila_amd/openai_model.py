@@ -1,0 +1,120 @@
+"""MI355X-native CLIP text Transformer behind the reference interface
+(`lavila/models/openai_model.py`: QuickGELU :177-179, ResidualAttentionBlock :182-216, Transformer :219-232).
+
+Same class names, constructor signatures and state_dict keys (attn.in_proj_weight, attn.in_proj_bias,
+attn.out_proj.*, ln_1.*, ln_2.*, mlp.c_fc.*, mlp.c_proj.*). The execution is batch-major ([B, L, W]; the
+reference's NLD<->LND permutes disappear), residual adds are fused into the LayerNorms, bias+QuickGELU is one
+kernel, and the causal attention core is a C-ABI call (lvl_causal_attn_fwd/_bwd).
+"""
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+import torch.utils.checkpoint as checkpoint
+
+from . import ops
+from .timesformer import LayerNorm
+
+
+class QuickGELU(nn.Module):
+    """x * sigmoid(1.702 x) -- openai_model.py:177-179 (HIP kernel)."""
+
+    def forward(self, x: torch.Tensor):
+        return ops.bias_quick_gelu(x, None)
+
+
+class _SelfAttentionParams(nn.Module):
+    """Parameter container with nn.MultiheadAttention's names (in_proj_weight/in_proj_bias/out_proj)."""
+
+    def __init__(self, d_model: int, n_head: int):
+        super().__init__()
+        self.embed_dim = d_model
+        self.num_heads = n_head
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * d_model, d_model))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * d_model))
+        self.out_proj = nn.Linear(d_model, d_model)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.constant_(self.out_proj.bias, 0.)
+
+
+class ResidualAttentionBlock(nn.Module):
+    def __init__(self, d_model: int, n_head: int, attn_mask: torch.Tensor = None):
+        super().__init__()
+        if d_model // n_head != 64:
+            raise NotImplementedError('lavila_amd attention kernels are built for head_dim 64')
+        self.attn = _SelfAttentionParams(d_model, n_head)
+        self.ln_1 = LayerNorm(d_model)
+        self.mlp = nn.Sequential(OrderedDict([
+            ("c_fc", nn.Linear(d_model, d_model * 4)),
+            ("gelu", QuickGELU()),
+            ("c_proj", nn.Linear(d_model * 4, d_model))
+        ]))
+        self.ln_2 = LayerNorm(d_model)
+        # The reference passes CLIP.build_attention_mask() (causal, models.py:131-137); the kernel applies the
+        # causal mask analytically. Any other mask is rejected loudly.
+        if attn_mask is not None:
+            L = attn_mask.shape[0]
+            causal = torch.full((L, L), float('-inf')).triu_(1)
+            if attn_mask.shape != causal.shape or not torch.equal(attn_mask.float().cpu(), causal):
+                raise NotImplementedError('only the causal CLIP text mask is supported')
+        else:
+            raise NotImplementedError('unmasked text attention is not on the LaViLa hot path')
+        self.attn_mask = attn_mask
+
+    def chain(self, res, pend, pend_bias):
+        """Batch-major block on the fused residual chain (see SpaceTimeBlock.chain)."""
+        l1, l2, at = self.ln_1, self.ln_2, self.attn
+        if pend is None:
+            x = res
+            h = ops.layer_norm(x, l1.weight, l1.bias, l1.eps)
+        else:
+            x, h = ops.add_layer_norm(res, pend, pend_bias, l1.weight, l1.bias, l1.eps, keep_sum=True)
+        o = ops.causal_attention(F.linear(h, at.in_proj_weight, at.in_proj_bias), at.num_heads)
+        y = F.linear(o, at.out_proj.weight)
+        x1, h2 = ops.add_layer_norm(x, y, at.out_proj.bias, l2.weight, l2.bias, l2.eps, keep_sum=True)
+        a = ops.bias_quick_gelu(F.linear(h2, self.mlp.c_fc.weight), self.mlp.c_fc.bias)
+        return x1, F.linear(a, self.mlp.c_proj.weight), self.mlp.c_proj.bias
+
+    def forward(self, x: torch.Tensor, use_checkpoint=False):
+        """Reference signature: x is [L, N, D] (openai_model.py:206-216)."""
+        xb = x.permute(1, 0, 2).contiguous()
+        x1, y, b = self.chain(xb, None, None)
+        return (x1 + y + b.to(y.dtype)).permute(1, 0, 2)
+
+
+class Transformer(nn.Module):
+    def __init__(self, width: int, layers: int, heads: int, attn_mask: torch.Tensor = None):
+        super().__init__()
+        self.width = width
+        self.layers = layers
+        self.resblocks = nn.Sequential(*[ResidualAttentionBlock(width, heads, attn_mask) for _ in range(layers)])
+
+    def forward_batch_major(self, x, final_ln, use_checkpoint=False, rows=None):
+        """x: [B, L, W]. Runs all blocks on the fused chain and applies `final_ln` (CLIP.ln_final). If `rows`
+        ([B] int64) is given only those token rows are normalised and returned ([B, W])."""
+        res, pend, pb = x.contiguous(), None, None
+        for blk in self.resblocks:
+            if use_checkpoint:
+                res, pend, pb = checkpoint.checkpoint(blk.chain, res, pend, pb, use_reentrant=False)
+            else:
+                res, pend, pb = blk.chain(res, pend, pb)
+        if rows is not None:
+            idx = torch.arange(res.shape[0], device=res.device)
+            r = res[idx, rows].contiguous()
+            if pend is None:
+                return ops.layer_norm(r, final_ln.weight, final_ln.bias, final_ln.eps)
+            return ops.add_layer_norm(r, pend[idx, rows].contiguous(), pb, final_ln.weight, final_ln.bias,
+                                      final_ln.eps, keep_sum=False)[1]
+        if pend is None:
+            return ops.layer_norm(res, final_ln.weight, final_ln.bias, final_ln.eps)
+        return ops.add_layer_norm(res, pend, pb, final_ln.weight, final_ln.bias, final_ln.eps, keep_sum=False)[1]
+
+    def forward(self, x: torch.Tensor, use_checkpoint=False):
+        """Reference signature: [L, N, D] -> [L, N, D] (openai_model.py:226-232)."""
+        res, pend, pb = x.permute(1, 0, 2).contiguous(), None, None
+        for blk in self.resblocks:
+            res, pend, pb = blk.chain(res, pend, pb)
+        if pend is not None:
+            res = res + pend + pb.to(pend.dtype)
+        return res.permute(1, 0, 2)

@@ -1,0 +1,306 @@
+"""autograd-aware wrappers around the C-ABI kernels (liblavila_hip.so).
+
+Each `*_raw` function is a 1:1 call of one C entry point on torch device tensors; each
+`torch.autograd.Function` pairs a forward kernel with its hand-written backward kernel so that the
+reference's training loop (loss.backward(), DDP hooks, AdamW) works unchanged. Parameters
+(gamma/beta/bias/embeddings) are always passed to the kernels as float32.
+"""
+from typing import Optional
+
+import torch
+
+from . import _cabi as C
+
+
+def _f32(p: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    if p is None:
+        return None
+    p = p.detach()
+    if p.dtype != torch.float32:
+        p = p.float()
+    return p.contiguous()
+
+
+def _rows_cols(x: torch.Tensor):
+    cols = x.shape[-1]
+    return x.numel() // cols, cols
+
+
+# --------------------------------------------------------------------------------------------------
+# LayerNorm (optionally fused with residual + bias add)
+# --------------------------------------------------------------------------------------------------
+def layernorm_fwd_raw(x, x2, xbias, gamma, beta, eps, keep_sum):
+    C.require_device(x, x2, xbias, gamma, beta)
+    rows, cols = _rows_cols(x)
+    y = torch.empty_like(x)
+    s = torch.empty_like(x) if keep_sum else None
+    mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+    C.check(C.lib().lvl_layernorm_fwd(C.ptr(x), C.ptr(x2), C.ptr(xbias), C.ptr(gamma), C.ptr(beta), C.ptr(s),
+                                      C.ptr(y), C.ptr(mean), C.ptr(rstd), rows, cols, float(eps),
+                                      C.dtype_code(x), C.stream_ptr()), 'lvl_layernorm_fwd')
+    return y, s, mean, rstd
+
+
+def layernorm_bwd_raw(dy, x, x2, xbias, gamma, mean, rstd, dadd, want_dxsum):
+    C.require_device(dy, x, x2, xbias, gamma, mean, rstd, dadd)
+    rows, cols = _rows_cols(x)
+    dx = torch.empty_like(x)
+    dgamma = torch.empty(cols, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(cols, dtype=torch.float32, device=x.device)
+    dxsum = torch.empty(cols, dtype=torch.float32, device=x.device) if want_dxsum else None
+    ws = C.workspace('layernorm_bwd', rows, cols, x.device)
+    C.check(C.lib().lvl_layernorm_bwd(C.ptr(dy), C.ptr(x), C.ptr(x2), C.ptr(xbias), C.ptr(gamma), C.ptr(mean),
+                                      C.ptr(rstd), C.ptr(dadd), C.ptr(dx), C.ptr(dgamma), C.ptr(dbeta),
+                                      C.ptr(dxsum), C.ptr(ws), rows, cols, C.dtype_code(x), C.stream_ptr()),
+            'lvl_layernorm_bwd')
+    return dx, dgamma, dbeta, dxsum
+
+
+class _LayerNormFn(torch.autograd.Function):
+    """y = LN(x) ; see lvl_layernorm_fwd/bwd."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        x = x.contiguous()
+        g, b = _f32(weight), _f32(bias)
+        y, _, mean, rstd = layernorm_fwd_raw(x, None, None, g, b, eps, False)
+        ctx.save_for_backward(x, g, mean, rstd)
+        ctx.pdt = (weight.dtype, bias.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g, mean, rstd = ctx.saved_tensors
+        dx, dg, db, _ = layernorm_bwd_raw(dy.contiguous(), x, None, None, g, mean, rstd, None, False)
+        return dx, dg.to(ctx.pdt[0]), db.to(ctx.pdt[1]), None
+
+
+def layer_norm(x, weight, bias, eps):
+    return _LayerNormFn.apply(x, weight, bias, eps)
+
+
+class _AddLayerNormFn(torch.autograd.Function):
+    """(s, h) = (res + y + ybias, LN(res + y + ybias)); s is only materialised when keep_sum."""
+
+    @staticmethod
+    def forward(ctx, res, y, ybias, weight, bias, eps, keep_sum):
+        res, y = res.contiguous(), y.contiguous()
+        yb, g, b = _f32(ybias), _f32(weight), _f32(bias)
+        h, s, mean, rstd = layernorm_fwd_raw(res, y, yb, g, b, eps, keep_sum)
+        if keep_sum:
+            ctx.save_for_backward(s, g, mean, rstd)
+        else:
+            ctx.save_for_backward(res, y, yb, g, mean, rstd)
+        ctx.keep_sum = keep_sum
+        ctx.has_ybias = ybias is not None
+        ctx.pdt = (weight.dtype, bias.dtype, ybias.dtype if ybias is not None else None)
+        if keep_sum:
+            return s, h
+        dummy = h.new_empty(0)
+        ctx.mark_non_differentiable(dummy)
+        return dummy, h
+
+    @staticmethod
+    def backward(ctx, ds, dh):
+        if ctx.keep_sum:
+            s, g, mean, rstd = ctx.saved_tensors
+            dadd = ds.contiguous() if ds is not None else None
+            dx, dg, db, dsum = layernorm_bwd_raw(dh.contiguous(), s, None, None, g, mean, rstd, dadd, ctx.has_ybias)
+        else:
+            res, y, yb, g, mean, rstd = ctx.saved_tensors
+            dx, dg, db, dsum = layernorm_bwd_raw(dh.contiguous(), res, y, yb, g, mean, rstd, None, ctx.has_ybias)
+        dyb = dsum.to(ctx.pdt[2]) if ctx.has_ybias else None
+        return dx, dx, dyb, dg.to(ctx.pdt[0]), db.to(ctx.pdt[1]), None, None
+
+
+def add_layer_norm(res, y, ybias, weight, bias, eps, keep_sum=True):
+    """Returns (s, h) with s = res + y (+ ybias) and h = LayerNorm(s). With keep_sum=False s is None."""
+    s, h = _AddLayerNormFn.apply(res, y, ybias, weight, bias, eps, keep_sum)
+    return (s if keep_sum else None), h
+
+
+# --------------------------------------------------------------------------------------------------
+# bias + QuickGELU
+# --------------------------------------------------------------------------------------------------
+class _BiasQuickGELUFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u, bias):
+        u = u.contiguous()
+        b = _f32(bias)
+        C.require_device(u, b)
+        rows, cols = _rows_cols(u)
+        a = torch.empty_like(u)
+        C.check(C.lib().lvl_bias_quickgelu_fwd(C.ptr(u), C.ptr(b), C.ptr(a), rows, cols, C.dtype_code(u),
+                                               C.stream_ptr()), 'lvl_bias_quickgelu_fwd')
+        ctx.save_for_backward(u, b)
+        ctx.bdt = bias.dtype if bias is not None else None
+        return a
+
+    @staticmethod
+    def backward(ctx, da):
+        u, b = ctx.saved_tensors
+        da = da.contiguous()
+        rows, cols = _rows_cols(u)
+        du = torch.empty_like(u)
+        dbias = torch.empty(cols, dtype=torch.float32, device=u.device) if b is not None else None
+        ws = C.workspace('bias_quickgelu_bwd', rows, cols, u.device) if b is not None else None
+        C.check(C.lib().lvl_bias_quickgelu_bwd(C.ptr(da), C.ptr(u), C.ptr(b), C.ptr(du), C.ptr(dbias), C.ptr(ws),
+                                               rows, cols, C.dtype_code(u), C.stream_ptr()),
+                'lvl_bias_quickgelu_bwd')
+        return du, (dbias.to(ctx.bdt) if b is not None else None)
+
+
+def bias_quick_gelu(u, bias=None):
+    """(u + bias) * sigmoid(1.702 (u + bias))"""
+    return _BiasQuickGELUFn.apply(u, bias)
+
+
+# --------------------------------------------------------------------------------------------------
+# patch gather + token assembly
+# --------------------------------------------------------------------------------------------------
+def patchify(video: torch.Tensor, patch: int, dtype: torch.dtype) -> torch.Tensor:
+    """[B,C,F,H,W] f32 -> [B, F*N, C*P*P] (no gradient w.r.t. pixels: the reference never needs one)."""
+    video = video.detach()
+    if video.dtype != torch.float32:
+        video = video.float()
+    video = video.contiguous()
+    C.require_device(video)
+    B, Ch, Fr, H, W = video.shape
+    N = (H // patch) * (W // patch)
+    out = torch.empty(B, Fr * N, Ch * patch * patch, dtype=dtype, device=video.device)
+    C.check(C.lib().lvl_patchify(C.ptr(video), C.ptr(out), B, Ch, Fr, H, W, patch, C.dtype_code(out),
+                                 C.stream_ptr()), 'lvl_patchify')
+    return out
+
+
+class _EmbedTokensFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pe, cls_token, pos_embed, temporal_embed, frames, n_per_frame):
+        pe = pe.contiguous()
+        B, FN, D = pe.shape
+        cls, pos, tem = _f32(cls_token).reshape(-1), _f32(pos_embed).reshape(-1, D), _f32(temporal_embed).reshape(-1, D)
+        C.require_device(pe, cls, pos, tem)
+        x = torch.empty(B, 1 + FN, D, dtype=pe.dtype, device=pe.device)
+        C.check(C.lib().lvl_embed_tokens_fwd(C.ptr(pe), C.ptr(cls), C.ptr(pos), C.ptr(tem), C.ptr(x), B, frames,
+                                             n_per_frame, D, C.dtype_code(pe), C.stream_ptr()),
+                'lvl_embed_tokens_fwd')
+        ctx.dims = (B, frames, n_per_frame, D, temporal_embed.shape[1])
+        ctx.pdt = (cls_token.dtype, pos_embed.dtype, temporal_embed.dtype)
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        B, Fr, N, D, num_frames = ctx.dims
+        body = dx[:, 1:].reshape(B, Fr, N, D).float()
+        d0 = dx[:, 0].float().sum(0)                                    # cls row: d cls_token = d pos[0]
+        dpos = torch.cat([d0[None], body.sum((0, 1))], 0)[None]         # [1, N+1, D]
+        dtem = dx.new_zeros((1, num_frames, D), dtype=torch.float32)
+        dtem[0, :Fr] = body.sum((0, 2))
+        return (dx[:, 1:], d0.reshape(1, 1, D).to(ctx.pdt[0]), dpos.to(ctx.pdt[1]), dtem.to(ctx.pdt[2]),
+                None, None)
+
+
+def embed_tokens(pe, cls_token, pos_embed, temporal_embed, frames, n_per_frame):
+    return _EmbedTokensFn.apply(pe, cls_token, pos_embed, temporal_embed, frames, n_per_frame)
+
+
+# --------------------------------------------------------------------------------------------------
+# attention cores
+# --------------------------------------------------------------------------------------------------
+class _DividedAttnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, frames, n_per_frame, heads, mode):
+        qkv = qkv.contiguous()
+        C.require_device(qkv)
+        B, T, D3 = qkv.shape
+        D = D3 // 3
+        if D != heads * 64 or T != 1 + frames * n_per_frame:
+            raise C.HipExtensionError(f'divided attention: qkv {tuple(qkv.shape)} inconsistent with heads={heads} '
+                                      f'(head dim must be 64), frames={frames}, patches/frame={n_per_frame}')
+        out = torch.empty(B, T, D, dtype=qkv.dtype, device=qkv.device)
+        lse = torch.empty(B, heads, T, dtype=torch.float32, device=qkv.device)
+        C.check(C.lib().lvl_divided_attn_fwd(C.ptr(qkv), C.ptr(out), C.ptr(lse), B, frames, n_per_frame, heads, mode,
+                                             C.dtype_code(qkv), C.stream_ptr()), 'lvl_divided_attn_fwd')
+        ctx.save_for_backward(qkv, out, lse)
+        ctx.cfg = (B, frames, n_per_frame, heads, mode)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse = ctx.saved_tensors
+        B, Fr, N, H, mode = ctx.cfg
+        dout = dout.contiguous()
+        dqkv = torch.empty_like(qkv)
+        ws = C.workspace('divided_attn_bwd', B * H, 1 + Fr * N, qkv.device)
+        C.check(C.lib().lvl_divided_attn_bwd(C.ptr(qkv), C.ptr(out), C.ptr(dout), C.ptr(lse), C.ptr(dqkv), C.ptr(ws),
+                                             B, Fr, N, H, mode, C.dtype_code(qkv), C.stream_ptr()),
+                'lvl_divided_attn_bwd')
+        return dqkv, None, None, None, None
+
+
+def divided_attention(qkv, frames, n_per_frame, heads, mode):
+    """mode: 'space' | 'time'. qkv [B,T,3D] -> [B,T,D] (timesformer.py:110-140 between the two Linears)."""
+    m = {'space': C.ATTN_SPACE, 'time': C.ATTN_TIME}[mode]
+    return _DividedAttnFn.apply(qkv, frames, n_per_frame, heads, m)
+
+
+class _CausalAttnFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, heads):
+        qkv = qkv.contiguous()
+        C.require_device(qkv)
+        B, L, D3 = qkv.shape
+        D = D3 // 3
+        if D != heads * 64:
+            raise C.HipExtensionError(f'causal attention: width {D} != heads*64 ({heads} heads)')
+        out = torch.empty(B, L, D, dtype=qkv.dtype, device=qkv.device)
+        lse = torch.empty(B, heads, L, dtype=torch.float32, device=qkv.device)
+        C.check(C.lib().lvl_causal_attn_fwd(C.ptr(qkv), C.ptr(out), C.ptr(lse), B, L, heads, C.dtype_code(qkv),
+                                            C.stream_ptr()), 'lvl_causal_attn_fwd')
+        ctx.save_for_backward(qkv, out, lse)
+        ctx.cfg = (B, L, heads)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse = ctx.saved_tensors
+        B, L, H = ctx.cfg
+        dout = dout.contiguous()
+        dqkv = torch.empty_like(qkv)
+        ws = C.workspace('causal_attn_bwd', B * H, L, qkv.device)
+        C.check(C.lib().lvl_causal_attn_bwd(C.ptr(qkv), C.ptr(out), C.ptr(dout), C.ptr(lse), C.ptr(dqkv), C.ptr(ws),
+                                            B, L, H, C.dtype_code(qkv), C.stream_ptr()), 'lvl_causal_attn_bwd')
+        return dqkv, None
+
+
+def causal_attention(qkv, heads):
+    return _CausalAttnFn.apply(qkv, heads)
+
+
+# --------------------------------------------------------------------------------------------------
+# contrastive head (raw kernels; the autograd wrapper + collectives live in lavila_amd/loss.py)
+# --------------------------------------------------------------------------------------------------
+def clip_loss_fwd_raw(img_all, txt_all, scale, B: int, row0: int, want_logits=False):
+    """scale: 0-dim/1-elem float32 DEVICE tensor (exp(logit_scale)); no host sync."""
+    C.require_device(img_all, txt_all, scale)
+    G, E = img_all.shape
+    dev = img_all.device
+    stats = torch.empty(2, B, 4, dtype=torch.float32, device=dev)
+    argmax = torch.empty(2, B, dtype=torch.int32, device=dev)
+    logits = torch.empty(2, B, G, dtype=torch.float32, device=dev) if want_logits else None
+    C.check(C.lib().lvl_clip_loss_fwd(C.ptr(img_all), C.ptr(txt_all), C.ptr(scale), B, G, E, row0, C.ptr(stats),
+                                      C.ptr(argmax), C.ptr(logits), C.dtype_code(img_all), C.stream_ptr()),
+            'lvl_clip_loss_fwd')
+    return stats, argmax, logits
+
+
+def clip_loss_bwd_raw(img_all, txt_all, lse_all, scale, upstream, coef: float, B: int, row0: int):
+    C.require_device(img_all, txt_all, lse_all, scale, upstream)
+    G, E = img_all.shape
+    dimg = torch.empty(B, E, dtype=torch.float32, device=img_all.device)
+    dtxt = torch.empty(B, E, dtype=torch.float32, device=img_all.device)
+    C.check(C.lib().lvl_clip_loss_bwd(C.ptr(img_all), C.ptr(txt_all), C.ptr(lse_all), C.ptr(scale), C.ptr(upstream),
+                                      float(coef), B, G, E, row0, C.ptr(dimg), C.ptr(dtxt), C.dtype_code(img_all),
+                                      C.stream_ptr()), 'lvl_clip_loss_bwd')
+    return dimg, dtxt

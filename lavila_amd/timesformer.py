@@ -1,0 +1,379 @@
+"""MI355X-native TimeSformer video tower behind the reference's own interface.
+
+Mirrors `lavila/models/timesformer.py` of facebookresearch/LaViLa (class names, constructor
+signatures, forward()/forward_features() signatures, parameter/state_dict names, error behaviour),
+but the execution plan is ours: no rearrange copies, no materialised attention scores, the
+BCTHW->BTCHW permute folded into the patch gather, every residual add fused into the LayerNorm
+that consumes it, bias+QuickGELU fused, and the divided space-time attention core run by
+hand-written HIP kernels through the C ABI (include/lavila_hip.h). Linear layers are plain GEMMs
+(torch -> hipBLASLt). There is no CPU path: forward() on a CPU tensor raises.
+"""
+from collections import OrderedDict
+from functools import partial
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+import torch.utils.checkpoint as checkpoint
+
+from . import ops
+
+
+def to_2tuple(x):
+    return tuple(x) if isinstance(x, (tuple, list)) else (x, x)
+
+
+def _compute_dtype(weight: torch.Tensor) -> torch.dtype:
+    """Activation dtype of the tower: the autocast dtype when autocast is on (fp16 autocast is remapped to
+    bf16 by the CLIP wrapper), else the dtype of the weights."""
+    if torch.is_autocast_enabled():
+        return torch.get_autocast_dtype('cuda')
+    return weight.dtype
+
+
+class LayerNorm(nn.Module):
+    """nn.LayerNorm(dim, eps) with the HIP kernel underneath; same parameter names (weight, bias)."""
+
+    def __init__(self, normalized_shape, eps=1e-5):
+        super().__init__()
+        dim = normalized_shape if isinstance(normalized_shape, int) else normalized_shape[-1]
+        self.normalized_shape = (dim,)
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(dim))
+        self.bias = nn.Parameter(torch.zeros(dim))
+
+    def forward(self, x):
+        return ops.layer_norm(x, self.weight, self.bias, self.eps)
+
+    def extra_repr(self):
+        return f'{self.normalized_shape}, eps={self.eps}'
+
+
+class DropPath(nn.Module):
+    """Per-sample stochastic depth (timm.models.layers.DropPath semantics, timesformer.py:31,161)."""
+
+    def __init__(self, drop_prob=0.0):
+        super().__init__()
+        self.drop_prob = float(drop_prob)
+
+    def forward(self, x):
+        if self.drop_prob == 0.0 or not self.training:
+            return x
+        keep = 1.0 - self.drop_prob
+        mask = x.new_empty((x.shape[0],) + (1,) * (x.ndim - 1)).bernoulli_(keep)
+        return x * (mask / keep)
+
+
+class QuickGELUAct(nn.Module):
+    """Marker for the fused bias+QuickGELU kernel; calling it standalone applies x*sigmoid(1.702x)."""
+
+    def forward(self, x):
+        return ops.bias_quick_gelu(x, None)
+
+
+class Mlp(nn.Module):
+    """fc2(act(fc1(x))) -- timesformer.py:42-58. With QuickGELU (all CLIP_OPENAI_* models) the fc1 bias add
+    and the activation run as one HIP kernel on the raw GEMM output."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features, out_features)
+        self.drop = nn.Dropout(drop)
+        self._fused_act = type(self.act).__name__ in ('QuickGELU', 'QuickGELUAct')
+
+    def hidden(self, x):
+        if self._fused_act:
+            return self.drop(ops.bias_quick_gelu(F.linear(x, self.fc1.weight), self.fc1.bias))
+        return self.drop(self.act(self.fc1(x)))
+
+    def forward(self, x):
+        return self.drop(self.fc2(self.hidden(x)))
+
+
+class VideoPatchEmbed(nn.Module):
+    """Video to patch embedding -- timesformer.py:61-84. `proj` keeps the Conv2d parameter layout
+    ([D,3,P,P], bias only when ln_pre=False) so checkpoints interoperate; the computation is the HIP patch
+    gather + one GEMM against proj.weight viewed as [D, 3*P*P]."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768, num_frames=8, ln_pre=False):
+        super().__init__()
+        img_size = to_2tuple(img_size)
+        patch_size = to_2tuple(patch_size)
+        self.img_size = img_size
+        self.patch_size = patch_size
+        self.num_patches = (img_size[1] // patch_size[1]) * (img_size[0] // patch_size[0]) * num_frames
+        self.num_frames = num_frames
+        self.embed_dim = embed_dim
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size, bias=not ln_pre)
+
+    def tokens_from_bcthw(self, video):
+        """[B,C,F,H,W] -> [B, F*N, D] without the BTCHW copy."""
+        assert video.shape[2] <= self.num_frames
+        if self.patch_size[0] != self.patch_size[1]:
+            raise NotImplementedError('non-square patches')
+        w = self.proj.weight
+        patches = ops.patchify(video, self.patch_size[0], _compute_dtype(w))
+        return F.linear(patches, w.reshape(w.shape[0], -1), self.proj.bias)
+
+    def forward(self, x):
+        """Reference signature: x [B,F,C,H,W] -> [B*F, D, H/P, W/P] (timesformer.py:79-84)."""
+        B, Fr, C, H, W = x.shape
+        assert Fr <= self.num_frames
+        tok = self.tokens_from_bcthw(x.permute(0, 2, 1, 3, 4))
+        gh, gw = H // self.patch_size[0], W // self.patch_size[1]
+        return tok.reshape(B * Fr, gh, gw, -1).permute(0, 3, 1, 2)
+
+
+class VarAttention(nn.Module):
+    """Divided attention layer -- timesformer.py:87-144. qkv/proj are plain Linears; everything between them
+    (head split, q scaling, CLS-attends-all, per-frame / per-location grouping, softmax, merge) is one C-ABI
+    call (lvl_divided_attn_fwd / _bwd)."""
+
+    def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0., proj_drop=0.,
+                 initialize='random'):
+        super().__init__()
+        self.num_heads = num_heads
+        head_dim = dim // num_heads
+        if head_dim != 64:
+            raise NotImplementedError(f'lavila_amd attention kernels are built for head_dim 64, got {head_dim}')
+        if qk_scale is not None and abs(qk_scale - head_dim ** -0.5) > 1e-12:
+            raise NotImplementedError('qk_scale override')
+        self.scale = qk_scale or head_dim ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+        if initialize == 'zeros':
+            self.qkv.weight.data.fill_(0)
+            self.qkv.bias.data.fill_(0)
+            self.proj.weight.data.fill_(1)
+            self.proj.bias.data.fill_(0)
+        if attn_drop != 0. or proj_drop != 0.:
+            raise NotImplementedError('attention / projection dropout (never used by the reference configs)')
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj_drop = nn.Dropout(proj_drop)
+
+    @staticmethod
+    def _mode(einops_to, einops_dims):
+        if einops_to.replace(' ', '') == '(bf)nd':
+            return 'space', int(einops_dims['f'])
+        if einops_to.replace(' ', '') == '(bn)fd':
+            return 'time', int(einops_dims['n'])
+        raise NotImplementedError(f'einops pattern {einops_to!r}')
+
+    def core(self, x, mode, frames, n_per_frame):
+        """qkv Linear + attention core; returns the pre-projection tensor [B,T,D]."""
+        return ops.divided_attention(self.qkv(x), frames, n_per_frame, self.num_heads, mode)
+
+    def forward(self, x, einops_from, einops_to, einops_dims):
+        mode, k = self._mode(einops_to, einops_dims)
+        patches = x.shape[1] - 1
+        frames, n = (k, patches // k) if mode == 'space' else (patches // k, k)
+        return self.proj(self.core(x, mode, frames, n))
+
+
+class SpaceTimeBlock(nn.Module):
+    """timesformer.py:147-198, 'frozen-in-time' wiring:
+         t = x + [tanh(alpha)] * timeattn(norm3(x));  x1 = x + attn(norm1(t));  out = x1 + mlp(norm2(x1))
+    """
+
+    def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, qk_scale=None, drop=0., attn_drop=0.,
+                 drop_path=0., act_layer=nn.GELU, norm_layer=nn.LayerNorm, time_init='zeros',
+                 attention_style='frozen-in-time', is_tanh_gating=False):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.attn = VarAttention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale,
+                                 attn_drop=attn_drop, proj_drop=drop)
+        self.timeattn = VarAttention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale,
+                                     attn_drop=attn_drop, proj_drop=drop, initialize=time_init)
+        if is_tanh_gating:
+            self.alpha_timeattn = nn.Parameter(torch.zeros([]))
+        self.drop_path = DropPath(drop_path) if drop_path > 0. else nn.Identity()
+        self.norm2 = norm_layer(dim)
+        mlp_hidden_dim = int(dim * mlp_ratio)
+        self.mlp = Mlp(in_features=dim, hidden_features=mlp_hidden_dim, act_layer=act_layer, drop=drop)
+        self.norm3 = norm_layer(dim)
+        self.attention_style = attention_style
+
+    def _dropping(self):
+        return self.training and isinstance(self.drop_path, DropPath) and self.drop_path.drop_prob > 0.
+
+    def chain(self, res, pend, pend_bias, frames, n_per_frame):
+        """One block on the fused residual chain.
+
+        The block input is x = res + pend + pend_bias (pend/pend_bias may be None); that add is fused into
+        norm3. Returns (x1, y, y_bias) with the block output = x1 + y + y_bias left *pending* so that the
+        next consumer (next block's norm3 or the final norm) fuses it too."""
+        if self.attention_style != 'frozen-in-time':
+            raise NotImplementedError
+        n3, n1, n2 = self.norm3, self.norm1, self.norm2
+        if pend is None:
+            x = res
+            h3 = ops.layer_norm(x, n3.weight, n3.bias, n3.eps)
+        else:
+            x, h3 = ops.add_layer_norm(res, pend, pend_bias, n3.weight, n3.bias, n3.eps, keep_sum=True)
+        ta, sa = self.timeattn, self.attn
+        o_t = ta.core(h3, 'time', frames, n_per_frame)
+        if hasattr(self, 'alpha_timeattn'):
+            y_t, b_t = torch.tanh(self.alpha_timeattn).to(o_t.dtype) * ta.proj(o_t), None
+        else:
+            y_t, b_t = F.linear(o_t, ta.proj.weight), ta.proj.bias
+        _, h1 = ops.add_layer_norm(x, y_t, b_t, n1.weight, n1.bias, n1.eps, keep_sum=False)   # t never stored
+        o_s = sa.core(h1, 'space', frames, n_per_frame)
+        if self._dropping():
+            y_s, b_s = self.drop_path(sa.proj(o_s)), None
+        else:
+            y_s, b_s = F.linear(o_s, sa.proj.weight), sa.proj.bias
+        x1, h2 = ops.add_layer_norm(x, y_s, b_s, n2.weight, n2.bias, n2.eps, keep_sum=True)
+        a = self.mlp.hidden(h2)
+        if self._dropping():
+            return x1, self.drop_path(self.mlp.drop(self.mlp.fc2(a))), None
+        return x1, F.linear(a, self.mlp.fc2.weight), self.mlp.fc2.bias
+
+    def forward(self, x, einops_from_space, einops_to_space, einops_from_time, einops_to_time,
+                time_n, space_f, use_checkpoint=False):
+        """Reference signature (timesformer.py:173-174); materialises the block output."""
+        frames, n = int(space_f), int(time_n)
+        if use_checkpoint:
+            x1, y, b = checkpoint.checkpoint(self.chain, x, None, None, frames, n, use_reentrant=False)
+        else:
+            x1, y, b = self.chain(x, None, None, frames, n)
+        return x1 + (y if b is None else y + b.to(y.dtype))
+
+
+class SpaceTimeTransformer(nn.Module):
+    """Divided space-time ViT -- timesformer.py:201-390 (same constructor, attributes and state_dict)."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dim=768, depth=12,
+                 num_heads=12, mlp_ratio=4., qkv_bias=True, qk_scale=None, representation_size=None,
+                 drop_rate=0., attn_drop_rate=0., drop_path_rate=0., hybrid_backbone=None, norm_layer=None,
+                 num_frames=8, time_init='rand', attention_style='frozen-in-time', ln_pre=False,
+                 act_layer=nn.GELU, is_tanh_gating=False):
+        super().__init__()
+        self.num_classes = num_classes
+        self.num_features = self.embed_dim = embed_dim
+        self.num_frames = num_frames
+        norm_layer = norm_layer or partial(LayerNorm, eps=1e-6)
+        print("######USING ATTENTION STYLE: ", attention_style)
+        if hybrid_backbone is not None:
+            raise NotImplementedError('hybrid backbone not implemented')
+        if drop_rate != 0.:
+            raise NotImplementedError('drop_rate != 0 (never used by the reference configs)')
+        self.patch_embed = VideoPatchEmbed(img_size=img_size, patch_size=patch_size, in_chans=in_chans,
+                                           embed_dim=embed_dim, num_frames=num_frames, ln_pre=ln_pre)
+        num_patches = self.patch_embed.num_patches
+        self.patches_per_frame = num_patches // num_frames
+
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, self.patches_per_frame + 1, embed_dim))
+        self.temporal_embed = nn.Parameter(torch.zeros(1, num_frames, embed_dim))
+        self.ln_pre = LayerNorm(embed_dim, eps=1e-5) if ln_pre else None
+        self.pos_drop = nn.Dropout(p=drop_rate)
+
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth)]
+        self.blocks = nn.ModuleList([
+            SpaceTimeBlock(dim=embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias,
+                           qk_scale=qk_scale, drop=drop_rate, attn_drop=attn_drop_rate, drop_path=dpr[i],
+                           norm_layer=norm_layer, time_init=time_init, attention_style=attention_style,
+                           act_layer=act_layer, is_tanh_gating=is_tanh_gating)
+            for i in range(depth)])
+        self.norm = norm_layer(embed_dim)
+
+        if representation_size:
+            self.num_features = representation_size
+            self.pre_logits = nn.Sequential(OrderedDict([('fc', nn.Linear(embed_dim, representation_size)),
+                                                         ('act', nn.Tanh())]))
+        else:
+            self.pre_logits = nn.Identity()
+        self.head = nn.Linear(self.num_features, num_classes) if num_classes > 0 else nn.Identity()
+
+        nn.init.trunc_normal_(self.pos_embed, std=.02)
+        nn.init.trunc_normal_(self.cls_token, std=.02)
+        if num_frames == 1:
+            self.apply(self._init_weights)
+
+        self.einops_from_space = 'b (f n) d'
+        self.einops_to_space = '(b f) n d'
+        self.einops_from_time = 'b (f n) d'
+        self.einops_to_time = '(b n) f d'
+
+    def _init_weights(self, m):
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, std=.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, (nn.LayerNorm, LayerNorm)):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {'pos_embed', 'cls_token'}
+
+    def get_classifier(self):
+        return self.head
+
+    def reset_classifier(self, num_classes, global_pool=''):
+        self.num_classes = num_classes
+        self.head = nn.Linear(self.embed_dim, num_classes) if num_classes > 0 else nn.Identity()
+
+    def _freeze(self, temporal):
+        freeze_list = []
+        for n, p in self.named_parameters():
+            is_temporal = 'temporal_embed' in n or 'timeattn' in n or 'norm3' in n
+            if is_temporal == temporal:
+                p.requires_grad = False
+                freeze_list.append(n)
+        print("Freeze the pretrained parts in vision model: {}".format(freeze_list))
+
+    def freeze_spatial_weights(self):
+        self._freeze(temporal=False)
+
+    def freeze_temporal_weights(self):
+        self._freeze(temporal=True)
+
+    # ------------------------------------------------------------------------------------------------
+    def _features_from_tokens(self, tok, frames, use_checkpoint, cls_at_last):
+        """tok: [B, F*N, D] patch-embedded tokens (frame-major)."""
+        n = self.patches_per_frame
+        if tok.shape[1] != frames * n:
+            raise ValueError(f'got {tok.shape[1]} patch tokens for {frames} frames; this model was built for '
+                             f'{n} patches per frame (img_size / patch_size are fixed at construction)')
+        x = ops.embed_tokens(tok, self.cls_token, self.pos_embed, self.temporal_embed, frames, n)
+        if self.ln_pre is not None:
+            x = self.ln_pre(x)
+        x = self.pos_drop(x)
+        res, pend, pend_b = x, None, None
+        for blk in self.blocks:
+            if use_checkpoint:
+                res, pend, pend_b = checkpoint.checkpoint(blk.chain, res, pend, pend_b, frames, n,
+                                                          use_reentrant=False)
+            else:
+                res, pend, pend_b = blk.chain(res, pend, pend_b, frames, n)
+        nm = self.norm
+        if cls_at_last:
+            # only row 0 of every sample feeds the output: final residual add + LayerNorm on [B, D]
+            r0 = res[:, 0].contiguous()
+            if pend is None:
+                out = ops.layer_norm(r0, nm.weight, nm.bias, nm.eps)
+            else:
+                _, out = ops.add_layer_norm(r0, pend[:, 0].contiguous(), pend_b, nm.weight, nm.bias, nm.eps,
+                                            keep_sum=False)
+            return self.pre_logits(out)
+        if pend is None:
+            return ops.layer_norm(res, nm.weight, nm.bias, nm.eps)
+        return ops.add_layer_norm(res, pend, pend_b, nm.weight, nm.bias, nm.eps, keep_sum=False)[1]
+
+    def forward_features(self, x, use_checkpoint=False, cls_at_last=True):
+        """Reference signature: x is [B, F, C, H, W] (timesformer.py:345-382)."""
+        b, curr_frames, channels, _, _ = x.shape
+        tok = self.patch_embed.tokens_from_bcthw(x.permute(0, 2, 1, 3, 4))
+        return self._features_from_tokens(tok, curr_frames, use_checkpoint, cls_at_last)
+
+    def forward(self, x, use_checkpoint=False):
+        """x: [B, C, T, H, W] (timesformer.py:384-390); the BCTHW->BTCHW copy is folded into the gather."""
+        tok = self.patch_embed.tokens_from_bcthw(x)
+        x = self._features_from_tokens(tok, x.shape[2], use_checkpoint, True)
+        return self.head(x)

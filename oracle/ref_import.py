@@ -101,7 +101,11 @@ def load_reference():
     for k in saved:
         del sys.modules[k]
     sys.modules.update(stubs)
-    sys.path.insert(0, REFERENCE_ROOT)
+    # a regular package (our shim has __init__.py) shadows the reference's namespace package wherever it sits
+    # on sys.path, so hide every path entry that holds a `lavila/__init__.py` while importing the reference
+    saved_path = list(sys.path)
+    sys.path[:] = [REFERENCE_ROOT] + [p for p in saved_path
+                                      if not os.path.isfile(os.path.join(p or os.getcwd(), 'lavila', '__init__.py'))]
     try:
         ns = types.SimpleNamespace()
         ns.timesformer = importlib.import_module("lavila.models.timesformer")
@@ -112,7 +116,7 @@ def load_reference():
         ns.models = importlib.import_module("lavila.models.models")
         assert ns.models.__file__.startswith(REFERENCE_ROOT), ns.models.__file__
     finally:
-        sys.path.remove(REFERENCE_ROOT)
+        sys.path[:] = saved_path
         ref_mods = {k: v for k, v in sys.modules.items() if k == "lavila" or k.startswith("lavila.")}
         for k in ref_mods:
             del sys.modules[k]

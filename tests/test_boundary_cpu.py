@@ -1,0 +1,115 @@
+"""CPU (-m "not gpu"): the drop-in boundary -- import paths, constructor kwargs, state_dict names, C-ABI
+exports, loud failure without a GPU, checkpoint helpers vs the reference."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+from helpers import build_model
+from oracle.ref_import import reference_available
+
+MODELS = ['tiny_p16', 'tiny_p14_gated', 'config1_tsfb_112']
+
+
+def test_cabi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, 'include', 'lavila_hip.h')).read()
+    hdr = re.sub(r'/\*.*?\*/', '', hdr, flags=re.S)
+    declared = set(re.findall(r'\b(lvl_[a-z0-9_]+)\s*\(', hdr))
+    assert len(declared) >= 15
+    from lavila_amd import _cabi
+    assert declared == set(_cabi.SIGNATURES), declared ^ set(_cabi.SIGNATURES)
+    lib = ctypes.CDLL(_cabi.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert b'gfx950' in _cabi.lib().lvl_version()
+    assert _cabi.lib().lvl_workspace_floats(b'layernorm_bwd', 10, 768) > 0
+
+
+@pytest.mark.parametrize('name', MODELS)
+def test_state_dict_names_and_shapes_match_reference(name):
+    fx = load_golden(f'model_{name}.pt')
+    m = build_model(fx['config'])
+    sd = m.state_dict()
+    assert list(sd.keys()) == fx['state_dict_keys']
+    assert [k for k, _ in m.named_parameters()] == fx['param_names']
+    assert {k: tuple(v.shape) for k, v in sd.items()} == fx['shapes']
+
+
+def test_named_constructor_swallows_driver_kwargs_and_matches_survey_counts():
+    from lavila.models import models
+    m = models.CLIP_OPENAI_TIMESFORMER_BASE(
+        pretrained=False, pretrained2d=True, text_use_cls_token=False, project_embed_dim=256, gated_xattn=False,
+        random_init_gpt2=False, timesformer_gated_xattn=False, timesformer_freeze_space=False, freeze_lm_vclm=False,
+        freeze_visual_vclm=False, freeze_visual_vclm_temporal=False, num_frames=4, drop_path_rate=0.0,
+        temperature_init=0.07)
+    assert len(m.state_dict()) == 375                                  # SURVEY.md 8b [probed]
+    assert abs(sum(p.numel() for p in m.parameters()) / 1e6 - 177.66) < 0.01
+    # shipped init: temporal attention starts as an exact no-op (timesformer.py:97-103)
+    ta = m.visual.blocks[0].timeattn
+    assert float(ta.qkv.weight.abs().max()) == 0 and float(ta.proj.weight.min()) == 1
+    assert m.visual.patch_embed.proj.bias is None                     # ln_pre=True -> bias=False
+    assert models.get_metric_names('CLIP_OPENAI_TIMESFORMER_BASE') == ['loss', 'clip_loss', 'clip_acc']
+    args = type('A', (), dict(contrastive_use_vissl=True, rank=0, world_size=1))
+    crit = models.get_loss('CLIP_OPENAI_TIMESFORMER_BASE', args)
+    assert isinstance(crit, models.loss.CLIPLoss) and crit.use_vissl and crit.state_dict() == {}
+    with pytest.raises(NotImplementedError):
+        models.get_loss('VCLM_OPENAI_TIMESFORMER_BASE_GPT2', args)
+
+
+def test_no_cpu_fallback():
+    from lavila_amd._cabi import HipExtensionError
+    fx = load_golden('model_tiny_p16.pt')
+    m = build_model(fx['config'])
+    with pytest.raises(HipExtensionError):
+        m(torch.randn(2, 3, 2, 32, 32), torch.zeros(2, 77, dtype=torch.long))
+    with pytest.raises(HipExtensionError):
+        m.visual.norm(torch.randn(4, 128))
+    from lavila.models.loss import CLIPLoss
+    with pytest.raises(HipExtensionError):
+        CLIPLoss()({'image_embed': torch.randn(4, 8), 'text_embed': torch.randn(4, 8),
+                    'logit_scale': torch.tensor(10.0)})
+
+
+def test_reference_error_behaviour():
+    from lavila.models.timesformer import SpaceTimeTransformer
+    with pytest.raises(NotImplementedError):
+        SpaceTimeTransformer(hybrid_backbone=object())
+    from lavila.models.loss import CLIPLoss
+    with pytest.raises(RuntimeError):
+        CLIPLoss(world_size=2)({'image_embed': torch.randn(2, 8), 'text_embed': torch.randn(2, 8),
+                                'logit_scale': torch.tensor(1.0)})
+
+
+@pytest.mark.skipif(not reference_available(), reason='reference only exists in the build container')
+def test_checkpoint_helpers_match_reference():
+    from oracle.ref_import import load_reference
+    from lavila.models.utils import inflate_positional_embeds, remap_keys
+    ref = load_reference()
+    g = torch.Generator().manual_seed(3)
+    clip = {'class_embedding': torch.randn(8, generator=g), 'positional_embedding': torch.randn(5, 8, generator=g),
+            'conv1.weight': torch.randn(8, 3, 2, 2, generator=g), 'ln_pre.weight': torch.randn(8, generator=g),
+            'ln_pre.bias': torch.randn(8, generator=g), 'ln_post.weight': torch.randn(8, generator=g),
+            'ln_post.bias': torch.randn(8, generator=g), 'proj': torch.randn(8, 4, generator=g)}
+    for layer in range(2):
+        for leaf, shp in [('attn.in_proj_weight', (24, 8)), ('attn.in_proj_bias', (24,)),
+                          ('attn.out_proj.weight', (8, 8)), ('attn.out_proj.bias', (8,)), ('ln_1.weight', (8,)),
+                          ('ln_1.bias', (8,)), ('mlp.c_fc.weight', (32, 8)), ('mlp.c_fc.bias', (32,)),
+                          ('mlp.c_proj.weight', (8, 32)), ('mlp.c_proj.bias', (8,)), ('ln_2.weight', (8,)),
+                          ('ln_2.bias', (8,))]:
+            clip[f'transformer.resblocks.{layer}.{leaf}'] = torch.randn(*shp, generator=g)
+    ours = remap_keys(dict(clip), transformer_layers=2)
+    theirs = ref.utils.remap_keys(dict(clip), transformer_layers=2)
+    assert list(ours.keys()) == list(theirs.keys())
+    for k in ours:
+        assert torch.equal(ours[k], theirs[k]), k
+    for have, want, fix in [(4, 8, 'bilinear'), (8, 4, 'bilinear'), (4, 6, 'zeros'), (4, 7, 'interp'), (4, 4, 'bilinear')]:
+        cur = {'visual.temporal_embed': torch.zeros(1, want, 8), 'visual.pos_embed': torch.zeros(1, 5, 8)}
+        new = {'visual.temporal_embed': torch.randn(1, have, 8, generator=g), 'visual.pos_embed': torch.zeros(1, 5, 8)}
+        a = inflate_positional_embeds(cur, dict(new), num_frames=want, load_temporal_fix=fix)
+        b = ref.utils.inflate_positional_embeds(cur, dict(new), num_frames=want, load_temporal_fix=fix)
+        assert torch.equal(a['visual.temporal_embed'], b['visual.temporal_embed'])
+    with pytest.raises(NotImplementedError):
+        inflate_positional_embeds({'visual.pos_embed': torch.zeros(1, 5, 8)}, {'visual.pos_embed': torch.zeros(1, 10, 8)})

@@ -1,0 +1,240 @@
+"""GPU (-m gpu): every C-ABI kernel against the CPU oracle on the same seeded inputs.
+
+Tolerances: float32 path = f32 round-off of a different summation order (<= 2e-4 abs on O(1) values; the
+north_star bar is 1e-3); bfloat16 path = inputs rounded to bf16 first, oracle evaluated in f32 on the rounded
+inputs, so the allowance covers output rounding (2^-9 relative) and bf16-rounded intermediates."""
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = 'cuda'
+TOL = {torch.float32: dict(atol=2e-4, rtol=2e-4), torch.bfloat16: dict(atol=3e-2, rtol=3e-2)}
+
+
+def _r(x, dt):
+    """round to dt and come back to f32 on CPU (what the oracle sees)"""
+    return x.to(dt).float()
+
+
+def _close(got, want, dt, scale=1.0, msg=''):
+    t = TOL[dt]
+    torch.testing.assert_close(got.float().cpu(), want, atol=t['atol'] * scale, rtol=t['rtol'], msg=lambda m: f'{msg}: {m}')
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('rows,cols,eps', [(37, 128, 1e-6), (4, 768, 1e-5), (1031, 768, 1e-6), (5, 1024, 1e-6),
+                                           (3, 512, 1e-5), (2, 3072, 1e-5), (0, 768, 1e-5)])
+def test_layernorm_fwd_bwd(dt, rows, cols, eps):
+    from lavila_amd import ops
+    g = torch.Generator().manual_seed(rows * 7 + cols)
+    x = _r(torch.randn(rows, cols, generator=g) * 2 + 0.5, dt)
+    w = 1 + 0.2 * torch.randn(cols, generator=g)
+    b = 0.1 * torch.randn(cols, generator=g)
+    dy = _r(torch.randn(rows, cols, generator=g), dt)
+    xo, wo, bo = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yo = O.layer_norm(xo, wo, bo, eps)
+    yo.backward(dy)
+    xg = x.to(DEV, dt).requires_grad_(True)
+    wg, bg = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    y = ops.layer_norm(xg, wg, bg, eps)
+    assert y.dtype == dt and y.shape == x.shape
+    if rows == 0:
+        return
+    y.backward(dy.to(DEV, dt))
+    _close(y, yo.detach(), dt, 4, 'y')
+    _close(xg.grad, xo.grad, dt, 4, 'dx')
+    _close(wg.grad, wo.grad, dt, 0.05 * rows + 1, 'dgamma')
+    _close(bg.grad, bo.grad, dt, 0.05 * rows + 1, 'dbeta')
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('keep_sum,with_bias', [(True, True), (False, True), (True, False), (False, False)])
+def test_add_layernorm_fused(dt, keep_sum, with_bias):
+    from lavila_amd import ops
+    rows, cols, eps = 77, 768, 1e-6
+    g = torch.Generator().manual_seed(11)
+    res, y = _r(torch.randn(rows, cols, generator=g), dt), _r(torch.randn(rows, cols, generator=g), dt)
+    yb = 0.3 * torch.randn(cols, generator=g) if with_bias else None
+    w, b = 1 + 0.2 * torch.randn(cols, generator=g), 0.1 * torch.randn(cols, generator=g)
+    dh, ds = _r(torch.randn(rows, cols, generator=g), dt), _r(torch.randn(rows, cols, generator=g), dt)
+    leaves = [t.clone().requires_grad_(True) if t is not None else None for t in (res, y, yb, w, b)]
+    ro, yo, ybo, wo, bo = leaves
+    so = ro + yo + (ybo if with_bias else 0)
+    if keep_sum and dt == torch.bfloat16:      # the kernel normalises the rounded sum it stores
+        so = so + (_r(so.detach(), dt) - so.detach())
+    ho = O.layer_norm(so, wo, bo, eps)
+    (ho * dh).sum().backward(retain_graph=True) if not keep_sum else ((ho * dh).sum() + (so * ds).sum()).backward()
+    dev = [t.to(DEV, dt if i < 2 else torch.float32).requires_grad_(True) if t is not None else None
+           for i, t in enumerate((res, y, yb, w, b))]
+    s, h = ops.add_layer_norm(dev[0], dev[1], dev[2], dev[3], dev[4], eps, keep_sum=keep_sum)
+    assert (s is None) == (not keep_sum)
+    loss = (h.float() * dh.to(DEV)).sum()
+    if keep_sum:
+        loss = loss + (s.float() * ds.to(DEV)).sum()
+        _close(s, so.detach(), dt, 4, 's')
+    loss.backward()
+    _close(h, ho.detach(), dt, 6, 'h')
+    _close(dev[0].grad, ro.grad, dt, 6, 'dres')
+    _close(dev[1].grad, yo.grad, dt, 6, 'dy')
+    if with_bias:
+        _close(dev[2].grad, ybo.grad, dt, 10, 'dybias')
+    _close(dev[3].grad, wo.grad, dt, 8, 'dgamma')
+    _close(dev[4].grad, bo.grad, dt, 8, 'dbeta')
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('rows,cols,with_bias', [(33, 3072, True), (5, 512, True), (300, 4096, True), (9, 2048, False)])
+def test_bias_quickgelu(dt, rows, cols, with_bias):
+    from lavila_amd import ops
+    g = torch.Generator().manual_seed(rows + cols)
+    u = _r(2 * torch.randn(rows, cols, generator=g), dt)
+    b = 0.5 * torch.randn(cols, generator=g) if with_bias else None
+    da = _r(torch.randn(rows, cols, generator=g), dt)
+    uo = u.clone().requires_grad_(True)
+    bo = b.clone().requires_grad_(True) if with_bias else None
+    ao = O.quick_gelu(uo + bo if with_bias else uo)
+    ao.backward(da)
+    ug = u.to(DEV, dt).requires_grad_(True)
+    bgp = b.to(DEV).requires_grad_(True) if with_bias else None
+    a = ops.bias_quick_gelu(ug, bgp)
+    a.backward(da.to(DEV, dt))
+    _close(a, ao.detach(), dt, 4, 'a')
+    _close(ug.grad, uo.grad, dt, 4, 'du')
+    if with_bias:
+        _close(bgp.grad, bo.grad, dt, 0.1 * rows + 1, 'dbias')
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('B,Fr,img,P', [(2, 2, 32, 16), (3, 4, 224, 16), (2, 3, 42, 14), (1, 2, 224, 14), (2, 1, 24, 8)])
+def test_patchify_and_patch_embed(dt, B, Fr, img, P):
+    from lavila_amd import ops
+    g = torch.Generator().manual_seed(B + img)
+    video = torch.randn(B, 3, Fr, img, img, generator=g)
+    want = _r(O.patchify(video, P), dt)
+    got = ops.patchify(video.to(DEV), P, dt)
+    assert got.shape == want.shape
+    assert torch.equal(got.float().cpu(), want)          # pure gather + one rounding: exact
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+def test_embed_tokens(dt):
+    from lavila_amd import ops
+    B, Fr, N, D, num_frames = 3, 2, 5, 128, 4
+    g = torch.Generator().manual_seed(5)
+    pe = _r(torch.randn(B, Fr * N, D, generator=g), dt)
+    cls, pos, tem = (0.5 * torch.randn(s, generator=g) for s in ((1, 1, D), (1, N + 1, D), (1, num_frames, D)))
+    dx = _r(torch.randn(B, 1 + Fr * N, D, generator=g), dt)
+    lo = [t.clone().requires_grad_(True) for t in (pe, cls, pos, tem)]
+    xo = torch.cat([lo[1].expand(B, -1, -1), lo[0]], 1) + O.total_pos_embed(lo[2], lo[3], N, Fr)
+    xo.backward(dx)
+    lg = [t.to(DEV, dt if i == 0 else torch.float32).requires_grad_(True) for i, t in enumerate((pe, cls, pos, tem))]
+    x = ops.embed_tokens(lg[0], lg[1], lg[2], lg[3], Fr, N)
+    x.backward(dx.to(DEV, dt))
+    _close(x, xo.detach(), dt, 2, 'x')
+    for a, b, n in zip(lg, lo, ('dpe', 'dcls', 'dpos', 'dtemporal')):
+        assert a.grad.shape == b.grad.shape, n
+        _close(a.grad, b.grad, dt, 4, n)
+
+
+def _attn_case(B, Fr, N, H, seed):
+    g = torch.Generator().manual_seed(seed)
+    T, D = 1 + Fr * N, 64 * H
+    return torch.randn(B, T, 3 * D, generator=g) * 1.5, torch.randn(B, T, D, generator=g)
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('mode', ['space', 'time'])
+@pytest.mark.parametrize('B,Fr,N,H', [(2, 3, 5, 2), (2, 2, 49, 3), (3, 1, 7, 2), (2, 16, 4, 1), (1, 4, 196, 2),
+                                      (2, 4, 70, 1)])
+def test_divided_attention_core(dt, mode, B, Fr, N, H):
+    from lavila_amd import ops
+    qkv, dout = _attn_case(B, Fr, N, H, 17 + Fr + N)
+    qkv, dout = _r(qkv, dt), _r(dout, dt)
+    qo = qkv.clone().requires_grad_(True)
+    oo = O.divided_attention_core(qo, H, Fr, N, mode)
+    oo.backward(dout)
+    qg = qkv.to(DEV, dt).requires_grad_(True)
+    o = ops.divided_attention(qg, Fr, N, H, mode)
+    o.backward(dout.to(DEV, dt))
+    _close(o, oo.detach(), dt, 2, 'out')
+    _close(qg.grad, qo.grad, dt, 6, 'dqkv')
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('B,L,H', [(3, 77, 2), (2, 5, 1), (2, 130, 2)])
+def test_causal_attention_core(dt, B, L, H):
+    from lavila_amd import ops
+    g = torch.Generator().manual_seed(L)
+    qkv = _r(torch.randn(B, L, 3 * 64 * H, generator=g) * 1.5, dt)
+    dout = _r(torch.randn(B, L, 64 * H, generator=g), dt)
+    qo = qkv.clone().requires_grad_(True)
+    oo = O.causal_attention_core(qo, H)
+    oo.backward(dout)
+    qg = qkv.to(DEV, dt).requires_grad_(True)
+    o = ops.causal_attention(qg, H)
+    o.backward(dout.to(DEV, dt))
+    _close(o, oo.detach(), dt, 2, 'out')
+    _close(qg.grad, qo.grad, dt, 6, 'dqkv')
+
+
+@pytest.mark.parametrize('case', range(4))
+@pytest.mark.parametrize('mode', ['space', 'time'])
+def test_var_attention_module_vs_reference_golden(case, mode):
+    """Whole VarAttention layer (qkv Linear -> HIP core -> proj Linear) against outputs of the reference."""
+    from lavila.models.timesformer import VarAttention
+    rec = load_golden('var_attention.pt')[case]
+    D = 64 * rec['H']
+    m = VarAttention(D, num_heads=rec['H'], qkv_bias=True)
+    m.load_state_dict(O.procedural_weights(rec['shapes'], seed=11))
+    m.to(DEV)
+    x = rec['x'].to(DEV).requires_grad_(True)
+    pat = {'space': ('b (f n) d', '(b f) n d', {'f': rec['F']}), 'time': ('b (f n) d', '(b n) f d', {'n': rec['N']})}[mode]
+    y = m(x, *pat)
+    y.backward(rec['gout'].to(DEV))
+    torch.testing.assert_close(y.detach().cpu(), rec[mode]['y'], atol=1e-4, rtol=1e-3)
+    torch.testing.assert_close(x.grad.cpu(), rec[mode]['dx'], atol=1e-4, rtol=1e-3)
+    for k, p in m.named_parameters():
+        torch.testing.assert_close(p.grad.cpu(), rec[mode]['dw'][k], atol=3e-4, rtol=1e-3, msg=lambda s: f'{k}: {s}')
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('B,G,E,row0', [(4, 4, 64, 0), (3, 12, 32, 6), (32, 256, 256, 64), (5, 300, 8, 295)])
+def test_clip_loss_slabs(dt, B, G, E, row0):
+    from helpers import oracle_slab_backward, oracle_slab_forward
+    from lavila_amd import ops
+    g = torch.Generator().manual_seed(G + E)
+    img = _r(O.l2_normalize(torch.randn(G, E, generator=g)), dt)
+    txt = _r(O.l2_normalize(torch.randn(G, E, generator=g) + 0.5 * img), dt)
+    scale = torch.tensor([14.285714])
+    lse_all = torch.stack([torch.logsumexp(O.clip_logits(img, txt, scale[0]), 1),
+                           torch.logsumexp(O.clip_logits(img, txt, scale[0]), 0)])
+    st_o, am_o = oracle_slab_forward(img, txt, scale[0], B, row0)
+    up = torch.tensor([0.7])
+    di_o, dt_o = oracle_slab_backward(img, txt, lse_all, scale, up, 3.0 / (2 * G), B, row0)
+    ig, tg = img.to(DEV, dt), txt.to(DEV, dt)
+    st, am, lg = ops.clip_loss_fwd_raw(ig, tg, scale.to(DEV), B, row0, want_logits=True)
+    li = O.clip_logits(img, txt, scale[0])
+    want_logits = torch.stack([li[row0:row0 + B], li.t()[row0:row0 + B]])
+    torch.testing.assert_close(lg.cpu(), want_logits, atol=1e-4, rtol=1e-4)       # f32 accumulate in both dtypes
+    torch.testing.assert_close(st.cpu(), st_o, atol=1e-4, rtol=1e-4)
+    assert torch.equal(am.cpu(), am_o)                                             # indices: bit-exact
+    di, dtx = ops.clip_loss_bwd_raw(ig, tg, lse_all.to(DEV), scale.to(DEV), up.to(DEV), 3.0 / (2 * G), B, row0)
+    torch.testing.assert_close(di.cpu(), di_o, atol=2e-5, rtol=1e-3)
+    torch.testing.assert_close(dtx.cpu(), dt_o, atol=2e-5, rtol=1e-3)
+
+
+def test_kernel_argument_errors_are_loud():
+    from lavila_amd import ops
+    from lavila_amd._cabi import HipExtensionError
+    x = torch.randn(4, 100, device=DEV)          # cols % 8 != 0
+    with pytest.raises(HipExtensionError):
+        ops.layer_norm(x, torch.ones(100, device=DEV), torch.zeros(100, device=DEV), 1e-5)
+    with pytest.raises(HipExtensionError):
+        ops.divided_attention(torch.randn(2, 11, 3 * 96, device=DEV), 2, 5, 3, 'space')   # head dim 32
+    with pytest.raises(HipExtensionError):
+        ops.layer_norm(torch.randn(4, 128, device=DEV, dtype=torch.float16), torch.ones(128, device=DEV),
+                       torch.zeros(128, device=DEV), 1e-5)
