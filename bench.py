@@ -1,0 +1,224 @@
+#!/usr/bin/env python
+"""bench.py -- clip-text pairs/s of the dual-encoder pretraining step on N MI355X GPUs of one node.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = forward (TimeSformer-B/16 video tower on 4x224^2 clips + CLIP text tower on 32-token captions padded to
+77) + all-gathered InfoNCE loss + backward + AdamW update, bf16 autocast over f32 master weights, local batch
+256 per GPU (BASELINE.json configs[1]; weak scaling). Synthetic data, seeded random
+weights with the temporal attention randomised so it is live. Rank 0 prints ONE JSON line.
+
+Extra objects in the line:
+  roofline     -- the dominant hand-written kernel (space-mode divided attention forward, lvl_divided_attn_fwd):
+                  algorithmic bytes per launch / its average duration, measured with HIP events on the launch
+                  stream inside the timed region, against the 8 TB/s HBM peak.
+  cpu_baseline -- the CPU oracle (oracle/oracle.py, kind "port") timed on this box's host cores on a bounded
+                  sample (one fwd+loss+bwd of a small batch of the same shapes), rank 0 at N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=8)
+    p.add_argument('--warmup', type=int, default=2)
+    p.add_argument('--batch', type=int, default=256, help='local batch per GPU')
+    p.add_argument('--frames', type=int, default=4)
+    p.add_argument('--model', default='CLIP_OPENAI_TIMESFORMER_BASE')
+    p.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
+    p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--cpu-batch', type=int, default=4)
+    p.add_argument('--no-events', action='store_true', help='skip per-launch HIP events (A/B their overhead)')
+    return p.parse_args()
+
+
+class KernelTimer:
+    """HIP-event pairs around every launch of one C-ABI op on the current (launch) stream."""
+
+    def __init__(self):
+        self.pairs = []
+        self.enabled = False
+
+    def wrap(self, fn, select):
+        def timed(*a, **k):
+            if not (self.enabled and select(*a, **k)):
+                return fn(*a, **k)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            out = fn(*a, **k)
+            e.record()
+            self.pairs.append((s, e))
+            return out
+        return timed
+
+    def mean_ms(self):
+        if not self.pairs:
+            return None
+        return sum(s.elapsed_time(e) for s, e in self.pairs) / len(self.pairs)
+
+
+def build_model(args, device):
+    import contextlib
+    import io
+    from lavila.models import models
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = getattr(models, args.model)(num_frames=args.frames, pretrained=False, project_embed_dim=256,
+                                            temperature_init=0.07, drop_path_rate=0.0)
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():       # shipped init leaves temporal attention an exact no-op: randomise it (std .02)
+        for n, p in model.named_parameters():
+            if 'timeattn' in n or n.endswith('temporal_embed'):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.02)
+    return model.to(device)
+
+
+def synthetic(args, rank, device, img):
+    from oracle import oracle as O      # data generator only (shared with the parity tests)
+    video, tokens = O.synthetic_batch(args.batch, args.frames, img, seed=1234 + rank)
+    return video.to(device), tokens.to(device)
+
+
+def cpu_baseline(args, model, img):
+    """Times the CPU oracle (port of the reference path) on one small batch: fwd + loss + bwd, f32."""
+    from oracle import oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    w = {k: v.detach().float().cpu().clone().requires_grad_(v.is_floating_point())
+         for k, v in model.state_dict().items()}
+    video, tokens = O.synthetic_batch(args.cpu_batch, args.frames, img, seed=99)
+    vis_heads = model.visual.blocks[0].attn.num_heads
+    txt_heads = model.transformer.resblocks[0].attn.num_heads
+    best = None
+    t_total = 0.0
+    for _ in range(2):
+        t0 = time.perf_counter()
+        out = O.clip_forward(video, tokens, w, vis_heads, txt_heads, norm_embed=True)
+        O.clip_loss(out['image_embed'], out['text_embed'], out['logit_scale'])['loss'].backward()
+        dt = time.perf_counter() - t0
+        t_total += dt
+        best = dt if best is None else min(best, dt)
+        for v in w.values():
+            v.grad = None
+        if t_total > 25:
+            break
+    return {'value': round(args.cpu_batch / best, 4), 'unit': 'clip-text pairs/s', 'cores': cores, 'kind': 'port',
+            'sample': f'oracle/oracle.py fwd+loss+bwd (no optimizer), f32, batch {args.cpu_batch}, '
+                      f'{args.frames}x{img}^2 clips + 77-token captions, best of {1 if t_total > 25 else 2}'}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
+    assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs (there is no CPU path)'
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=device)     # RCCL over xGMI
+
+    from lavila_amd import ops
+    from lavila.models.loss import CLIPLoss
+    timer = KernelTimer()
+    ops.divided_attention = timer.wrap(ops.divided_attention, lambda qkv, f, n, h, mode: mode == 'space')
+
+    model = build_model(args, device)
+    img = model.visual.patch_embed.img_size[0]
+    net = model
+    if world > 1:
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], bucket_cap_mb=200,
+                                                        gradient_as_bucket_view=True)
+    crit = CLIPLoss(use_vissl=True, cache_labels=True, rank=rank, world_size=world)
+    decay = [p for n, p in model.named_parameters() if not (p.ndim < 2 or 'bias' in n or 'ln' in n or 'bn' in n)]
+    no_decay = [p for n, p in model.named_parameters() if (p.ndim < 2 or 'bias' in n or 'ln' in n or 'bn' in n)]
+    opt = torch.optim.AdamW([{'params': decay, 'weight_decay': 0.01}, {'params': no_decay, 'weight_decay': 0.0}],
+                            lr=3e-5, betas=(0.9, 0.999), eps=1e-8, fused=True)
+    video, tokens = synthetic(args, rank, device, img)
+    amp = torch.bfloat16 if args.dtype == 'bf16' else None
+
+    def step():
+        with torch.autocast('cuda', dtype=amp, enabled=amp is not None):
+            out = net(video, tokens, use_checkpoint=False, norm_embed=True)
+            loss = crit(out)['loss']
+        loss.backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        model.logit_scale.data.clamp_(0, 4.6052)       # main_pretrain.py:527-528
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    timer.enabled = not args.no_events
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    final_loss = float(loss.item())
+
+    if rank == 0:
+        B, Fr = args.batch, args.frames
+        N = model.visual.patches_per_frame
+        T = 1 + Fr * N
+        D = model.visual.embed_dim
+        esize = 2 if amp is not None else 4
+        alg_bytes = B * (T * 3 * D + T * D) * esize            # read packed qkv once, write out once
+        kms = timer.mean_ms()
+        roofline = None
+        if kms:
+            achieved = alg_bytes / (kms * 1e-3) / 1e9
+            roofline = {'bound': 'hbm', 'kernel': 'lvl_divided_attn_fwd[space]', 'achieved': round(achieved, 1),
+                        'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
+                        'traffic': None, 'avg_ms': round(kms, 4), 'launches': len(timer.pairs),
+                        'alg_bytes_per_launch': alg_bytes}
+        line = {
+            'metric': 'clip-text pairs/s (whole node), TSF-B/16 4x224^2 + CLIP text tower, fwd+loss+bwd+AdamW',
+            'value': round(world * B * args.steps / elapsed, 2), 'unit': 'clip-text pairs/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'bf16' if amp is not None else 'f32', 'data': 'synthetic',
+            'config': {'workload': f'{args.model}: TSF-B/16 {Fr}x{img}^2 clips + 32-token captions (77 ctx), '
+                                   f'local batch {B}, global batch {world * B}, contrastive all-gather over RCCL',
+                       'global_batch': world * B, 'parallelism': f'dp{world}', 'final_loss': round(final_loss, 4)},
+            'roofline': roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(args, model, img)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -219,7 +219,7 @@ int lvl_launch_column_reduce(const float* part, int nparts, int width, int seg, 
 extern "C" int lvl_layernorm_fwd(const void* x, const void* x2, const float* xbias, const float* gamma,
                                  const float* beta, void* s_out, void* y, float* mean, float* rstd, int64_t rows,
                                  int cols, float eps, int dtype, void* stream) {
-  LVL_REQUIRE(x && gamma && beta && y, "layernorm_fwd: null pointer");
+  LVL_REQUIRE(rows == 0 || (x && gamma && beta && y), "layernorm_fwd: null pointer");
   LVL_REQUIRE(rows >= 0 && cols > 0 && cols % 8 == 0 && cols <= 4096,
               "layernorm_fwd: cols=%d must be a multiple of 8, <= 4096", cols);
   LVL_REQUIRE(lvl_aligned16(x) && lvl_aligned16(x2) && lvl_aligned16(xbias) && lvl_aligned16(y) &&
@@ -247,7 +247,7 @@ extern "C" int lvl_layernorm_bwd(const void* dy, const void* x, const void* x2, 
                                  const float* gamma, const float* mean, const float* rstd, const void* dadd,
                                  void* dx, float* dgamma, float* dbeta, float* dxsum, float* ws, int64_t rows,
                                  int cols, int dtype, void* stream) {
-  LVL_REQUIRE(dy && x && gamma && mean && rstd && dx && ws, "layernorm_bwd: null pointer");
+  LVL_REQUIRE((rows == 0 || (dy && x && mean && rstd && dx)) && gamma && ws, "layernorm_bwd: null pointer");
   LVL_REQUIRE(rows >= 0 && cols > 0 && cols % 8 == 0 && cols <= 4096,
               "layernorm_bwd: cols=%d must be a multiple of 8, <= 4096", cols);
   LVL_REQUIRE(lvl_aligned16(dy) && lvl_aligned16(x) && lvl_aligned16(x2) && lvl_aligned16(xbias) &&
