@@ -95,9 +95,10 @@ int lvl_embed_tokens_fwd(const void* pe, const float* cls, const float* pos, con
  * location (LVL_ATTN_TIME: F queries x [cls + F] keys), softmax in f32, heads merged.
  * qkv: [B,T,3*H*64] dtype (T = 1+F*N; q|k|v thirds, head-major inside each third);
  * out/dout: [B,T,H*64] dtype; lse: [B,H,T] f32 (log-sum-exp of every query row, saved for backward);
- * dqkv: [B,T,3*H*64] dtype. bwd workspace: lvl_workspace_floats("divided_attn_bwd", B*H, T). */
-int lvl_divided_attn_fwd(const void* qkv, void* out, float* lse, int B, int F, int N, int H,
-                         int mode, int dtype, void* stream);
+ * dqkv: [B,T,3*H*64] dtype. Workspaces (f32): fwd lvl_workspace_floats("divided_attn_fwd", B*H, T)
+ * (partial records of the CLS row), bwd lvl_workspace_floats("divided_attn_bwd", B*H, T). */
+int lvl_divided_attn_fwd(const void* qkv, void* out, float* lse, float* ws, int B, int F, int N,
+                         int H, int mode, int dtype, void* stream);
 int lvl_divided_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
                          void* dqkv, float* ws, int B, int F, int N, int H, int mode, int dtype,
                          void* stream);

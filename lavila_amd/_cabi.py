@@ -29,7 +29,7 @@ SIGNATURES = {
     'lvl_bias_quickgelu_bwd': (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
     'lvl_patchify': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'lvl_embed_tokens_fwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
-    'lvl_divided_attn_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    'lvl_divided_attn_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'lvl_divided_attn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'lvl_causal_attn_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     'lvl_causal_attn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

@@ -9,6 +9,10 @@ int lvl_generic_divided_bwd(const void* qkv, const void* out, const void* dout, 
 int lvl_generic_causal_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, int dtype, hipStream_t st);
 int lvl_generic_causal_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
                            float* ws, int B, int L, int H, int dtype, hipStream_t st);
+bool lvl_space_mfma_supported(int F, int N);
+int lvl_space_mfma_fwd(const void* qkv, void* out, float* lse, float* ws, int B, int F, int N, int H, hipStream_t st);
+bool lvl_time_fast_supported(int F, int N, int H);
+int lvl_time_fast_fwd(const void* qkv, void* out, float* lse, float* ws, int B, int F, int N, int H, hipStream_t st);
 
 static int check_divided(const char* name, const void* qkv, const void* out, int B, int F, int N, int H, int mode,
                          int dtype) {
@@ -20,11 +24,15 @@ static int check_divided(const char* name, const void* qkv, const void* out, int
   return LVL_OK;
 }
 
-extern "C" int lvl_divided_attn_fwd(const void* qkv, void* out, float* lse, int B, int F, int N, int H, int mode,
-                                    int dtype, void* stream) {
+extern "C" int lvl_divided_attn_fwd(const void* qkv, void* out, float* lse, float* ws, int B, int F, int N, int H,
+                                    int mode, int dtype, void* stream) {
   if (int rc = check_divided("divided_attn_fwd", qkv, out, B, F, N, H, mode, dtype)) return rc;
-  LVL_REQUIRE(lse, "divided_attn_fwd: null lse");
+  LVL_REQUIRE(lse && ws, "divided_attn_fwd: null lse / workspace");
   if (B == 0) return LVL_OK;
+  if (dtype == LVL_BF16 && mode == LVL_ATTN_SPACE && lvl_space_mfma_supported(F, N))
+    return lvl_space_mfma_fwd(qkv, out, lse, ws, B, F, N, H, (hipStream_t)stream);
+  if (dtype == LVL_BF16 && mode == LVL_ATTN_TIME && lvl_time_fast_supported(F, N, H))
+    return lvl_time_fast_fwd(qkv, out, lse, ws, B, F, N, H, (hipStream_t)stream);
   return lvl_generic_divided_fwd(qkv, out, lse, B, F, N, H, mode, dtype, (hipStream_t)stream, true, true);
 }
 

@@ -220,8 +220,9 @@ class _DividedAttnFn(torch.autograd.Function):
                                       f'(head dim must be 64), frames={frames}, patches/frame={n_per_frame}')
         out = torch.empty(B, T, D, dtype=qkv.dtype, device=qkv.device)
         lse = torch.empty(B, heads, T, dtype=torch.float32, device=qkv.device)
-        C.check(C.lib().lvl_divided_attn_fwd(C.ptr(qkv), C.ptr(out), C.ptr(lse), B, frames, n_per_frame, heads, mode,
-                                             C.dtype_code(qkv), C.stream_ptr()), 'lvl_divided_attn_fwd')
+        ws = C.workspace('divided_attn_fwd', B * heads, T, qkv.device)
+        C.check(C.lib().lvl_divided_attn_fwd(C.ptr(qkv), C.ptr(out), C.ptr(lse), C.ptr(ws), B, frames, n_per_frame,
+                                             heads, mode, C.dtype_code(qkv), C.stream_ptr()), 'lvl_divided_attn_fwd')
         ctx.save_for_backward(qkv, out, lse)
         ctx.cfg = (B, frames, n_per_frame, heads, mode)
         return out
