@@ -12,6 +12,12 @@ int lvl_generic_causal_bwd(const void* qkv, const void* out, const void* dout, c
 bool lvl_space_mfma_supported(int F, int N);
 int lvl_space_mfma_fwd(const void* qkv, void* out, float* lse, float* ws, int B, int F, int N, int H, hipStream_t st);
 bool lvl_time_fast_supported(int F, int N, int H);
+bool lvl_space_mfma_bwd_supported(int F, int N);
+int lvl_space_mfma_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* ws,
+                       int B, int F, int N, int H, hipStream_t st);
+bool lvl_time_fast_bwd_supported(int F, int N, int H);
+int lvl_time_fast_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* ws,
+                      int B, int F, int N, int H, hipStream_t st);
 int lvl_time_fast_fwd(const void* qkv, void* out, float* lse, float* ws, int B, int F, int N, int H, hipStream_t st);
 
 static int check_divided(const char* name, const void* qkv, const void* out, int B, int F, int N, int H, int mode,
@@ -42,6 +48,10 @@ extern "C" int lvl_divided_attn_bwd(const void* qkv, const void* out, const void
   LVL_REQUIRE(dout && lse && dqkv && ws, "divided_attn_bwd: null pointer");
   LVL_REQUIRE(lvl_aligned16(dout) && lvl_aligned16(dqkv), "divided_attn_bwd: pointers must be 16-byte aligned");
   if (B == 0) return LVL_OK;
+  if (dtype == LVL_BF16 && mode == LVL_ATTN_SPACE && lvl_space_mfma_bwd_supported(F, N))
+    return lvl_space_mfma_bwd(qkv, out, dout, lse, dqkv, ws, B, F, N, H, (hipStream_t)stream);
+  if (dtype == LVL_BF16 && mode == LVL_ATTN_TIME && lvl_time_fast_bwd_supported(F, N, H))
+    return lvl_time_fast_bwd(qkv, out, dout, lse, dqkv, ws, B, F, N, H, (hipStream_t)stream);
   return lvl_generic_divided_bwd(qkv, out, dout, lse, dqkv, ws, B, F, N, H, mode, dtype, (hipStream_t)stream);
 }
 

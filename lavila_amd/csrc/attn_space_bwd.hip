@@ -1,0 +1,465 @@
+// Space-mode divided attention backward on the matrix cores (bf16, f32 accumulate), gfx950.
+//
+// With every key of a (sample, frame, head) group LDS-resident the backward recomputes P = exp(S - lse)
+// from the saved row log-sum-exp (no max/sum pass) and needs four contractions:
+//     dP = dO V^T (over d)     dS = P o (dP - delta),  delta_q = dO_q . O_q
+//     dQ = dS K   (over keys)  dK = dS^T Q (over queries)   dV = P^T dO (over queries)
+// A 16x16x32 MFMA wants its contraction index contiguous per lane, so contractions over keys / queries
+// read TRANSPOSED LDS images (Kt[d][key], Qt[d][q], dOt[d][q]) as B operands while the A operand is the
+// freshly computed tile itself: the C layout of S^T (resp. S) puts one query (resp. key) per lane, which
+// is exactly the A-fragment layout with a permuted k-order (same trick as the forward's P.V).
+// Two kernels, each one workgroup of 8 waves per (b, f, h):
+//   dq kernel : waves own 16-query tiles, all keys resident (Ks, Vs row-major, Kt transposed) -> dQ, delta
+//   dkv kernel: waves own 16-key tiles, all queries resident (Qs, dOs row-major, Qt, dOt transposed)
+//               -> dK, dV; also folds in the CLS query's rank-1 contributions to dK/dV (it attends to every
+//               key, timesformer.py:116-119) and accumulates d(cls q) and d(cls k,v) -- which receive
+//               gradient from every frame -- with f32 atomics into a workspace finalised by a tiny kernel.
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+namespace {
+
+constexpr int KS = 80;   // row-major LDS row stride (elements): conflict-free ds_read_b128 fragments
+constexpr int OS = 72;   // per-wave output transposition tile stride
+
+__device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+__device__ __forceinline__ f32x4 mfma(uint4 a, uint4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a), as_bf16x8(b), c, 0, 0, 0);
+}
+
+// Cooperative staging of `nrows` rows of 64 bf16 (row r at src(r)) into a row-major image rm[r*KS + d]
+// (optional) and/or a transposed image tr[d*LD + r] (optional); rows in [nrows, rows_pad) are zero.
+// NT threads, 8 lanes per row. The transposed image is written as packed row pairs with a per-lane
+// rotation so that writes are at most 2-way bank conflicted (see attn_space_mfma.hip).
+template <int NT, typename SrcFn>
+__device__ __forceinline__ void stage_rows(uint16_t* rm, uint16_t* tr, int LD, int rows_pad, int nrows, SrcFn src,
+                                           int tid) {
+  const int c8 = tid & 7, r_in = tid >> 3, par = r_in & 1, rot = c8 & 3;
+#pragma unroll 1
+  for (int r0 = 0; r0 < rows_pad; r0 += NT / 8) {
+    const int r = r0 + r_in;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (r < nrows) v = *reinterpret_cast<const uint4*>(src(r) + c8 * 8);
+    if (rm != nullptr && r < rows_pad) *reinterpret_cast<uint4*>(rm + r * KS + c8 * 8) = v;
+    if (tr != nullptr) {
+      const uint32_t s0 = par ? v.x : v.z, s1 = par ? v.y : v.w;
+      const uint32_t p0 = __shfl_xor(s0, 8, 64), p1 = __shfl_xor(s1, 8, 64);
+      const uint32_t o0 = par ? v.z : v.x, o1 = par ? v.w : v.y;
+      const uint32_t lo0 = par ? p0 : o0, lo1 = par ? p1 : o1;
+      const uint32_t hi0 = par ? o0 : p0, hi1 = par ? o1 : p1;
+      const uint32_t pk0 = (lo0 & 0xffffu) | (hi0 << 16), pk1 = (lo0 >> 16) | (hi0 & 0xffff0000u);
+      const uint32_t pk2 = (lo1 & 0xffffu) | (hi1 << 16), pk3 = (lo1 >> 16) | (hi1 & 0xffff0000u);
+      const uint32_t t0 = (rot & 1) ? pk1 : pk0, t1 = (rot & 1) ? pk2 : pk1, t2 = (rot & 1) ? pk3 : pk2,
+                     t3 = (rot & 1) ? pk0 : pk3;
+      const uint32_t w0 = (rot & 2) ? t2 : t0, w1 = (rot & 2) ? t3 : t1, w2 = (rot & 2) ? t0 : t2,
+                     w3 = (rot & 2) ? t1 : t3;
+      if (r < rows_pad) {
+        uint16_t* col = tr + (size_t)(c8 * 8 + 4 * par) * LD + (r & ~1);
+        *reinterpret_cast<uint32_t*>(col + ((0 + rot) & 3) * LD) = w0;
+        *reinterpret_cast<uint32_t*>(col + ((1 + rot) & 3) * LD) = w1;
+        *reinterpret_cast<uint32_t*>(col + ((2 + rot) & 3) * LD) = w2;
+        *reinterpret_cast<uint32_t*>(col + ((3 + rot) & 3) * LD) = w3;
+      }
+    }
+  }
+}
+
+// writes a 16x64 f32 tile held in the MFMA C layout (o[dt][r] = X[row g*4+r][col dt*16+c]) as bf16 rows:
+// row i of the tile goes to dst(i) (64 contiguous bf16) if valid(i). Per-wave LDS scratch `ot`.
+template <typename DstFn, typename ValidFn>
+__device__ __forceinline__ void store_tile_rows(uint16_t* ot, const f32x4 (&o)[4], float mul, int lane, DstFn dst,
+                                                ValidFn valid) {
+  const int c = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) ot[(g * 4 + r) * OS + dt * 16 + c] = f32_to_bf16(o[dt][r] * mul);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int row = (lane >> 3) + 8 * k, ch = lane & 7;
+    const uint4 v = *reinterpret_cast<const uint4*>(ot + row * OS + ch * 8);
+    if (valid(row)) *reinterpret_cast<uint4*>(dst(row) + ch * 8) = v;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// dQ kernel
+// ------------------------------------------------------------------------------------------------------------
+template <int NKT> struct DqLds {
+  static constexpr int KROWS = NKT * 16, LDK = NKT * 16 + 8;
+  static constexpr int ks_off = 0;
+  static constexpr int vs_off = ks_off + KROWS * KS * 2;
+  static constexpr int kt_off = vs_off + KROWS * KS * 2;
+  static constexpr int ot_off = kt_off + 64 * LDK * 2;
+  static constexpr int total = ot_off + 8 * 16 * OS * 2;
+};
+
+template <int NKT>
+__global__ __launch_bounds__(512) void space_bwd_dq_kernel(const uint16_t* __restrict__ qkv,
+                                                           const uint16_t* __restrict__ out,
+                                                           const uint16_t* __restrict__ dout,
+                                                           const float* __restrict__ lse, uint16_t* __restrict__ dqkv,
+                                                           float* __restrict__ delta, int F, int N, int H) {
+  using L = DqLds<NKT>;
+  constexpr int LDK = L::LDK;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint16_t* Ks = reinterpret_cast<uint16_t*>(smem + L::ks_off);
+  uint16_t* Vs = reinterpret_cast<uint16_t*>(smem + L::vs_off);
+  uint16_t* Kt = reinterpret_cast<uint16_t*>(smem + L::kt_off);
+  uint16_t* Ot = reinterpret_cast<uint16_t*>(smem + L::ot_off);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = blockIdx.x % H, f = (blockIdx.x / H) % F, b = blockIdx.x / (H * F);
+  const int D = H * 64, T = 1 + F * N, nkeys = N + 1, tok0 = 1 + f * N;
+  const size_t ts = (size_t)3 * D;
+  const uint16_t* base = qkv + (size_t)b * T * ts + h * 64;
+  const uint16_t* obase = out + (size_t)b * T * D + h * 64;
+  const uint16_t* dobase = dout + (size_t)b * T * D + h * 64;
+
+  stage_rows<512>(Ks, Kt, LDK, L::KROWS, nkeys,
+                  [&](int r) { return base + (size_t)(r == 0 ? 0 : tok0 + r - 1) * ts + D; }, tid);
+  stage_rows<512>(Vs, nullptr, 0, L::KROWS, nkeys,
+                  [&](int r) { return base + (size_t)(r == 0 ? 0 : tok0 + r - 1) * ts + 2 * D; }, tid);
+  __syncthreads();
+
+  const int c = lane & 15, g = lane >> 4;
+  uint16_t* ot = Ot + wave * 16 * OS;
+#pragma unroll 1
+  for (int qt = wave; qt * 16 < N; qt += 8) {
+    const int qrow = qt * 16 + c;
+    const int tok = tok0 + (qrow < N ? qrow : N - 1);
+    const uint16_t* qp = base + (size_t)tok * ts + g * 8;
+    const uint4 q0 = *reinterpret_cast<const uint4*>(qp), q1 = *reinterpret_cast<const uint4*>(qp + 32);
+    const uint4 g0 = *reinterpret_cast<const uint4*>(dobase + (size_t)tok * D + g * 8);
+    const uint4 g1 = *reinterpret_cast<const uint4*>(dobase + (size_t)tok * D + g * 8 + 32);
+    const uint4 y0 = *reinterpret_cast<const uint4*>(obase + (size_t)tok * D + g * 8);
+    const uint4 y1 = *reinterpret_cast<const uint4*>(obase + (size_t)tok * D + g * 8 + 32);
+    float dl;
+    {
+      float a[8], bb[8];
+      Elem<bf16_t>::load8(reinterpret_cast<const bf16_t*>(&g0), a);
+      Elem<bf16_t>::load8(reinterpret_cast<const bf16_t*>(&y0), bb);
+      dl = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dl = fmaf(a[i], bb[i], dl);
+      Elem<bf16_t>::load8(reinterpret_cast<const bf16_t*>(&g1), a);
+      Elem<bf16_t>::load8(reinterpret_cast<const bf16_t*>(&y1), bb);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dl = fmaf(a[i], bb[i], dl);
+      dl += __shfl_xor(dl, 16, 64);
+      dl += __shfl_xor(dl, 32, 64);
+    }
+    const size_t srow = ((size_t)b * H + h) * T + tok;
+    const float Lq = lse[srow];
+    if (g == 0 && qrow < N) delta[srow] = dl;
+
+    f32x4 ds[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      const uint16_t* kp = Ks + (kt * 16 + c) * KS + g * 8;
+      const uint16_t* vp = Vs + (kt * 16 + c) * KS + g * 8;
+      f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+      s = mfma(*reinterpret_cast<const uint4*>(kp), q0, s);
+      s = mfma(*reinterpret_cast<const uint4*>(kp + 32), q1, s);
+      dp = mfma(*reinterpret_cast<const uint4*>(vp), g0, dp);
+      dp = mfma(*reinterpret_cast<const uint4*>(vp + 32), g1, dp);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kt * 16 + g * 4 + r;
+        const float p = key < nkeys ? __expf(s[r] * 0.125f - Lq) : 0.f;
+        ds[kt][r] = p * (dp[r] - dl);
+      }
+    }
+    f32x4 o[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < (NKT + 1) / 2; ++j) {
+      uint4 pa;
+      pa.x = pack_bf16x2(ds[2 * j][0], ds[2 * j][1]);
+      pa.y = pack_bf16x2(ds[2 * j][2], ds[2 * j][3]);
+      constexpr int last = NKT - 1;
+      const int j1 = 2 * j + 1 <= last ? 2 * j + 1 : last;
+      pa.z = 2 * j + 1 <= last ? pack_bf16x2(ds[j1][0], ds[j1][1]) : 0u;
+      pa.w = 2 * j + 1 <= last ? pack_bf16x2(ds[j1][2], ds[j1][3]) : 0u;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const uint16_t* kp = Kt + (size_t)(dt * 16 + c) * LDK + 2 * j * 16 + g * 4;
+        const uint2 lo = *reinterpret_cast<const uint2*>(kp);
+        uint2 hi = make_uint2(0, 0);
+        if (2 * j + 1 <= last) hi = *reinterpret_cast<const uint2*>(kp + 16);
+        o[dt] = mfma(pa, make_uint4(lo.x, lo.y, hi.x, hi.y), o[dt]);
+      }
+    }
+    store_tile_rows(ot, o, 0.125f, lane,
+                    [&](int row) { return dqkv + (size_t)b * T * ts + (size_t)(tok0 + qt * 16 + row) * ts + h * 64; },
+                    [&](int row) { return qt * 16 + row < N; });
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// dK / dV kernel
+// ------------------------------------------------------------------------------------------------------------
+struct DkvGeom {
+  int QROWS, LDQ;                         // queries padded to a multiple of 32; transposed row stride
+  int qs_off, dos_off, qt_off, dot_off, lse_off, del_off, vec_off, ot_off, total;   // bytes
+};
+
+inline DkvGeom dkv_geometry(int N) {
+  DkvGeom g{};
+  g.QROWS = (N + 31) / 32 * 32;
+  g.LDQ = g.QROWS + 8;
+  g.qs_off = 0;
+  g.dos_off = g.qs_off + g.QROWS * KS * 2;
+  g.qt_off = g.dos_off + g.QROWS * KS * 2;
+  g.dot_off = g.qt_off + 64 * g.LDQ * 2;
+  g.lse_off = g.dot_off + 64 * g.LDQ * 2;
+  g.del_off = g.lse_off + g.QROWS * 4;
+  g.vec_off = g.del_off + g.QROWS * 4;          // f32: qc[64], doc[64], dqc[64], scalars[8]
+  g.ot_off = g.vec_off + (3 * 64 + 8) * 4;
+  g.total = g.ot_off + 8 * 16 * OS * 2;
+  return g;
+}
+
+__global__ __launch_bounds__(512) void space_bwd_dkv_kernel(const uint16_t* __restrict__ qkv,
+                                                            const uint16_t* __restrict__ out,
+                                                            const uint16_t* __restrict__ dout,
+                                                            const float* __restrict__ lse,
+                                                            const float* __restrict__ delta,
+                                                            uint16_t* __restrict__ dqkv, float* __restrict__ atom_ws,
+                                                            int F, int N, int H, DkvGeom G) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint16_t* Qs = reinterpret_cast<uint16_t*>(smem + G.qs_off);
+  uint16_t* dOs = reinterpret_cast<uint16_t*>(smem + G.dos_off);
+  uint16_t* Qt = reinterpret_cast<uint16_t*>(smem + G.qt_off);
+  uint16_t* dOt = reinterpret_cast<uint16_t*>(smem + G.dot_off);
+  float* lse_s = reinterpret_cast<float*>(smem + G.lse_off);
+  float* del_s = reinterpret_cast<float*>(smem + G.del_off);
+  float* qc = reinterpret_cast<float*>(smem + G.vec_off);        // raw cls query
+  float* doc = qc + 64;                                           // d out of the cls row
+  float* dqc = doc + 64;                                          // d cls query accumulator (unscaled)
+  float* scal = dqc + 64;                                         // [0] lse_c, [1] delta_c
+  uint16_t* Ot = reinterpret_cast<uint16_t*>(smem + G.ot_off);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = blockIdx.x % H, f = (blockIdx.x / H) % F, b = blockIdx.x / (H * F);
+  const int D = H * 64, T = 1 + F * N, nkeys = N + 1, tok0 = 1 + f * N;
+  const int LDQ = G.LDQ, QROWS = G.QROWS;
+  const size_t ts = (size_t)3 * D;
+  const uint16_t* base = qkv + (size_t)b * T * ts + h * 64;
+  const uint16_t* dobase = dout + (size_t)b * T * D + h * 64;
+  const float* lrow = lse + ((size_t)b * H + h) * T;
+  const float* drow = delta + ((size_t)b * H + h) * T;
+
+  stage_rows<512>(Qs, Qt, LDQ, QROWS, N, [&](int r) { return base + (size_t)(tok0 + r) * ts; }, tid);
+  stage_rows<512>(dOs, dOt, LDQ, QROWS, N, [&](int r) { return dobase + (size_t)(tok0 + r) * D; }, tid);
+  for (int q = tid; q < QROWS; q += 512) {
+    lse_s[q] = q < N ? lrow[tok0 + q] : INFINITY;      // padded queries: exp(s - inf) = 0
+    del_s[q] = q < N ? drow[tok0 + q] : 0.f;
+  }
+  if (tid < 64) {
+    qc[tid] = bf16_to_f32(base[tid]);
+    const float go = bf16_to_f32(dobase[tid]);
+    doc[tid] = go;
+    dqc[tid] = 0.f;
+    const float dsum = wave_sum(go * bf16_to_f32(out[(size_t)b * T * D + h * 64 + tid]));
+    if (tid == 0) { scal[0] = lrow[0]; scal[1] = dsum; }
+  }
+  __syncthreads();
+
+  const int c = lane & 15, g = lane >> 4;
+  const float Lc = scal[0], dlc = scal[1];
+  uint16_t* ot = Ot + wave * 16 * OS;
+  float dqc_part[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) dqc_part[i] = 0.f;
+
+  const int nkt = (nkeys + 15) / 16;
+#pragma unroll 1
+  for (int kt = wave; kt < nkt; kt += 8) {
+    const int krow = kt * 16 + c;
+    uint4 k0 = make_uint4(0, 0, 0, 0), k1 = k0, v0 = k0, v1 = k0;
+    if (krow < nkeys) {
+      const uint16_t* kp = base + (size_t)(krow == 0 ? 0 : tok0 + krow - 1) * ts + D + g * 8;
+      k0 = *reinterpret_cast<const uint4*>(kp);
+      k1 = *reinterpret_cast<const uint4*>(kp + 32);
+      v0 = *reinterpret_cast<const uint4*>(kp + D);
+      v1 = *reinterpret_cast<const uint4*>(kp + D + 32);
+    }
+    f32x4 adk[4], adv[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { adk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; adv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+#pragma unroll 1
+    for (int qp = 0; qp < QROWS / 32; ++qp) {
+      uint4 pa, da;     // A fragments: P^T and dS^T of 32 queries x this key tile
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int qt = 2 * qp + t;
+        const uint16_t* qsp = Qs + (qt * 16 + c) * KS + g * 8;
+        const uint16_t* dsp = dOs + (qt * 16 + c) * KS + g * 8;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        s = mfma(*reinterpret_cast<const uint4*>(qsp), k0, s);
+        s = mfma(*reinterpret_cast<const uint4*>(qsp + 32), k1, s);
+        dp = mfma(*reinterpret_cast<const uint4*>(dsp), v0, dp);
+        dp = mfma(*reinterpret_cast<const uint4*>(dsp + 32), v1, dp);
+        float p[4], d[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int q = qt * 16 + g * 4 + r;
+          p[r] = __expf(s[r] * 0.125f - lse_s[q]);
+          d[r] = p[r] * (dp[r] - del_s[q]);
+        }
+        if (t == 0) {
+          pa.x = pack_bf16x2(p[0], p[1]); pa.y = pack_bf16x2(p[2], p[3]);
+          da.x = pack_bf16x2(d[0], d[1]); da.y = pack_bf16x2(d[2], d[3]);
+        } else {
+          pa.z = pack_bf16x2(p[0], p[1]); pa.w = pack_bf16x2(p[2], p[3]);
+          da.z = pack_bf16x2(d[0], d[1]); da.w = pack_bf16x2(d[2], d[3]);
+        }
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const uint16_t* gp = dOt + (size_t)(dt * 16 + c) * LDQ + qp * 32 + g * 4;
+        const uint16_t* qq = Qt + (size_t)(dt * 16 + c) * LDQ + qp * 32 + g * 4;
+        const uint2 g_lo = *reinterpret_cast<const uint2*>(gp), g_hi = *reinterpret_cast<const uint2*>(gp + 16);
+        const uint2 q_lo = *reinterpret_cast<const uint2*>(qq), q_hi = *reinterpret_cast<const uint2*>(qq + 16);
+        adv[dt] = mfma(pa, make_uint4(g_lo.x, g_lo.y, g_hi.x, g_hi.y), adv[dt]);
+        adk[dt] = mfma(da, make_uint4(q_lo.x, q_lo.y, q_hi.x, q_hi.y), adk[dt]);
+      }
+    }
+
+    // ---- CLS query (attends to every key): rank-1 terms for this key tile --------------------------------
+    float kf[16], vf[16];
+    {
+      float t8[8];
+      Elem<bf16_t>::load8(reinterpret_cast<const bf16_t*>(&k0), t8);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) kf[i] = t8[i];
+      Elem<bf16_t>::load8(reinterpret_cast<const bf16_t*>(&k1), t8);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) kf[8 + i] = t8[i];
+      Elem<bf16_t>::load8(reinterpret_cast<const bf16_t*>(&v0), t8);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) vf[i] = t8[i];
+      Elem<bf16_t>::load8(reinterpret_cast<const bf16_t*>(&v1), t8);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) vf[8 + i] = t8[i];
+    }
+    float sc = 0.f, dpc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      sc = fmaf(qc[g * 8 + i], kf[i], sc);
+      sc = fmaf(qc[32 + g * 8 + i], kf[8 + i], sc);
+      dpc = fmaf(doc[g * 8 + i], vf[i], dpc);
+      dpc = fmaf(doc[32 + g * 8 + i], vf[8 + i], dpc);
+    }
+    sc += __shfl_xor(sc, 16, 64); sc += __shfl_xor(sc, 32, 64);
+    dpc += __shfl_xor(dpc, 16, 64); dpc += __shfl_xor(dpc, 32, 64);
+    const bool cls_sees = krow < nkeys && (krow > 0 || f == 0);
+    const float pc = cls_sees ? __expf(sc * 0.125f - Lc) : 0.f;
+    const float dsc = pc * (dpc - dlc);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) dqc_part[i] = fmaf(dsc, kf[i], dqc_part[i]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float pr = __shfl(pc, g * 4 + r, 64), dsr = __shfl(dsc, g * 4 + r, 64);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        adv[dt][r] = fmaf(pr, doc[dt * 16 + c], adv[dt][r]);
+        adk[dt][r] = fmaf(dsr, qc[dt * 16 + c], adk[dt][r]);
+      }
+    }
+
+    // ---- the cls KEY (row 0 of tile 0) collects gradient from every frame: f32 atomics ----------------------
+    if (kt == 0 && g == 0) {
+      float* kv0 = atom_ws + ((size_t)b * H + h) * 192 + 64;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        atomicAdd(kv0 + dt * 16 + c, adk[dt][0] * 0.125f);
+        atomicAdd(kv0 + 64 + dt * 16 + c, adv[dt][0]);
+      }
+    }
+    uint16_t* dkb = dqkv + (size_t)b * T * ts + D + h * 64;
+    store_tile_rows(ot, adk, 0.125f, lane, [&](int row) { return dkb + (size_t)(tok0 + kt * 16 + row - 1) * ts; },
+                    [&](int row) { const int kr = kt * 16 + row; return kr >= 1 && kr < nkeys; });
+    store_tile_rows(ot, adv, 1.0f, lane, [&](int row) { return dkb + D + (size_t)(tok0 + kt * 16 + row - 1) * ts; },
+                    [&](int row) { const int kr = kt * 16 + row; return kr >= 1 && kr < nkeys; });
+  }
+
+  // ---- d(cls query): reduce over the 16 key lanes, then across waves in LDS, one atomic per channel ----------
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    float v = dqc_part[i];
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+    dqc_part[i] = v;
+  }
+  if (c == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      atomicAdd(dqc + g * 8 + i, dqc_part[i]);
+      atomicAdd(dqc + 32 + g * 8 + i, dqc_part[8 + i]);
+    }
+  }
+  __syncthreads();
+  if (tid < 64) atomicAdd(atom_ws + ((size_t)b * H + h) * 192 + tid, dqc[tid] * 0.125f);
+}
+
+// dqkv[b, token 0, :] = (d cls q | d cls k | d cls v) from the f32 atomic workspace
+__global__ __launch_bounds__(192) void cls_grad_finalize_kernel(const float* __restrict__ atom_ws,
+                                                                uint16_t* __restrict__ dqkv, int T, int H) {
+  const int h = blockIdx.x % H, b = blockIdx.x / H, t = threadIdx.x;      // t in [0,192): part = t/64
+  const int D = H * 64;
+  dqkv[(size_t)b * T * 3 * D + (t >> 6) * D + h * 64 + (t & 63)] = f32_to_bf16(atom_ws[((size_t)b * H + h) * 192 + t]);
+}
+
+template <int NKT>
+int launch_dq(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* delta, int B,
+              int F, int N, int H, hipStream_t st) {
+  using L = DqLds<NKT>;
+  static_assert(L::total <= 160 * 1024, "LDS per CU");
+  (void)hipFuncSetAttribute((const void*)space_bwd_dq_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, L::total);
+  hipLaunchKernelGGL((space_bwd_dq_kernel<NKT>), dim3((unsigned)(B * F * H)), dim3(512), L::total, st,
+                     (const uint16_t*)qkv, (const uint16_t*)out, (const uint16_t*)dout, lse, (uint16_t*)dqkv, delta, F,
+                     N, H);
+  LVL_CHECK_LAUNCH("space_bwd_dq");
+  return LVL_OK;
+}
+
+}  // namespace
+
+void lvl_launch_cls_grad_finalize(const float* atom_ws, void* dqkv, int B, int T, int H, hipStream_t st) {
+  hipLaunchKernelGGL(cls_grad_finalize_kernel, dim3((unsigned)(B * H)), dim3(192), 0, st, atom_ws, (uint16_t*)dqkv, T, H);
+}
+
+bool lvl_space_mfma_bwd_supported(int F, int N) {
+  return N >= 1 && N + 1 <= 208 && dkv_geometry(N).total <= 160 * 1024 && F <= 64;
+}
+
+// ws layout: delta [B*H*T] f32, then atomics [B*H*192] f32 (d cls q | d cls k | d cls v)
+int lvl_space_mfma_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* ws,
+                       int B, int F, int N, int H, hipStream_t st) {
+  const int T = 1 + F * N, nkeys = N + 1;
+  float* delta = ws;
+  float* atom_ws = ws + (size_t)B * H * T;
+  hipError_t e = hipMemsetAsync(atom_ws, 0, (size_t)B * H * 192 * sizeof(float), st);
+  if (e != hipSuccess) return lvl_fail(LVL_EHIP, "space_bwd memset: %s", hipGetErrorString(e));
+  int rc;
+  if (nkeys <= 64) rc = launch_dq<4>(qkv, out, dout, lse, dqkv, delta, B, F, N, H, st);
+  else if (nkeys <= 128) rc = launch_dq<8>(qkv, out, dout, lse, dqkv, delta, B, F, N, H, st);
+  else rc = launch_dq<13>(qkv, out, dout, lse, dqkv, delta, B, F, N, H, st);
+  if (rc) return rc;
+  const DkvGeom G = dkv_geometry(N);
+  (void)hipFuncSetAttribute((const void*)space_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G.total);
+  hipLaunchKernelGGL(space_bwd_dkv_kernel, dim3((unsigned)(B * F * H)), dim3(512), G.total, st, (const uint16_t*)qkv,
+                     (const uint16_t*)out, (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, atom_ws, F, N, H, G);
+  LVL_CHECK_LAUNCH("space_bwd_dkv");
+  hipLaunchKernelGGL(cls_grad_finalize_kernel, dim3((unsigned)(B * H)), dim3(192), 0, st, atom_ws, (uint16_t*)dqkv, T, H);
+  LVL_CHECK_LAUNCH("cls_grad_finalize");
+  return LVL_OK;
+}

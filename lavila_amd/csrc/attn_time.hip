@@ -154,6 +154,175 @@ __global__ __launch_bounds__(256) void time_fwd_kernel(const uint16_t* __restric
   }
 }
 
+
+// ---- backward ------------------------------------------------------------------------------------------------
+// Same thread geometry as the forward. Everything of a (b, n, h) problem is thread-group local: the softmax is
+// recomputed from the F+1 keys in registers (no saved statistics needed), dq/dk/dv rows of the patch tokens are
+// written exactly once. Gradient of the cls key/value (shared by all N locations) and of the cls query (which
+// attends to every key; its rank-1 terms are folded into dk/dv here) is accumulated per thread group, merged
+// per workgroup through LDS and added to an f32 workspace with atomics (finalised by cls_grad_finalize_kernel).
+template <int F>
+__global__ __launch_bounds__(256) void time_bwd_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out,
+                                                       const uint16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                       uint16_t* __restrict__ dqkv, float* __restrict__ atom_ws, int N,
+                                                       int H, int NPB, int NCH, int NC) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];      // [NPB][H][8 lanes][24]
+  const int tid = threadIdx.x, dl = tid & 7, grp = tid >> 3;
+  const int h = grp % H, n_sub = grp / H;
+  const int chunk = blockIdx.x % NC, b = blockIdx.x / NC;
+  const int D = H * 64, T = 1 + F * N;
+  const size_t ts = (size_t)3 * D;
+  const uint16_t* base = qkv + (size_t)b * T * ts + h * 64 + dl * 8;
+  uint16_t* gbase = dqkv + (size_t)b * T * ts + h * 64 + dl * 8;
+  const uint16_t* obase = out + (size_t)b * T * D + h * 64 + dl * 8;
+  const uint16_t* dobase = dout + (size_t)b * T * D + h * 64 + dl * 8;
+
+  const uint4 kcp = *reinterpret_cast<const uint4*>(base + D);
+  const uint4 vcp = *reinterpret_cast<const uint4*>(base + 2 * D);
+  float qc[8], doc[8], kc[8], vc[8];
+  unpack8(*reinterpret_cast<const uint4*>(base), qc);              // raw cls query
+  unpack8(*reinterpret_cast<const uint4*>(dobase), doc);           // d out of the cls row
+  unpack8(kcp, kc);
+  unpack8(vcp, vc);
+  float dlc;
+  {
+    float oc[8];
+    unpack8(*reinterpret_cast<const uint4*>(obase), oc);
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t = fmaf(doc[i], oc[i], t);
+    dlc = group8_sum(t);
+  }
+  const float Lc = lse[((size_t)b * H + h) * T];
+
+  float dqc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dkc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dvc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (chunk == 0 && n_sub == 0) {     // the cls key inside the CLS row, once per (b,h)
+    float s = 0.f, dp = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s = fmaf(qc[i], kc[i], s); dp = fmaf(doc[i], vc[i], dp); }
+    s = group8_sum(s) * 0.125f;
+    dp = group8_sum(dp);
+    const float p = __expf(s - Lc), ds = p * (dp - dlc) * 0.125f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { dvc[i] = p * doc[i]; dkc[i] = ds * qc[i]; dqc[i] = ds * kc[i]; }
+  }
+
+  const int n_end = min(N, (chunk + 1) * NCH);
+#pragma unroll 1
+  for (int n = chunk * NCH + n_sub; n < n_end; n += NPB) {
+    uint4 kk[F], vv[F];
+    float dk[F][8], dv[F][8];
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+      const uint16_t* p = base + (size_t)(1 + f * N + n) * ts;
+      kk[f] = *reinterpret_cast<const uint4*>(p + D);
+      vv[f] = *reinterpret_cast<const uint4*>(p + 2 * D);
+    }
+    // CLS-row terms for this location's F keys
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+      float kf[8], vf[8];
+      unpack8(kk[f], kf);
+      unpack8(vv[f], vf);
+      float s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { s = fmaf(qc[i], kf[i], s); dp = fmaf(doc[i], vf[i], dp); }
+      s = group8_sum(s) * 0.125f;
+      dp = group8_sum(dp);
+      const float p = __expf(s - Lc), ds = p * (dp - dlc) * 0.125f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        dv[f][i] = p * doc[i];
+        dk[f][i] = ds * qc[i];
+        dqc[i] = fmaf(ds, kf[i], dqc[i]);
+      }
+    }
+    // the F patch queries
+#pragma unroll
+    for (int fq = 0; fq < F; ++fq) {
+      const int tok = 1 + fq * N + n;
+      float q[8], go[8], oo[8];
+      unpack8(*reinterpret_cast<const uint4*>(base + (size_t)tok * ts), q);
+      unpack8(*reinterpret_cast<const uint4*>(dobase + (size_t)tok * D), go);
+      unpack8(*reinterpret_cast<const uint4*>(obase + (size_t)tok * D), oo);
+      float dlt = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dlt = fmaf(go[i], oo[i], dlt);
+      dlt = group8_sum(dlt);
+      float s[F + 1], dp[F + 1];
+      {
+        float a = 0.f, d = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { a = fmaf(q[i], kc[i], a); d = fmaf(go[i], vc[i], d); }
+        s[0] = group8_sum(a) * 0.125f;
+        dp[0] = group8_sum(d);
+      }
+      float mx = s[0];
+#pragma unroll
+      for (int f = 0; f < F; ++f) {
+        s[f + 1] = group8_sum(dot8(q, kk[f])) * 0.125f;
+        dp[f + 1] = group8_sum(dot8(go, vv[f]));
+        mx = fmaxf(mx, s[f + 1]);
+      }
+      float l = 0.f;
+#pragma unroll
+      for (int j = 0; j <= F; ++j) { s[j] = __expf(s[j] - mx); l += s[j]; }
+      const float linv = 1.0f / l;
+      float dq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      {
+        const float p = s[0] * linv, ds = p * (dp[0] - dlt) * 0.125f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          dq[i] = ds * kc[i];
+          dkc[i] = fmaf(ds, q[i], dkc[i]);
+          dvc[i] = fmaf(p, go[i], dvc[i]);
+        }
+      }
+#pragma unroll
+      for (int f = 0; f < F; ++f) {
+        const float p = s[f + 1] * linv, ds = p * (dp[f + 1] - dlt) * 0.125f;
+        float kf[8];
+        unpack8(kk[f], kf);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          dq[i] = fmaf(ds, kf[i], dq[i]);
+          dk[f][i] = fmaf(ds, q[i], dk[f][i]);
+          dv[f][i] = fmaf(p, go[i], dv[f][i]);
+        }
+      }
+      Elem<bf16_t>::store8(reinterpret_cast<bf16_t*>(gbase + (size_t)tok * ts), dq);
+    }
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+      uint16_t* p = gbase + (size_t)(1 + f * N + n) * ts;
+      Elem<bf16_t>::store8(reinterpret_cast<bf16_t*>(p + D), dk[f]);
+      Elem<bf16_t>::store8(reinterpret_cast<bf16_t*>(p + 2 * D), dv[f]);
+    }
+  }
+
+  float* mine = smem + ((size_t)(n_sub * H + h) * 8 + dl) * 24;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { mine[i] = dqc[i]; mine[8 + i] = dkc[i]; mine[16 + i] = dvc[i]; }
+  __syncthreads();
+  if (n_sub == 0) {
+    float acc[24];
+#pragma unroll
+    for (int i = 0; i < 24; ++i) acc[i] = 0.f;
+    for (int s = 0; s < NPB; ++s) {
+      const float* r = smem + ((size_t)(s * H + h) * 8 + dl) * 24;
+#pragma unroll
+      for (int i = 0; i < 24; ++i) acc[i] += r[i];
+    }
+    float* dst = atom_ws + ((size_t)b * H + h) * 192 + dl * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      atomicAdd(dst + i, acc[i]);
+      atomicAdd(dst + 64 + i, acc[8 + i]);
+      atomicAdd(dst + 128 + i, acc[16 + i]);
+    }
+  }
+}
+
 int gcd_int(int a, int b) { return b ? gcd_int(b, a % b) : a; }
 
 struct TimeGeom { int NPB, NCH, NC, block; bool ok; };
@@ -202,5 +371,41 @@ int lvl_time_fast_fwd(const void* qkv, void* out, float* lse, float* ws, int B, 
   LVL_CHECK_LAUNCH("time_fwd");
   lvl_launch_cls_combine(ws, out, lse, B, H, g.NC, 1 + F * N, st);
   LVL_CHECK_LAUNCH("cls_combine");
+  return LVL_OK;
+}
+
+void lvl_launch_cls_grad_finalize(const float* atom_ws, void* dqkv, int B, int T, int H, hipStream_t st);
+
+bool lvl_time_fast_bwd_supported(int F, int N, int H) {
+  if (!(F == 1 || F == 2 || F == 3 || F == 4 || F == 8)) return false;
+  return time_geometry(N, H).ok;
+}
+
+// ws layout: delta [B*H*T] f32 (unused here), then atomics [B*H*192] f32
+int lvl_time_fast_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* ws,
+                      int B, int F, int N, int H, hipStream_t st) {
+  const TimeGeom g = time_geometry(N, H);
+  if (!g.ok) return lvl_fail(LVL_ENOSYS, "time_fast_bwd: unsupported head count %d", H);
+  const int T = 1 + F * N;
+  float* atom_ws = ws + (size_t)B * H * T;
+  hipError_t e = hipMemsetAsync(atom_ws, 0, (size_t)B * H * 192 * sizeof(float), st);
+  if (e != hipSuccess) return lvl_fail(LVL_EHIP, "time_bwd memset: %s", hipGetErrorString(e));
+  const size_t shmem = (size_t)g.NPB * H * 8 * 24 * sizeof(float);
+  const dim3 grid((unsigned)(B * g.NC)), block(g.block);
+#define TIME_BWD(FF)                                                                                              \
+  hipLaunchKernelGGL((time_bwd_kernel<FF>), grid, block, shmem, st, (const uint16_t*)qkv, (const uint16_t*)out,   \
+                     (const uint16_t*)dout, lse, (uint16_t*)dqkv, atom_ws, N, H, g.NPB, g.NCH, g.NC)
+  switch (F) {
+    case 1: TIME_BWD(1); break;
+    case 2: TIME_BWD(2); break;
+    case 3: TIME_BWD(3); break;
+    case 4: TIME_BWD(4); break;
+    case 8: TIME_BWD(8); break;
+    default: return lvl_fail(LVL_ENOSYS, "time_fast_bwd: unsupported frame count %d", F);
+  }
+#undef TIME_BWD
+  LVL_CHECK_LAUNCH("time_bwd");
+  lvl_launch_cls_grad_finalize(atom_ws, dqkv, B, T, H, st);
+  LVL_CHECK_LAUNCH("cls_grad_finalize");
   return LVL_OK;
 }

@@ -24,7 +24,7 @@ extern "C" int64_t lvl_workspace_floats(const char* op, int64_t rows, int64_t co
   if (!strcmp(op, "layernorm_bwd")) return (int64_t)lvl_ln_bwd_parts() * 3 * cols;
   if (!strcmp(op, "bias_quickgelu_bwd")) return (int64_t)lvl_gelu_bwd_row_blocks() * cols;
   if (!strcmp(op, "divided_attn_fwd")) return rows * 64 * 66;   // <= 64 CLS-row partial records per (b,h)
-  if (!strcmp(op, "divided_attn_bwd")) return rows * cols;   // delta [B*H, T]
+  if (!strcmp(op, "divided_attn_bwd")) return rows * cols + rows * 192;   // delta [B*H, T] + cls-grad atomics
   if (!strcmp(op, "causal_attn_bwd")) return rows * cols;    // delta [B*H, L]
   return -1;
 }
