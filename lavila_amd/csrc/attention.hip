@@ -12,6 +12,11 @@ int lvl_generic_causal_bwd(const void* qkv, const void* out, const void* dout, c
 bool lvl_space_mfma_supported(int F, int N);
 int lvl_space_mfma_fwd(const void* qkv, void* out, float* lse, float* ws, int B, int F, int N, int H, hipStream_t st);
 bool lvl_time_fast_supported(int F, int N, int H);
+bool lvl_text_mfma_supported(int L);
+int lvl_text_mfma_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, hipStream_t st);
+bool lvl_text_mfma_bwd_supported(int L);
+int lvl_text_mfma_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* ws,
+                      int B, int L, int H, hipStream_t st);
 bool lvl_space_mfma_bwd_supported(int F, int N);
 int lvl_space_mfma_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* ws,
                        int B, int F, int N, int H, hipStream_t st);
@@ -61,6 +66,7 @@ extern "C" int lvl_causal_attn_fwd(const void* qkv, void* out, float* lse, int B
   LVL_REQUIRE(B >= 0 && L > 0 && H > 0, "causal_attn_fwd: bad shape B=%d L=%d H=%d", B, L, H);
   LVL_REQUIRE(lvl_aligned16(qkv) && lvl_aligned16(out), "causal_attn_fwd: pointers must be 16-byte aligned");
   if (B == 0) return LVL_OK;
+  if (dtype == LVL_BF16 && lvl_text_mfma_supported(L)) return lvl_text_mfma_fwd(qkv, out, lse, B, L, H, (hipStream_t)stream);
   return lvl_generic_causal_fwd(qkv, out, lse, B, L, H, dtype, (hipStream_t)stream);
 }
 
@@ -71,5 +77,7 @@ extern "C" int lvl_causal_attn_bwd(const void* qkv, const void* out, const void*
   LVL_REQUIRE(lvl_aligned16(qkv) && lvl_aligned16(out) && lvl_aligned16(dout) && lvl_aligned16(dqkv),
               "causal_attn_bwd: pointers must be 16-byte aligned");
   if (B == 0) return LVL_OK;
+  if (dtype == LVL_BF16 && lvl_text_mfma_bwd_supported(L))
+    return lvl_text_mfma_bwd(qkv, out, dout, lse, dqkv, ws, B, L, H, (hipStream_t)stream);
   return lvl_generic_causal_bwd(qkv, out, dout, lse, dqkv, ws, B, L, H, dtype, (hipStream_t)stream);
 }

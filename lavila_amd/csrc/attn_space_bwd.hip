@@ -99,7 +99,7 @@ template <int NKT> struct DqLds {
   static constexpr int total = ot_off + 8 * 16 * OS * 2;
 };
 
-template <int NKT>
+template <int NKT, bool TEXT>
 __global__ __launch_bounds__(512) void space_bwd_dq_kernel(const uint16_t* __restrict__ qkv,
                                                            const uint16_t* __restrict__ out,
                                                            const uint16_t* __restrict__ dout,
@@ -115,16 +115,16 @@ __global__ __launch_bounds__(512) void space_bwd_dq_kernel(const uint16_t* __res
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = blockIdx.x % H, f = (blockIdx.x / H) % F, b = blockIdx.x / (H * F);
-  const int D = H * 64, T = 1 + F * N, nkeys = N + 1, tok0 = 1 + f * N;
+  const int D = H * 64, T = TEXT ? N : 1 + F * N, nkeys = TEXT ? N : N + 1, tok0 = TEXT ? 0 : 1 + f * N;
   const size_t ts = (size_t)3 * D;
   const uint16_t* base = qkv + (size_t)b * T * ts + h * 64;
   const uint16_t* obase = out + (size_t)b * T * D + h * 64;
   const uint16_t* dobase = dout + (size_t)b * T * D + h * 64;
 
   stage_rows<512>(Ks, Kt, LDK, L::KROWS, nkeys,
-                  [&](int r) { return base + (size_t)(r == 0 ? 0 : tok0 + r - 1) * ts + D; }, tid);
+                  [&](int r) { return base + (size_t)(TEXT ? r : (r == 0 ? 0 : tok0 + r - 1)) * ts + D; }, tid);
   stage_rows<512>(Vs, nullptr, 0, L::KROWS, nkeys,
-                  [&](int r) { return base + (size_t)(r == 0 ? 0 : tok0 + r - 1) * ts + 2 * D; }, tid);
+                  [&](int r) { return base + (size_t)(TEXT ? r : (r == 0 ? 0 : tok0 + r - 1)) * ts + 2 * D; }, tid);
   __syncthreads();
 
   const int c = lane & 15, g = lane >> 4;
@@ -171,7 +171,8 @@ __global__ __launch_bounds__(512) void space_bwd_dq_kernel(const uint16_t* __res
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = kt * 16 + g * 4 + r;
-        const float p = key < nkeys ? __expf(s[r] * 0.125f - Lq) : 0.f;
+        const bool vis = key < nkeys && (!TEXT || key <= qrow);
+        const float p = vis ? __expf(s[r] * 0.125f - Lq) : 0.f;
         ds[kt][r] = p * (dp[r] - dl);
       }
     }
@@ -226,6 +227,7 @@ inline DkvGeom dkv_geometry(int N) {
   return g;
 }
 
+template <bool TEXT>
 __global__ __launch_bounds__(512) void space_bwd_dkv_kernel(const uint16_t* __restrict__ qkv,
                                                             const uint16_t* __restrict__ out,
                                                             const uint16_t* __restrict__ dout,
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(512) void space_bwd_dkv_kernel(const uint16_t* __re
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = blockIdx.x % H, f = (blockIdx.x / H) % F, b = blockIdx.x / (H * F);
-  const int D = H * 64, T = 1 + F * N, nkeys = N + 1, tok0 = 1 + f * N;
+  const int D = H * 64, T = TEXT ? N : 1 + F * N, nkeys = TEXT ? N : N + 1, tok0 = TEXT ? 0 : 1 + f * N;
   const int LDQ = G.LDQ, QROWS = G.QROWS;
   const size_t ts = (size_t)3 * D;
   const uint16_t* base = qkv + (size_t)b * T * ts + h * 64;
@@ -262,7 +264,7 @@ __global__ __launch_bounds__(512) void space_bwd_dkv_kernel(const uint16_t* __re
     lse_s[q] = q < N ? lrow[tok0 + q] : INFINITY;      // padded queries: exp(s - inf) = 0
     del_s[q] = q < N ? drow[tok0 + q] : 0.f;
   }
-  if (tid < 64) {
+  if (!TEXT && tid < 64) {
     qc[tid] = bf16_to_f32(base[tid]);
     const float go = bf16_to_f32(dobase[tid]);
     doc[tid] = go;
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(512) void space_bwd_dkv_kernel(const uint16_t* __re
   __syncthreads();
 
   const int c = lane & 15, g = lane >> 4;
-  const float Lc = scal[0], dlc = scal[1];
+  const float Lc = TEXT ? 0.f : scal[0], dlc = TEXT ? 0.f : scal[1];
   uint16_t* ot = Ot + wave * 16 * OS;
   float dqc_part[16];
 #pragma unroll
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(512) void space_bwd_dkv_kernel(const uint16_t* __re
     const int krow = kt * 16 + c;
     uint4 k0 = make_uint4(0, 0, 0, 0), k1 = k0, v0 = k0, v1 = k0;
     if (krow < nkeys) {
-      const uint16_t* kp = base + (size_t)(krow == 0 ? 0 : tok0 + krow - 1) * ts + D + g * 8;
+      const uint16_t* kp = base + (size_t)(TEXT ? krow : (krow == 0 ? 0 : tok0 + krow - 1)) * ts + D + g * 8;
       k0 = *reinterpret_cast<const uint4*>(kp);
       k1 = *reinterpret_cast<const uint4*>(kp + 32);
       v0 = *reinterpret_cast<const uint4*>(kp + D);
@@ -312,7 +314,7 @@ __global__ __launch_bounds__(512) void space_bwd_dkv_kernel(const uint16_t* __re
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int q = qt * 16 + g * 4 + r;
-          p[r] = __expf(s[r] * 0.125f - lse_s[q]);
+          p[r] = (!TEXT || q >= krow) ? __expf(s[r] * 0.125f - lse_s[q]) : 0.f;
           d[r] = p[r] * (dp[r] - del_s[q]);
         }
         if (t == 0) {
@@ -334,6 +336,14 @@ __global__ __launch_bounds__(512) void space_bwd_dkv_kernel(const uint16_t* __re
       }
     }
 
+    if constexpr (TEXT) {
+      uint16_t* dkb = dqkv + (size_t)b * T * ts + D + h * 64;
+      store_tile_rows(ot, adk, 0.125f, lane, [&](int row) { return dkb + (size_t)(kt * 16 + row) * ts; },
+                      [&](int row) { return kt * 16 + row < nkeys; });
+      store_tile_rows(ot, adv, 1.0f, lane, [&](int row) { return dkb + D + (size_t)(kt * 16 + row) * ts; },
+                      [&](int row) { return kt * 16 + row < nkeys; });
+      continue;
+    }
     // ---- CLS query (attends to every key): rank-1 terms for this key tile --------------------------------
     float kf[16], vf[16];
     {
@@ -392,6 +402,7 @@ __global__ __launch_bounds__(512) void space_bwd_dkv_kernel(const uint16_t* __re
                     [&](int row) { const int kr = kt * 16 + row; return kr >= 1 && kr < nkeys; });
   }
 
+  if constexpr (TEXT) return;
   // ---- d(cls query): reduce over the 16 key lanes, then across waves in LDS, one atomic per channel ----------
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
@@ -418,13 +429,14 @@ __global__ __launch_bounds__(192) void cls_grad_finalize_kernel(const float* __r
   dqkv[(size_t)b * T * 3 * D + (t >> 6) * D + h * 64 + (t & 63)] = f32_to_bf16(atom_ws[((size_t)b * H + h) * 192 + t]);
 }
 
-template <int NKT>
+template <int NKT, bool TEXT = false>
 int launch_dq(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* delta, int B,
               int F, int N, int H, hipStream_t st) {
   using L = DqLds<NKT>;
   static_assert(L::total <= 160 * 1024, "LDS per CU");
-  (void)hipFuncSetAttribute((const void*)space_bwd_dq_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, L::total);
-  hipLaunchKernelGGL((space_bwd_dq_kernel<NKT>), dim3((unsigned)(B * F * H)), dim3(512), L::total, st,
+  (void)hipFuncSetAttribute((const void*)space_bwd_dq_kernel<NKT, TEXT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            L::total);
+  hipLaunchKernelGGL((space_bwd_dq_kernel<NKT, TEXT>), dim3((unsigned)(B * F * H)), dim3(512), L::total, st,
                      (const uint16_t*)qkv, (const uint16_t*)out, (const uint16_t*)dout, lse, (uint16_t*)dqkv, delta, F,
                      N, H);
   LVL_CHECK_LAUNCH("space_bwd_dq");
@@ -455,11 +467,30 @@ int lvl_space_mfma_bwd(const void* qkv, const void* out, const void* dout, const
   else rc = launch_dq<13>(qkv, out, dout, lse, dqkv, delta, B, F, N, H, st);
   if (rc) return rc;
   const DkvGeom G = dkv_geometry(N);
-  (void)hipFuncSetAttribute((const void*)space_bwd_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, G.total);
-  hipLaunchKernelGGL(space_bwd_dkv_kernel, dim3((unsigned)(B * F * H)), dim3(512), G.total, st, (const uint16_t*)qkv,
+  (void)hipFuncSetAttribute((const void*)space_bwd_dkv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            G.total);
+  hipLaunchKernelGGL(space_bwd_dkv_kernel<false>, dim3((unsigned)(B * F * H)), dim3(512), G.total, st, (const uint16_t*)qkv,
                      (const uint16_t*)out, (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv, atom_ws, F, N, H, G);
   LVL_CHECK_LAUNCH("space_bwd_dkv");
   hipLaunchKernelGGL(cls_grad_finalize_kernel, dim3((unsigned)(B * H)), dim3(192), 0, st, atom_ws, (uint16_t*)dqkv, T, H);
   LVL_CHECK_LAUNCH("cls_grad_finalize");
+  return LVL_OK;
+}
+
+bool lvl_text_mfma_bwd_supported(int L) { return L >= 1 && L <= 208 && dkv_geometry(L).total <= 160 * 1024; }
+
+// ws: delta [B*H*L] f32
+int lvl_text_mfma_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* ws,
+                      int B, int L, int H, hipStream_t st) {
+  int rc;
+  if (L <= 64) rc = launch_dq<4, true>(qkv, out, dout, lse, dqkv, ws, B, 1, L, H, st);
+  else if (L <= 128) rc = launch_dq<8, true>(qkv, out, dout, lse, dqkv, ws, B, 1, L, H, st);
+  else rc = launch_dq<13, true>(qkv, out, dout, lse, dqkv, ws, B, 1, L, H, st);
+  if (rc) return rc;
+  const DkvGeom G = dkv_geometry(L);
+  (void)hipFuncSetAttribute((const void*)space_bwd_dkv_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, G.total);
+  hipLaunchKernelGGL(space_bwd_dkv_kernel<true>, dim3((unsigned)(B * H)), dim3(512), G.total, st, (const uint16_t*)qkv,
+                     (const uint16_t*)out, (const uint16_t*)dout, lse, ws, (uint16_t*)dqkv, nullptr, 1, L, H, G);
+  LVL_CHECK_LAUNCH("text_bwd_dkv");
   return LVL_OK;
 }

@@ -47,7 +47,9 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
 }
 
-template <int NKT>
+// TEXT = true reuses the kernel for the causal text tower (openai_model.py:196-198): one group per (b, h),
+// L queries x L keys, no cls row, key j visible to query i iff j <= i, no CLS partial.
+template <int NKT, bool TEXT>
 __global__ __launch_bounds__(256, 2) void space_fwd_kernel(const uint16_t* __restrict__ qkv,
                                                            uint16_t* __restrict__ out, float* __restrict__ lse,
                                                            float* __restrict__ cls_ws, int F, int N, int H) {
@@ -63,10 +65,10 @@ __global__ __launch_bounds__(256, 2) void space_fwd_kernel(const uint16_t* __res
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = blockIdx.x % H, f = (blockIdx.x / H) % F, b = blockIdx.x / (H * F);
-  const int D = H * 64, T = 1 + F * N, nkeys = N + 1;
+  const int D = H * 64, T = TEXT ? N : 1 + F * N, nkeys = TEXT ? N : N + 1;
   const size_t tstride = (size_t)3 * D;
   const uint16_t* base = qkv + (size_t)b * T * tstride + h * 64;      // + token*3D (+D: k, +2D: v)
-  const int tok0 = 1 + f * N;                                          // token of key row 1 / query 0
+  const int tok0 = TEXT ? 0 : 1 + f * N;                               // token of query 0 (and of key row 1)
 
   // ---- stage K (row-major) and V (transposed, packed row pairs) ------------------------------------
   {
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(256, 2) void space_fwd_kernel(const uint16_t* __res
       const int r = r0 + r_in;
       uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
       if (r < nkeys) {
-        const uint16_t* p = base + (size_t)(r == 0 ? 0 : tok0 + r - 1) * tstride + c8 * 8;
+        const uint16_t* p = base + (size_t)(TEXT ? r : (r == 0 ? 0 : tok0 + r - 1)) * tstride + c8 * 8;
         kv = *reinterpret_cast<const uint4*>(p + D);
         vv = *reinterpret_cast<const uint4*>(p + 2 * D);
       }
@@ -132,7 +134,8 @@ __global__ __launch_bounds__(256, 2) void space_fwd_kernel(const uint16_t* __res
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = kt * 16 + g * 4 + r;
-        const float s = key < nkeys ? acc[kt][r] * 0.125f : -INFINITY;
+        const bool vis = key < nkeys && (!TEXT || key <= qrow);
+        const float s = vis ? acc[kt][r] * 0.125f : -INFINITY;
         acc[kt][r] = s;
         m = fmaxf(m, s);
       }
@@ -194,6 +197,7 @@ __global__ __launch_bounds__(256, 2) void space_fwd_kernel(const uint16_t* __res
     if (g == 0 && qrow < N) lse[((size_t)b * H + h) * T + tok0 + qrow] = m + __logf(l);
   }
 
+  if constexpr (TEXT) return;
   // ---- CLS query partial over this frame's keys (key row 0 = the cls key itself: frame 0 only) -----------
   float s_loc[2];
   float mloc = -INFINITY;
@@ -274,15 +278,17 @@ __global__ __launch_bounds__(64) void cls_combine_kernel(const float* __restrict
   if (d == 0) lse[((size_t)b * H + h) * T] = M + __logf(Lsum);
 }
 
-template <int NKT>
+template <int NKT, bool TEXT = false>
 int launch_space_fwd(const void* qkv, void* out, float* lse, float* ws, int B, int F, int N, int H, hipStream_t st) {
   using L = SpaceLds<NKT>;
   static_assert(L::total <= 160 * 1024, "LDS per CU");   // <= 80 KB (NKT <= 13) keeps 2 workgroups per CU
   if (L::total > 64 * 1024)
-    (void)hipFuncSetAttribute((const void*)space_fwd_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, L::total);
-  hipLaunchKernelGGL((space_fwd_kernel<NKT>), dim3((unsigned)(B * F * H)), dim3(256), L::total, st,
+    (void)hipFuncSetAttribute((const void*)space_fwd_kernel<NKT, TEXT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              L::total);
+  hipLaunchKernelGGL((space_fwd_kernel<NKT, TEXT>), dim3((unsigned)(B * F * H)), dim3(256), L::total, st,
                      (const uint16_t*)qkv, (uint16_t*)out, lse, ws, F, N, H);
   LVL_CHECK_LAUNCH("space_fwd_mfma");
+  if (TEXT) return LVL_OK;
   hipLaunchKernelGGL(cls_combine_kernel, dim3((unsigned)(B * H)), dim3(64), 0, st, ws, (uint16_t*)out, lse, F,
                      1 + F * N, H);
   LVL_CHECK_LAUNCH("cls_combine");
@@ -304,4 +310,14 @@ int lvl_space_mfma_fwd(const void* qkv, void* out, float* lse, float* ws, int B,
   if (nkeys <= 208) return launch_space_fwd<13>(qkv, out, lse, ws, B, F, N, H, st);
   if (nkeys <= 272) return launch_space_fwd<17>(qkv, out, lse, ws, B, F, N, H, st);
   return lvl_fail(LVL_ENOSYS, "space_mfma_fwd: %d keys per group exceeds the LDS-resident kernel", nkeys);
+}
+
+bool lvl_text_mfma_supported(int L) { return L >= 1 && L <= 272; }
+
+int lvl_text_mfma_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, hipStream_t st) {
+  if (L <= 64) return launch_space_fwd<4, true>(qkv, out, lse, nullptr, B, 1, L, H, st);
+  if (L <= 128) return launch_space_fwd<8, true>(qkv, out, lse, nullptr, B, 1, L, H, st);
+  if (L <= 208) return launch_space_fwd<13, true>(qkv, out, lse, nullptr, B, 1, L, H, st);
+  if (L <= 272) return launch_space_fwd<17, true>(qkv, out, lse, nullptr, B, 1, L, H, st);
+  return lvl_fail(LVL_ENOSYS, "text_mfma_fwd: context length %d exceeds the LDS-resident kernel", L);
 }
