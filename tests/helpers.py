@@ -52,9 +52,10 @@ def oracle_slab_backward(img_all, txt_all, lse_all, scale, upstream, coef, B, ro
     """CPU restatement of lvl_clip_loss_bwd via autograd on the oracle's full loss:
     coef*upstream*d(sum of both CE sums)/d(local rows) = coef*upstream*2G * d(loss)/d(local rows)."""
     G = img_all.shape[0]
-    ia = img_all.float().clone().requires_grad_(True)
-    ta = txt_all.float().clone().requires_grad_(True)
-    loss = O.clip_loss(ia, ta, scale.float().reshape(()))['loss']
-    gi, gt = torch.autograd.grad(loss, [ia, ta])
+    with torch.enable_grad():          # may be called from inside an autograd backward (grad mode off)
+        ia = img_all.float().clone().requires_grad_(True)
+        ta = txt_all.float().clone().requires_grad_(True)
+        loss = O.clip_loss(ia, ta, scale.float().reshape(()))['loss']
+        gi, gt = torch.autograd.grad(loss, [ia, ta])
     k = coef * upstream.reshape(()) * 2 * G
     return (k * gi[row0:row0 + B]).contiguous(), (k * gt[row0:row0 + B]).contiguous()
