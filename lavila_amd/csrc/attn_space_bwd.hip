@@ -14,78 +14,11 @@
 //               -> dK, dV; also folds in the CLS query's rank-1 contributions to dK/dV (it attends to every
 //               key, timesformer.py:116-119) and accumulates d(cls q) and d(cls k,v) -- which receive
 //               gradient from every frame -- with f32 atomics into a workspace finalised by a tiny kernel.
-#include "common.h"
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
+#include "attn_mfma_common.h"
 
 namespace {
 
-constexpr int KS = 80;   // row-major LDS row stride (elements): conflict-free ds_read_b128 fragments
-constexpr int OS = 72;   // per-wave output transposition tile stride
-
-__device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
-__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
-}
-__device__ __forceinline__ f32x4 mfma(uint4 a, uint4 b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a), as_bf16x8(b), c, 0, 0, 0);
-}
-
-// Cooperative staging of `nrows` rows of 64 bf16 (row r at src(r)) into a row-major image rm[r*KS + d]
-// (optional) and/or a transposed image tr[d*LD + r] (optional); rows in [nrows, rows_pad) are zero.
-// NT threads, 8 lanes per row. The transposed image is written as packed row pairs with a per-lane
-// rotation so that writes are at most 2-way bank conflicted (see attn_space_mfma.hip).
-template <int NT, typename SrcFn>
-__device__ __forceinline__ void stage_rows(uint16_t* rm, uint16_t* tr, int LD, int rows_pad, int nrows, SrcFn src,
-                                           int tid) {
-  const int c8 = tid & 7, r_in = tid >> 3, par = r_in & 1, rot = c8 & 3;
-#pragma unroll 1
-  for (int r0 = 0; r0 < rows_pad; r0 += NT / 8) {
-    const int r = r0 + r_in;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (r < nrows) v = *reinterpret_cast<const uint4*>(src(r) + c8 * 8);
-    if (rm != nullptr && r < rows_pad) *reinterpret_cast<uint4*>(rm + r * KS + c8 * 8) = v;
-    if (tr != nullptr) {
-      const uint32_t s0 = par ? v.x : v.z, s1 = par ? v.y : v.w;
-      const uint32_t p0 = __shfl_xor(s0, 8, 64), p1 = __shfl_xor(s1, 8, 64);
-      const uint32_t o0 = par ? v.z : v.x, o1 = par ? v.w : v.y;
-      const uint32_t lo0 = par ? p0 : o0, lo1 = par ? p1 : o1;
-      const uint32_t hi0 = par ? o0 : p0, hi1 = par ? o1 : p1;
-      const uint32_t pk0 = (lo0 & 0xffffu) | (hi0 << 16), pk1 = (lo0 >> 16) | (hi0 & 0xffff0000u);
-      const uint32_t pk2 = (lo1 & 0xffffu) | (hi1 << 16), pk3 = (lo1 >> 16) | (hi1 & 0xffff0000u);
-      const uint32_t t0 = (rot & 1) ? pk1 : pk0, t1 = (rot & 1) ? pk2 : pk1, t2 = (rot & 1) ? pk3 : pk2,
-                     t3 = (rot & 1) ? pk0 : pk3;
-      const uint32_t w0 = (rot & 2) ? t2 : t0, w1 = (rot & 2) ? t3 : t1, w2 = (rot & 2) ? t0 : t2,
-                     w3 = (rot & 2) ? t1 : t3;
-      if (r < rows_pad) {
-        uint16_t* col = tr + (size_t)(c8 * 8 + 4 * par) * LD + (r & ~1);
-        *reinterpret_cast<uint32_t*>(col + ((0 + rot) & 3) * LD) = w0;
-        *reinterpret_cast<uint32_t*>(col + ((1 + rot) & 3) * LD) = w1;
-        *reinterpret_cast<uint32_t*>(col + ((2 + rot) & 3) * LD) = w2;
-        *reinterpret_cast<uint32_t*>(col + ((3 + rot) & 3) * LD) = w3;
-      }
-    }
-  }
-}
-
-// writes a 16x64 f32 tile held in the MFMA C layout (o[dt][r] = X[row g*4+r][col dt*16+c]) as bf16 rows:
-// row i of the tile goes to dst(i) (64 contiguous bf16) if valid(i). Per-wave LDS scratch `ot`.
-template <typename DstFn, typename ValidFn>
-__device__ __forceinline__ void store_tile_rows(uint16_t* ot, const f32x4 (&o)[4], float mul, int lane, DstFn dst,
-                                                ValidFn valid) {
-  const int c = lane & 15, g = lane >> 4;
-#pragma unroll
-  for (int r = 0; r < 4; ++r)
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) ot[(g * 4 + r) * OS + dt * 16 + c] = f32_to_bf16(o[dt][r] * mul);
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int row = (lane >> 3) + 8 * k, ch = lane & 7;
-    const uint4 v = *reinterpret_cast<const uint4*>(ot + row * OS + ch * 8);
-    if (valid(row)) *reinterpret_cast<uint4*>(dst(row) + ch * 8) = v;
-  }
-}
+using namespace attn_mfma;
 
 // ------------------------------------------------------------------------------------------------------------
 // dQ kernel
@@ -121,24 +54,34 @@ __global__ __launch_bounds__(512) void space_bwd_dq_kernel(const uint16_t* __res
   const uint16_t* obase = out + (size_t)b * T * D + h * 64;
   const uint16_t* dobase = dout + (size_t)b * T * D + h * 64;
 
-  stage_rows<512>(Ks, Kt, LDK, L::KROWS, nkeys,
-                  [&](int r) { return base + (size_t)(TEXT ? r : (r == 0 ? 0 : tok0 + r - 1)) * ts + D; }, tid);
-  stage_rows<512>(Vs, nullptr, 0, L::KROWS, nkeys,
-                  [&](int r) { return base + (size_t)(TEXT ? r : (r == 0 ? 0 : tok0 + r - 1)) * ts + 2 * D; }, tid);
+  // fragments of this wave's first query tile: issued before the staging so that both are in flight together
+  const int c = lane & 15, g = lane >> 4;
+  auto tok_of = [&](int qt) { const int qr = qt * 16 + c; return tok0 + (qr < N ? qr : N - 1); };
+  uint4 nq0, nq1, ng0, ng1, ny0, ny1;
+  auto load_frags = [&](int qt) {
+    const int tk = tok_of(qt);
+    const uint16_t* qp = base + (size_t)tk * ts + g * 8;
+    nq0 = *reinterpret_cast<const uint4*>(qp); nq1 = *reinterpret_cast<const uint4*>(qp + 32);
+    ng0 = *reinterpret_cast<const uint4*>(dobase + (size_t)tk * D + g * 8);
+    ng1 = *reinterpret_cast<const uint4*>(dobase + (size_t)tk * D + g * 8 + 32);
+    ny0 = *reinterpret_cast<const uint4*>(obase + (size_t)tk * D + g * 8);
+    ny1 = *reinterpret_cast<const uint4*>(obase + (size_t)tk * D + g * 8 + 32);
+  };
+  load_frags(wave * 16 < N ? wave : 0);
+
+  stage_rows2<512, (L::KROWS + 63) / 64>(
+      Ks, Kt, [&](int r) { return base + (size_t)(TEXT ? r : (r == 0 ? 0 : tok0 + r - 1)) * ts + D; },
+      Vs, nullptr, [&](int r) { return base + (size_t)(TEXT ? r : (r == 0 ? 0 : tok0 + r - 1)) * ts + 2 * D; },
+      LDK, L::KROWS, nkeys, tid);
   __syncthreads();
 
-  const int c = lane & 15, g = lane >> 4;
   uint16_t* ot = Ot + wave * 16 * OS;
 #pragma unroll 1
   for (int qt = wave; qt * 16 < N; qt += 8) {
     const int qrow = qt * 16 + c;
-    const int tok = tok0 + (qrow < N ? qrow : N - 1);
-    const uint16_t* qp = base + (size_t)tok * ts + g * 8;
-    const uint4 q0 = *reinterpret_cast<const uint4*>(qp), q1 = *reinterpret_cast<const uint4*>(qp + 32);
-    const uint4 g0 = *reinterpret_cast<const uint4*>(dobase + (size_t)tok * D + g * 8);
-    const uint4 g1 = *reinterpret_cast<const uint4*>(dobase + (size_t)tok * D + g * 8 + 32);
-    const uint4 y0 = *reinterpret_cast<const uint4*>(obase + (size_t)tok * D + g * 8);
-    const uint4 y1 = *reinterpret_cast<const uint4*>(obase + (size_t)tok * D + g * 8 + 32);
+    const int tok = tok_of(qt);
+    const uint4 q0 = nq0, q1 = nq1, g0 = ng0, g1 = ng1, y0 = ny0, y1 = ny1;
+    if ((qt + 8) * 16 < N) load_frags(qt + 8);
     float dl;
     {
       float a[8], bb[8];
@@ -258,8 +201,8 @@ __global__ __launch_bounds__(512) void space_bwd_dkv_kernel(const uint16_t* __re
   const float* lrow = lse + ((size_t)b * H + h) * T;
   const float* drow = delta + ((size_t)b * H + h) * T;
 
-  stage_rows<512>(Qs, Qt, LDQ, QROWS, N, [&](int r) { return base + (size_t)(tok0 + r) * ts; }, tid);
-  stage_rows<512>(dOs, dOt, LDQ, QROWS, N, [&](int r) { return dobase + (size_t)(tok0 + r) * D; }, tid);
+  stage_rows2<512, 4>(Qs, Qt, [&](int r) { return base + (size_t)(tok0 + r) * ts; },
+                      dOs, dOt, [&](int r) { return dobase + (size_t)(tok0 + r) * D; }, LDQ, QROWS, N, tid);
   for (int q = tid; q < QROWS; q += 512) {
     lse_s[q] = q < N ? lrow[tok0 + q] : INFINITY;      // padded queries: exp(s - inf) = 0
     del_s[q] = q < N ? drow[tok0 + q] : 0.f;
@@ -450,7 +393,7 @@ void lvl_launch_cls_grad_finalize(const float* atom_ws, void* dqkv, int B, int T
 }
 
 bool lvl_space_mfma_bwd_supported(int F, int N) {
-  return N >= 1 && N + 1 <= 208 && dkv_geometry(N).total <= 160 * 1024 && F <= 64;
+  return N >= 1 && N + 1 <= 208 && dkv_geometry(N).QROWS <= 256 && dkv_geometry(N).total <= 160 * 1024 && F <= 64;
 }
 
 // ws layout: delta [B*H*T] f32, then atomics [B*H*192] f32 (d cls q | d cls k | d cls v)

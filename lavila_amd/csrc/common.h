@@ -34,11 +34,13 @@ static inline bool lvl_aligned16(const void* p) { return (reinterpret_cast<uintp
 struct bf16_t { uint16_t bits; };
 
 __device__ __forceinline__ float bf16_to_f32(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
-__device__ __forceinline__ uint16_t f32_to_bf16(float f) {   // round-to-nearest-even, NaN preserved
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {   // round-to-nearest-even: one v_cvt_pk_bf16_f32
+  return __builtin_bit_cast(uint16_t, (__bf16)f);
+}
+typedef __attribute__((ext_vector_type(2))) __bf16 lvl_bf16x2;
+__device__ __forceinline__ uint32_t f32x2_to_bf16x2(float lo, float hi) {
+  const lvl_bf16x2 v = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(uint32_t, v);
 }
 
 template <typename T> struct Elem;
@@ -70,10 +72,10 @@ template <> struct Elem<bf16_t> {
   }
   static __device__ __forceinline__ void store8(bf16_t* p, const float (&v)[8]) {
     uint4 a;
-    a.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-    a.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-    a.z = (uint32_t)f32_to_bf16(v[4]) | ((uint32_t)f32_to_bf16(v[5]) << 16);
-    a.w = (uint32_t)f32_to_bf16(v[6]) | ((uint32_t)f32_to_bf16(v[7]) << 16);
+    a.x = f32x2_to_bf16x2(v[0], v[1]);
+    a.y = f32x2_to_bf16x2(v[2], v[3]);
+    a.z = f32x2_to_bf16x2(v[4], v[5]);
+    a.w = f32x2_to_bf16x2(v[6], v[7]);
     *reinterpret_cast<uint4*>(p) = a;
   }
 };
