@@ -27,6 +27,28 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+
+
+def _enable_tuned_gemms():
+    """hipBLASLt/rocBLAS solution table for the Linear-layer GEMM shapes of this config, produced once on an
+    MI355X with PyTorch TunableOp (PYTORCH_TUNABLEOP_TUNING=1) and committed under lavila_amd/tuning/. Replay only
+    (no tuning inside the bench); unknown shapes fall back to the library default."""
+    src = os.path.join(ROOT, 'lavila_amd', 'tuning', 'tunableop_gfx950_tsfb_b256.csv')
+    if os.environ.get('LAVILA_NO_TUNED_GEMMS') or not os.path.isfile(src) or 'PYTORCH_TUNABLEOP_ENABLED' in os.environ:
+        return False
+    import shutil
+    import tempfile
+    dev = int(os.environ.get('LOCAL_RANK', '0'))
+    base = os.path.join(tempfile.gettempdir(), f'lavila_tunableop_{os.getpid()}_')
+    shutil.copy(src, f'{base}{dev}.csv')          # TunableOp appends the device ordinal to the file name
+    os.environ['PYTORCH_TUNABLEOP_ENABLED'] = '1'
+    os.environ['PYTORCH_TUNABLEOP_TUNING'] = '0'
+    os.environ['PYTORCH_TUNABLEOP_FILENAME'] = base + '.csv'
+    return True
+
+
+TUNED_GEMMS = _enable_tuned_gemms()
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -209,7 +231,8 @@ def main():
             'dtype': 'bf16' if amp is not None else 'f32', 'data': 'synthetic',
             'config': {'workload': f'{args.model}: TSF-B/16 {Fr}x{img}^2 clips + 32-token captions (77 ctx), '
                                    f'local batch {B}, global batch {world * B}, contrastive all-gather over RCCL',
-                       'global_batch': world * B, 'parallelism': f'dp{world}', 'final_loss': round(final_loss, 4)},
+                       'global_batch': world * B, 'parallelism': f'dp{world}', 'final_loss': round(final_loss, 4),
+                       'tuned_gemm_table': TUNED_GEMMS},
             'roofline': roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

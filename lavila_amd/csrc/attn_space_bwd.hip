@@ -101,22 +101,31 @@ __global__ __launch_bounds__(512) void space_bwd_dq_kernel(const uint16_t* __res
     const float Lq = lse[srow];
     if (g == 0 && qrow < N) delta[srow] = dl;
 
-    f32x4 ds[NKT];
+    // sweeps of independent MFMAs over the key tiles (see attn_space_mfma.hip): S^T = K.Q^T, dP^T = V.dO^T
+    constexpr float kExp2 = 0.125f * 1.4426950408889634f;
+    const float Lk = Lq * 1.4426950408889634f;
+    f32x4 ds[NKT], dp[NKT];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
-      const uint16_t* kp = Ks + (kt * 16 + c) * KS + g * 8;
-      const uint16_t* vp = Vs + (kt * 16 + c) * KS + g * 8;
-      f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-      s = mfma(*reinterpret_cast<const uint4*>(kp), q0, s);
-      s = mfma(*reinterpret_cast<const uint4*>(kp + 32), q1, s);
-      dp = mfma(*reinterpret_cast<const uint4*>(vp), g0, dp);
-      dp = mfma(*reinterpret_cast<const uint4*>(vp + 32), g1, dp);
+      ds[kt] = mfma(*reinterpret_cast<const uint4*>(Ks + (kt * 16 + c) * KS + g * 8), q0, f32x4{0.f, 0.f, 0.f, 0.f});
+      dp[kt] = mfma(*reinterpret_cast<const uint4*>(Vs + (kt * 16 + c) * KS + g * 8), g0, f32x4{0.f, 0.f, 0.f, 0.f});
+    }
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      ds[kt] = mfma(*reinterpret_cast<const uint4*>(Ks + (kt * 16 + c) * KS + g * 8 + 32), q1, ds[kt]);
+      dp[kt] = mfma(*reinterpret_cast<const uint4*>(Vs + (kt * 16 + c) * KS + g * 8 + 32), g1, dp[kt]);
+    }
+    // space groups: NKT = ceil(nkeys/16) exactly -> only the last tile holds padded keys; text: causal mask
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int key = kt * 16 + g * 4 + r;
-        const bool vis = key < nkeys && (!TEXT || key <= qrow);
-        const float p = vis ? __expf(s[r] * 0.125f - Lq) : 0.f;
-        ds[kt][r] = p * (dp[r] - dl);
+        float p = __builtin_amdgcn_exp2f(fmaf(ds[kt][r], kExp2, -Lk));
+        if (TEXT || kt == NKT - 1) {
+          const int key = kt * 16 + g * 4 + r;
+          p = (key < nkeys && (!TEXT || key <= qrow)) ? p : 0.f;
+        }
+        ds[kt][r] = p * (dp[kt][r] - dl);
       }
     }
     f32x4 o[4];
@@ -204,7 +213,7 @@ __global__ __launch_bounds__(512) void space_bwd_dkv_kernel(const uint16_t* __re
   stage_rows2<512, 4>(Qs, Qt, [&](int r) { return base + (size_t)(tok0 + r) * ts; },
                       dOs, dOt, [&](int r) { return dobase + (size_t)(tok0 + r) * D; }, LDQ, QROWS, N, tid);
   for (int q = tid; q < QROWS; q += 512) {
-    lse_s[q] = q < N ? lrow[tok0 + q] : INFINITY;      // padded queries: exp(s - inf) = 0
+    lse_s[q] = q < N ? lrow[tok0 + q] * 1.4426950408889634f : INFINITY;   // in log2 units; padded queries: exp2(-inf) = 0
     del_s[q] = q < N ? drow[tok0 + q] : 0.f;
   }
   if (!TEXT && tid < 64) {
@@ -257,7 +266,7 @@ __global__ __launch_bounds__(512) void space_bwd_dkv_kernel(const uint16_t* __re
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int q = qt * 16 + g * 4 + r;
-          p[r] = (!TEXT || q >= krow) ? __expf(s[r] * 0.125f - lse_s[q]) : 0.f;
+          p[r] = (!TEXT || q >= krow) ? __builtin_amdgcn_exp2f(fmaf(s[r], 0.125f * 1.4426950408889634f, -lse_s[q])) : 0.f;
           d[r] = p[r] * (dp[r] - del_s[q]);
         }
         if (t == 0) {
@@ -405,9 +414,13 @@ int lvl_space_mfma_bwd(const void* qkv, const void* out, const void* dout, const
   hipError_t e = hipMemsetAsync(atom_ws, 0, (size_t)B * H * 192 * sizeof(float), st);
   if (e != hipSuccess) return lvl_fail(LVL_EHIP, "space_bwd memset: %s", hipGetErrorString(e));
   int rc;
-  if (nkeys <= 64) rc = launch_dq<4>(qkv, out, dout, lse, dqkv, delta, B, F, N, H, st);
-  else if (nkeys <= 128) rc = launch_dq<8>(qkv, out, dout, lse, dqkv, delta, B, F, N, H, st);
-  else rc = launch_dq<13>(qkv, out, dout, lse, dqkv, delta, B, F, N, H, st);
+  switch ((nkeys + 15) / 16) {          // exact tile count: the kernel masks only the last key tile
+#define SPACE_DQ_CASE(K) case K: rc = launch_dq<K>(qkv, out, dout, lse, dqkv, delta, B, F, N, H, st); break;
+    SPACE_DQ_CASE(1) SPACE_DQ_CASE(2) SPACE_DQ_CASE(3) SPACE_DQ_CASE(4) SPACE_DQ_CASE(5) SPACE_DQ_CASE(6) SPACE_DQ_CASE(7)
+    SPACE_DQ_CASE(8) SPACE_DQ_CASE(9) SPACE_DQ_CASE(10) SPACE_DQ_CASE(11) SPACE_DQ_CASE(12) SPACE_DQ_CASE(13)
+#undef SPACE_DQ_CASE
+    default: return lvl_fail(LVL_ENOSYS, "space_mfma_bwd: %d keys per group not supported", nkeys);
+  }
   if (rc) return rc;
   const DkvGeom G = dkv_geometry(N);
   (void)hipFuncSetAttribute((const void*)space_bwd_dkv_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
