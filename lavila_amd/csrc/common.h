@@ -58,6 +58,13 @@ template <> struct Elem<float> {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
     *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
   }
+  static __device__ __forceinline__ void load4(const float* p, float (&v)[4]) {
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+  }
+  static __device__ __forceinline__ void store4(float* p, const float (&v)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  }
 };
 template <> struct Elem<bf16_t> {
   static __device__ __forceinline__ float load(const bf16_t* p) { return bf16_to_f32(p->bits); }
@@ -78,6 +85,25 @@ template <> struct Elem<bf16_t> {
     a.w = f32x2_to_bf16x2(v[6], v[7]);
     *reinterpret_cast<uint4*>(p) = a;
   }
+  static __device__ __forceinline__ void load4(const bf16_t* p, float (&v)[4]) {
+    const uint2 a = *reinterpret_cast<const uint2*>(p);
+    v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xffff0000u);
+    v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xffff0000u);
+  }
+  static __device__ __forceinline__ void store4(bf16_t* p, const float (&v)[4]) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(f32x2_to_bf16x2(v[0], v[1]), f32x2_to_bf16x2(v[2], v[3]));
+  }
+};
+
+// W consecutive elements (W = 4 or 8)
+template <typename T, int W> struct VecIO;
+template <typename T> struct VecIO<T, 8> {
+  static __device__ __forceinline__ void load(const T* p, float (&v)[8]) { Elem<T>::load8(p, v); }
+  static __device__ __forceinline__ void store(T* p, const float (&v)[8]) { Elem<T>::store8(p, v); }
+};
+template <typename T> struct VecIO<T, 4> {
+  static __device__ __forceinline__ void load(const T* p, float (&v)[4]) { Elem<T>::load4(p, v); }
+  static __device__ __forceinline__ void store(T* p, const float (&v)[4]) { Elem<T>::store4(p, v); }
 };
 
 __device__ __forceinline__ void load8_f32(const float* p, float (&v)[8]) { Elem<float>::load8(p, v); }

@@ -1,9 +1,10 @@
 // LayerNorm forward/backward, optionally fused with the residual(+bias) add that feeds it. gfx950.
 //
 // HBM-bound: one pass over [rows, cols]. One 64-lane wave owns one row at a time and keeps the
-// whole row in registers (cols <= 4096 -> <= 8 x 16-byte vectors per lane), so every operand is
-// read exactly once; statistics are the two-pass (mean, then centred variance) form in f32, matching
-// F.layer_norm. Loads/stores are 16 B per lane, consecutive lanes on consecutive vectors.
+// whole row in registers, so every operand is read exactly once; statistics are the two-pass (mean, then
+// centred variance) form in f32, matching F.layer_norm. Consecutive lanes take consecutive W-element vectors.
+// Two vector widths: W = 4 when cols is a multiple of 256 (768 -> exactly 3 vectors per lane, no idle lanes,
+// 25 % fewer registers than 2 x 8 -> one more wave per SIMD in the backward), W = 8 otherwise.
 // Algorithmic bytes per row (E = element size): fwd cols*E*(n_in + n_out), bwd cols*E*(1 + n_in + 1).
 #include "common.h"
 
@@ -12,50 +13,54 @@ namespace {
 constexpr int kRowsPerBlock = 4;          // 4 waves per 256-thread workgroup
 constexpr int kLnBwdParts = 1024;         // partial dgamma/dbeta/dxsum slabs (one per workgroup)
 
-// s = x (+ x2) (+ bias), rounded to T when it is materialised
-template <typename T>
-__device__ __forceinline__ void load_sum8(const T* __restrict__ x, const T* __restrict__ x2,
-                                          const float* __restrict__ bias, int64_t off, int c8, float (&v)[8]) {
-  Elem<T>::load8(x + off, v);
+template <int W>
+__device__ __forceinline__ void load_f32(const float* p, float (&v)[W]) { VecIO<float, W>::load(p, v); }
+
+// s = x (+ x2) (+ bias)
+template <typename T, int W>
+__device__ __forceinline__ void load_sum(const T* __restrict__ x, const T* __restrict__ x2,
+                                         const float* __restrict__ bias, int64_t off, int c0, float (&v)[W]) {
+  VecIO<T, W>::load(x + off, v);
   if (x2 != nullptr) {
-    float w[8];
-    Elem<T>::load8(x2 + off, w);
+    float w[W];
+    VecIO<T, W>::load(x2 + off, w);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] += w[j];
+    for (int j = 0; j < W; ++j) v[j] += w[j];
   }
   if (bias != nullptr) {
-    float bb[8];
-    load8_f32(bias + c8, bb);
+    float bb[W];
+    load_f32<W>(bias + c0, bb);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] += bb[j];
+    for (int j = 0; j < W; ++j) v[j] += bb[j];
   }
 }
 
-template <typename T, int VPL>
+template <typename T, int VPL, int W>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(
     const T* __restrict__ x, const T* __restrict__ x2, const float* __restrict__ bias,
     const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ s_out,
     T* __restrict__ out, float* __restrict__ mean, float* __restrict__ rstd, int64_t rows, int cols,
     float eps) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nvec = cols >> 3;
+  const int nvec = cols / W;
   const float inv_cols = 1.0f / (float)cols;
   for (int64_t row = (int64_t)blockIdx.x * kRowsPerBlock + wave; row < rows;
        row += (int64_t)gridDim.x * kRowsPerBlock) {
-    float v[VPL][8];
+    float v[VPL][W];
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
       const int c = lane + i * 64;
       if (c < nvec) {
-        load_sum8<T>(x, x2, bias, row * cols + c * 8, c * 8, v[i]);
+        load_sum<T, W>(x, x2, bias, row * cols + c * W, c * W, v[i]);
         if (s_out != nullptr) {
-          Elem<T>::store8(s_out + row * cols + c * 8, v[i]);
+          // the sum is what downstream residuals read: round it once, then normalise the rounded value
+          VecIO<T, W>::store(s_out + row * cols + c * W, v[i]);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[i][j] = Elem<T>::round(v[i][j]);
+          for (int j = 0; j < W; ++j) v[i][j] = Elem<T>::round(v[i][j]);
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) sum += v[i][j];
+        for (int j = 0; j < W; ++j) sum += v[i][j];
       }
     }
     const float mu = wave_sum(sum) * inv_cols;
@@ -64,7 +69,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(
     for (int i = 0; i < VPL; ++i) {
       if (lane + i * 64 < nvec) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mu; sq += d * d; }
+        for (int j = 0; j < W; ++j) { const float d = v[i][j] - mu; sq += d * d; }
       }
     }
     const float rs = rsqrtf(wave_sum(sq) * inv_cols + eps);
@@ -72,12 +77,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(
     for (int i = 0; i < VPL; ++i) {
       const int c = lane + i * 64;
       if (c < nvec) {
-        float g[8], b[8], o[8];
-        load8_f32(gamma + c * 8, g);
-        load8_f32(beta + c * 8, b);
+        float g[W], b[W], o[W];
+        load_f32<W>(gamma + c * W, g);
+        load_f32<W>(beta + c * W, b);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mu) * rs * g[j] + b[j];
-        Elem<T>::store8(out + row * cols + c * 8, o);
+        for (int j = 0; j < W; ++j) o[j] = (v[i][j] - mu) * rs * g[j] + b[j];
+        VecIO<T, W>::store(out + row * cols + c * W, o);
       }
     }
     if (lane == 0) {
@@ -89,38 +94,38 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(
 
 // dx = rstd * (dy*g - mean(dy*g) - shat * mean(dy*g*shat)) (+ dadd);
 // per-workgroup partial slabs [3][cols] = {sum dy*shat, sum dy, sum dx}
-template <typename T, int VPL>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(
+template <typename T, int VPL, int W>
+__global__ __launch_bounds__(256, (VPL * W <= 12 ? 4 : 1)) void ln_bwd_kernel(
     const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ x2,
     const float* __restrict__ bias, const float* __restrict__ gamma, const float* __restrict__ mean,
     const float* __restrict__ rstd, const T* __restrict__ dadd, T* __restrict__ dx,
     float* __restrict__ part, int64_t rows, int cols) {
   extern __shared__ __attribute__((aligned(16))) float smem[];   // [3 waves][3][cols]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nvec = cols >> 3;
+  const int nvec = cols / W;
   const float inv_cols = 1.0f / (float)cols;
-  float g[VPL][8], ag[VPL][8], ab[VPL][8], ax[VPL][8];
+  float g[VPL][W], ag[VPL][W], ab[VPL][W], ax[VPL][W];
 #pragma unroll
   for (int i = 0; i < VPL; ++i) {
     const int c = lane + i * 64;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { ag[i][j] = 0.f; ab[i][j] = 0.f; ax[i][j] = 0.f; g[i][j] = 0.f; }
-    if (c < nvec) load8_f32(gamma + c * 8, g[i]);
+    for (int j = 0; j < W; ++j) { ag[i][j] = 0.f; ab[i][j] = 0.f; ax[i][j] = 0.f; g[i][j] = 0.f; }
+    if (c < nvec) load_f32<W>(gamma + c * W, g[i]);
   }
   for (int64_t row = (int64_t)blockIdx.x * kRowsPerBlock + wave; row < rows;
        row += (int64_t)gridDim.x * kRowsPerBlock) {
     const float mu = mean[row], rs = rstd[row];
-    float xh[VPL][8], dg[VPL][8];
+    float xh[VPL][W], dg[VPL][W];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
       const int c = lane + i * 64;
       if (c < nvec) {
-        float xv[8], dv[8];
-        load_sum8<T>(x, x2, bias, row * cols + c * 8, c * 8, xv);
-        Elem<T>::load8(dy + row * cols + c * 8, dv);
+        float xv[W], dv[W];
+        load_sum<T, W>(x, x2, bias, row * cols + c * W, c * W, xv);
+        VecIO<T, W>::load(dy + row * cols + c * W, dv);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < W; ++j) {
           xh[i][j] = (xv[j] - mu) * rs;
           dg[i][j] = dv[j] * g[i][j];
           s1 += dg[i][j];
@@ -135,18 +140,18 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
     for (int i = 0; i < VPL; ++i) {
       const int c = lane + i * 64;
       if (c < nvec) {
-        float o[8];
+        float o[W];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = rs * (dg[i][j] - c1 - xh[i][j] * c2);
+        for (int j = 0; j < W; ++j) o[j] = rs * (dg[i][j] - c1 - xh[i][j] * c2);
         if (dadd != nullptr) {
-          float e[8];
-          Elem<T>::load8(dadd + row * cols + c * 8, e);
+          float e[W];
+          VecIO<T, W>::load(dadd + row * cols + c * W, e);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) o[j] += e[j];
+          for (int j = 0; j < W; ++j) o[j] += e[j];
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ax[i][j] += Elem<T>::round(o[j]);
-        Elem<T>::store8(dx + row * cols + c * 8, o);
+        for (int j = 0; j < W; ++j) ax[i][j] += Elem<T>::round(o[j]);
+        VecIO<T, W>::store(dx + row * cols + c * W, o);
       }
     }
   }
@@ -158,10 +163,10 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
       const int c = lane + i * 64;
       if (c < nvec) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          dst[c * 8 + j] = ag[i][j];
-          dst[cols + c * 8 + j] = ab[i][j];
-          dst[2 * cols + c * 8 + j] = ax[i][j];
+        for (int j = 0; j < W; ++j) {
+          dst[c * W + j] = ag[i][j];
+          dst[cols + c * W + j] = ab[i][j];
+          dst[2 * cols + c * W + j] = ax[i][j];
         }
       }
     }
@@ -174,16 +179,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(
       const int c = lane + i * 64;
       if (c < nvec) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < W; ++j) {
           float a = ag[i][j], b = ab[i][j], e = ax[i][j];
           for (int w = 0; w < 3; ++w) {
-            a += smem[(size_t)w * 3 * cols + c * 8 + j];
-            b += smem[(size_t)w * 3 * cols + cols + c * 8 + j];
-            e += smem[(size_t)w * 3 * cols + 2 * cols + c * 8 + j];
+            a += smem[(size_t)w * 3 * cols + c * W + j];
+            b += smem[(size_t)w * 3 * cols + cols + c * W + j];
+            e += smem[(size_t)w * 3 * cols + 2 * cols + c * W + j];
           }
-          pg[c * 8 + j] = a;
-          pg[cols + c * 8 + j] = b;
-          pg[2 * cols + c * 8 + j] = e;
+          pg[c * W + j] = a;
+          pg[cols + c * W + j] = b;
+          pg[2 * cols + c * W + j] = e;
         }
       }
     }
@@ -220,6 +225,21 @@ __global__ __launch_bounds__(256) void column_reduce_kernel(const float* __restr
   }
 }
 
+// (VPL, W) for a row length: W = 4 with exactly cols/256 vectors per lane when possible
+#define LN_DISPATCH(cols, CALL)                          \
+  do {                                                   \
+    if ((cols) % 256 == 0 && (cols) <= 1024) {           \
+      switch ((cols) / 256) {                            \
+        case 1: CALL(1, 4); break;                       \
+        case 2: CALL(2, 4); break;                       \
+        case 3: CALL(3, 4); break;                       \
+        default: CALL(4, 4); break;                      \
+      }                                                  \
+    } else if ((cols) / 8 <= 128) CALL(2, 8);            \
+    else if ((cols) / 8 <= 256) CALL(4, 8);              \
+    else CALL(8, 8);                                     \
+  } while (0)
+
 }  // namespace
 
 int lvl_ln_bwd_parts() { return kLnBwdParts; }
@@ -245,17 +265,13 @@ extern "C" int lvl_layernorm_fwd(const void* x, const void* x2, const float* xbi
   if (rows == 0) return LVL_OK;
   int64_t blocks = (rows + kRowsPerBlock - 1) / kRowsPerBlock;
   if (blocks > 8192) blocks = 8192;
-  const int nvec = cols / 8;
-#define LN_FWD(TT, VPL)                                                                                  \
-  hipLaunchKernelGGL((ln_fwd_kernel<TT, VPL>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, \
-                     (const TT*)x, (const TT*)x2, xbias, gamma, beta, (TT*)s_out, (TT*)y, mean, rstd, rows, \
-                     cols, eps)
-  LVL_DISPATCH_DTYPE(dtype, {
-    if (nvec <= 128) LN_FWD(T, 2);
-    else if (nvec <= 256) LN_FWD(T, 4);
-    else LN_FWD(T, 8);
-  });
+#define LN_FWD_T(TT, VPL, W)                                                                                  \
+  hipLaunchKernelGGL((ln_fwd_kernel<TT, VPL, W>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,   \
+                     (const TT*)x, (const TT*)x2, xbias, gamma, beta, (TT*)s_out, (TT*)y, mean, rstd, rows, cols, eps)
+#define LN_FWD(VPL, W) LN_FWD_T(T, VPL, W)
+  LVL_DISPATCH_DTYPE(dtype, LN_DISPATCH(cols, LN_FWD));
 #undef LN_FWD
+#undef LN_FWD_T
   LVL_CHECK_LAUNCH("layernorm_fwd");
   return LVL_OK;
 }
@@ -274,23 +290,20 @@ extern "C" int lvl_layernorm_bwd(const void* dy, const void* x, const void* x2, 
   int64_t blocks = (rows + kRowsPerBlock - 1) / kRowsPerBlock;
   if (blocks > kLnBwdParts) blocks = kLnBwdParts;
   if (blocks < 1) blocks = 1;
-  const int nvec = cols / 8;
   const size_t shmem = (size_t)3 * 3 * cols * sizeof(float);
-#define LN_BWD(TT, VPL)                                                                                     \
-  do {                                                                                                      \
-    if (shmem > 64 * 1024)                                                                                  \
-      (void)hipFuncSetAttribute((const void*)ln_bwd_kernel<TT, VPL>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                (int)shmem);                                                                \
-    hipLaunchKernelGGL((ln_bwd_kernel<TT, VPL>), dim3((unsigned)blocks), dim3(256), shmem, st, (const TT*)dy, \
+#define LN_BWD_T(TT, VPL, W)                                                                                    \
+  do {                                                                                                          \
+    if (shmem > 64 * 1024)                                                                                      \
+      (void)hipFuncSetAttribute((const void*)ln_bwd_kernel<TT, VPL, W>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)shmem);                                                                    \
+    hipLaunchKernelGGL((ln_bwd_kernel<TT, VPL, W>), dim3((unsigned)blocks), dim3(256), shmem, st, (const TT*)dy, \
                        (const TT*)x, (const TT*)x2, xbias, gamma, mean, rstd, (const TT*)dadd, (TT*)dx, ws, rows, \
-                       cols);                                                                               \
+                       cols);                                                                                   \
   } while (0)
-  LVL_DISPATCH_DTYPE(dtype, {
-    if (nvec <= 128) LN_BWD(T, 2);
-    else if (nvec <= 256) LN_BWD(T, 4);
-    else LN_BWD(T, 8);
-  });
+#define LN_BWD(VPL, W) LN_BWD_T(T, VPL, W)
+  LVL_DISPATCH_DTYPE(dtype, LN_DISPATCH(cols, LN_BWD));
 #undef LN_BWD
+#undef LN_BWD_T
   LVL_CHECK_LAUNCH("layernorm_bwd");
   return lvl_launch_column_reduce(ws, (int)blocks, 3 * cols, cols, dgamma, dbeta, dxsum, st);
 }

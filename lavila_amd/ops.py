@@ -27,6 +27,56 @@ def _rows_cols(x: torch.Tensor):
 
 
 # --------------------------------------------------------------------------------------------------
+# Linear layers: library GEMMs (hipBLASLt through torch), with an MI355X-shaped weight-gradient
+# --------------------------------------------------------------------------------------------------
+class _LinearFn(torch.autograd.Function):
+    """y = x W^T (+ b) for token-major activations [rows, in] with rows ~ 2e5.
+
+    Forward and input-gradient are plain library GEMMs. The weight gradient dW[out,in] = dY^T X contracts over
+    the ~2e5 rows and writes a tiny output (9..36 tiles of 256x256): the library's stream-K kernels reach only
+    0.3-0.9 PF/s there. Splitting the rows into S batches (one bmm, S x more output tiles, all 256 CUs busy)
+    and summing the S partial products in f32 measured 1.3-2.3x faster on MI355X (tools/probe_wgrad.py) with the
+    same rounding error as the single GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        w = weight if weight.dtype == x.dtype else weight.to(x.dtype)
+        b = None if bias is None else (bias if bias.dtype == x.dtype else bias.to(x.dtype))
+        ctx.save_for_backward(x, w)
+        ctx.meta = (weight.dtype, None if bias is None else bias.dtype)
+        with torch.autocast('cuda', enabled=False):
+            return torch.nn.functional.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        wdt, bdt = ctx.meta
+        with torch.autocast('cuda', enabled=False):
+            dy2 = dy.reshape(-1, dy.shape[-1])
+            x2 = x.reshape(-1, x.shape[-1])
+            dx = (dy2 @ w).reshape(x.shape) if ctx.needs_input_grad[0] else None
+            dw = None
+            if ctx.needs_input_grad[1]:
+                rows, n_out, n_in = dy2.shape[0], dy2.shape[1], x2.shape[1]
+                split = 32 if n_out >= 3 * n_in else 16
+                if rows >= 32768 and rows % split == 0 and dy2.is_contiguous() and x2.is_contiguous():
+                    part = torch.bmm(dy2.view(split, rows // split, n_out).transpose(1, 2),
+                                     x2.view(split, rows // split, n_in))
+                    dw = part.float().sum(0).to(wdt)
+                else:
+                    dw = (dy2.t() @ x2).to(wdt)
+            db = dy2.sum(0).to(bdt) if (bdt is not None and ctx.needs_input_grad[2]) else None
+        return dx, dw, db
+
+
+def linear(x, weight, bias=None):
+    """F.linear with the split-row weight gradient. Activation dtype = x.dtype (weights are cast to it)."""
+    if torch.is_autocast_enabled() and x.dtype == torch.float32:
+        x = x.to(torch.get_autocast_dtype('cuda'))
+    return _LinearFn.apply(x, weight, bias)
+
+
+# --------------------------------------------------------------------------------------------------
 # LayerNorm (optionally fused with residual + bias add)
 # --------------------------------------------------------------------------------------------------
 def layernorm_fwd_raw(x, x2, xbias, gamma, beta, eps, keep_sum):

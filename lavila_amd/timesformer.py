@@ -87,7 +87,7 @@ class Mlp(nn.Module):
 
     def hidden(self, x):
         if self._fused_act:
-            return self.drop(ops.bias_quick_gelu(F.linear(x, self.fc1.weight), self.fc1.bias))
+            return self.drop(ops.bias_quick_gelu(ops.linear(x, self.fc1.weight), self.fc1.bias))
         return self.drop(self.act(self.fc1(x)))
 
     def forward(self, x):
@@ -117,7 +117,7 @@ class VideoPatchEmbed(nn.Module):
             raise NotImplementedError('non-square patches')
         w = self.proj.weight
         patches = ops.patchify(video, self.patch_size[0], _compute_dtype(w))
-        return F.linear(patches, w.reshape(w.shape[0], -1), self.proj.bias)
+        return ops.linear(patches, w.reshape(w.shape[0], -1), self.proj.bias)
 
     def forward(self, x):
         """Reference signature: x [B,F,C,H,W] -> [B*F, D, H/P, W/P] (timesformer.py:79-84)."""
@@ -165,7 +165,8 @@ class VarAttention(nn.Module):
 
     def core(self, x, mode, frames, n_per_frame):
         """qkv Linear + attention core; returns the pre-projection tensor [B,T,D]."""
-        return ops.divided_attention(self.qkv(x), frames, n_per_frame, self.num_heads, mode)
+        return ops.divided_attention(ops.linear(x, self.qkv.weight, self.qkv.bias), frames, n_per_frame,
+                                     self.num_heads, mode)
 
     def forward(self, x, einops_from, einops_to, einops_dims):
         mode, k = self._mode(einops_to, einops_dims)
@@ -219,18 +220,18 @@ class SpaceTimeBlock(nn.Module):
         if hasattr(self, 'alpha_timeattn'):
             y_t, b_t = torch.tanh(self.alpha_timeattn).to(o_t.dtype) * ta.proj(o_t), None
         else:
-            y_t, b_t = F.linear(o_t, ta.proj.weight), ta.proj.bias
+            y_t, b_t = ops.linear(o_t, ta.proj.weight), ta.proj.bias
         _, h1 = ops.add_layer_norm(x, y_t, b_t, n1.weight, n1.bias, n1.eps, keep_sum=False)   # t never stored
         o_s = sa.core(h1, 'space', frames, n_per_frame)
         if self._dropping():
             y_s, b_s = self.drop_path(sa.proj(o_s)), None
         else:
-            y_s, b_s = F.linear(o_s, sa.proj.weight), sa.proj.bias
+            y_s, b_s = ops.linear(o_s, sa.proj.weight), sa.proj.bias
         x1, h2 = ops.add_layer_norm(x, y_s, b_s, n2.weight, n2.bias, n2.eps, keep_sum=True)
         a = self.mlp.hidden(h2)
         if self._dropping():
             return x1, self.drop_path(self.mlp.drop(self.mlp.fc2(a))), None
-        return x1, F.linear(a, self.mlp.fc2.weight), self.mlp.fc2.bias
+        return x1, ops.linear(a, self.mlp.fc2.weight), self.mlp.fc2.bias
 
     def forward(self, x, einops_from_space, einops_to_space, einops_from_time, einops_to_time,
                 time_n, space_f, use_checkpoint=False):
