@@ -217,11 +217,15 @@ def main():
         alg_bytes = B * (T * 3 * D + T * D) * esize            # read packed qkv once, write out once
         kms = timer.mean_ms()
         roofline = None
+        traffic = None
+        tfile = os.path.join(ROOT, 'profiles', 'r01_traffic_space_fwd.json')   # PMC pass of the same kernel/shape
+        if os.path.isfile(tfile) and (B, Fr, N, D) == (256, 4, 196, 768) and amp is not None:
+            traffic = json.load(open(tfile))['traffic_bytes_per_launch']
         if kms:
             achieved = alg_bytes / (kms * 1e-3) / 1e9
             roofline = {'bound': 'hbm', 'kernel': 'lvl_divided_attn_fwd[space]', 'achieved': round(achieved, 1),
                         'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
-                        'traffic': None, 'avg_ms': round(kms, 4), 'launches': len(timer.pairs),
+                        'traffic': traffic, 'avg_ms': round(kms, 4), 'launches': len(timer.pairs),
                         'alg_bytes_per_launch': alg_bytes}
         line = {
             'metric': 'clip-text pairs/s (whole node), TSF-B/16 4x224^2 + CLIP text tower, fwd+loss+bwd+AdamW',

@@ -1,4 +1,5 @@
-// Contrastive (InfoNCE) head in slab form, gfx950 -- first (VALU, f32-accumulate) implementation.
+// Contrastive (InfoNCE) head in slab form, gfx950: shape-generic VALU kernels (any E % 8 == 0) and the backward.
+// The forward for E in {64,128,256,512} runs on the matrix cores (clip_loss_mfma.hip).
 //
 // Each rank owns B rows of both logit matrices: direction 0 = logits_per_image rows
 // (scale*img_local) @ txt_all^T, direction 1 = logits_per_text rows (scale*txt_local) @ img_all^T.
@@ -121,6 +122,10 @@ __global__ __launch_bounds__(256) void clip_bwd_kernel(const T* __restrict__ img
 
 }  // namespace
 
+bool lvl_clip_mfma_supported(int E);
+int lvl_clip_fwd_mfma(const void* img_all, const void* txt_all, const float* scale, int B, int G, int E, int row0,
+                      float* stats, int32_t* argmax, float* logits, int dtype, hipStream_t st);
+
 extern "C" int lvl_clip_loss_fwd(const void* img_all, const void* txt_all, const float* scale, int B, int G, int E, int row0,
                                  float* stats, int32_t* argmax, float* logits, int dtype, void* stream) {
   LVL_REQUIRE(img_all && txt_all && scale && stats && argmax, "clip_loss_fwd: null pointer");
@@ -128,6 +133,8 @@ extern "C" int lvl_clip_loss_fwd(const void* img_all, const void* txt_all, const
               "clip_loss_fwd: bad shape B=%d G=%d E=%d row0=%d", B, G, E, row0);
   LVL_REQUIRE(lvl_aligned16(img_all) && lvl_aligned16(txt_all), "clip_loss_fwd: pointers must be 16-byte aligned");
   if (B == 0) return LVL_OK;
+  if (lvl_clip_mfma_supported(E) && (dtype == LVL_F32 || dtype == LVL_BF16))
+    return lvl_clip_fwd_mfma(img_all, txt_all, scale, B, G, E, row0, stats, argmax, logits, dtype, (hipStream_t)stream);
   const size_t shmem = (size_t)(E + 32) * sizeof(float);
   LVL_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((clip_fwd_kernel<T>), dim3(B, 2), dim3(256), shmem, (hipStream_t)stream,
                                                (const T*)img_all, (const T*)txt_all, scale, B, G, E, row0, stats,
