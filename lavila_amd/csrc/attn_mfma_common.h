@@ -1,13 +1,24 @@
 // Shared pieces of the MFMA attention kernels (forward + backward), gfx950.
+//
+// LDS images are ROW-MAJOR with 128-byte rows (64 bf16 = one head row) and a 16-byte-slot XOR swizzle
+//     phys_slot = slot ^ (row & 7)
+// One image serves both operand kinds of a 16x16x32 MFMA:
+//   * contraction over d (QK^T, dO V^T): fragment = 8 consecutive channels of one row -> one ds_read_b128
+//     (conflict-free: the 16 rows of a lane group land on 16 different slots);
+//   * contraction over rows (P V, dS K, dS^T Q, P^T dO): fragment = 4 consecutive ROWS at one channel -> one
+//     ds_read_b64_tr_b16 (the gfx950 LDS transpose read: within a 16-lane group, lane m points at row
+//     r0 + m/4, channels d0 + 4*(m%4) .. +3, and lane c receives rows r0..r0+3 at channel d0 + c; verified on
+//     hardware by tools/probes/tr_read_probe.hip). No transposed copies are ever staged.
 #pragma once
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 namespace attn_mfma {
 
-constexpr int KS = 80;   // row-major LDS row stride (elements, 160 B): conflict-free ds_read_b128 fragments
+constexpr int RS = 64;   // image row stride in elements (128 B)
 constexpr int OS = 72;   // per-wave output transposition tile stride (elements)
 
 __device__ __forceinline__ bf16x8 as_bf16x8(uint4 v) { return __builtin_bit_cast(bf16x8, v); }
@@ -16,42 +27,57 @@ __device__ __forceinline__ f32x4 mfma(uint4 a, uint4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a), as_bf16x8(b), c, 0, 0, 0);
 }
 
-// LDS write half of the staging: row r (8 lanes x 16 B, this lane holds chunk c8 = v) into the row-major image
-// rm[r*KS + d] and/or the transposed image tr[d*LD + r]. The transposed image is written as packed row pairs
-// (lane pairs exchange halves with one xor-8 shuffle) with a per-lane rotation of the write order so that the
-// 8 chunk-lanes of a row hit different banks at every step (2-way conflicts at most).
-__device__ __forceinline__ void stage_write(uint16_t* rm, uint16_t* tr, int LD, int rows_pad, int r, int c8, uint4 v) {
-  const int par = r & 1, rot = c8 & 3;
-  if (rm != nullptr && r < rows_pad) *reinterpret_cast<uint4*>(rm + r * KS + c8 * 8) = v;
-  if (tr != nullptr) {
-    const uint32_t s0 = par ? v.x : v.z, s1 = par ? v.y : v.w;
-    const uint32_t p0 = __shfl_xor(s0, 8, 64), p1 = __shfl_xor(s1, 8, 64);
-    const uint32_t o0 = par ? v.z : v.x, o1 = par ? v.w : v.y;
-    const uint32_t lo0 = par ? p0 : o0, lo1 = par ? p1 : o1;          // even row's two dwords
-    const uint32_t hi0 = par ? o0 : p0, hi1 = par ? o1 : p1;          // odd row's two dwords
-    const uint32_t pk0 = (lo0 & 0xffffu) | (hi0 << 16), pk1 = (lo0 >> 16) | (hi0 & 0xffff0000u);
-    const uint32_t pk2 = (lo1 & 0xffffu) | (hi1 << 16), pk3 = (lo1 >> 16) | (hi1 & 0xffff0000u);
-    const uint32_t t0 = (rot & 1) ? pk1 : pk0, t1 = (rot & 1) ? pk2 : pk1, t2 = (rot & 1) ? pk3 : pk2,
-                   t3 = (rot & 1) ? pk0 : pk3;
-    const uint32_t w0 = (rot & 2) ? t2 : t0, w1 = (rot & 2) ? t3 : t1, w2 = (rot & 2) ? t0 : t2,
-                   w3 = (rot & 2) ? t1 : t3;
-    if (r < rows_pad) {
-      uint16_t* col = tr + (size_t)(c8 * 8 + 4 * par) * LD + (r & ~1);
-      *reinterpret_cast<uint32_t*>(col + ((0 + rot) & 3) * LD) = w0;
-      *reinterpret_cast<uint32_t*>(col + ((1 + rot) & 3) * LD) = w1;
-      *reinterpret_cast<uint32_t*>(col + ((2 + rot) & 3) * LD) = w2;
-      *reinterpret_cast<uint32_t*>(col + ((3 + rot) & 3) * LD) = w3;
-    }
-  }
+// element offset of 16-byte slot `slot` (8 channels) of row `row`
+__device__ __forceinline__ int img_off(int row, int slot) { return row * RS + ((slot ^ (row & 7)) << 3); }
+
+// 8 consecutive channels [slot*8, slot*8+8) of one row
+__device__ __forceinline__ uint4 img_frag(const uint16_t* img, int row, int slot) {
+  return *reinterpret_cast<const uint4*>(img + img_off(row, slot));
 }
 
-// Cooperative staging of two row sets A and B (`nrows` rows of 64 bf16 each; row r at srcA(r) / srcB(r)); rows in
-// [nrows, rows_pad) are zero-filled. NT threads, 8 lanes per row, MAXP >= ceil(rows_pad / (NT/8)) passes.
-// ALL global loads are issued before the first LDS write so that the passes overlap in flight instead of
-// paying one HBM latency each.
+// rows r0..r0+3 at channel d0 + (lane & 15); r0 must be the same for the 16 lanes of a group (it may differ
+// between groups), d0 a multiple of 16
+__device__ __forceinline__ uint2 img_frag_tr(const uint16_t* img, int r0, int d0, int lane) {
+  const int m = lane & 15, row = r0 + (m >> 2), col = d0 + ((m & 3) << 2);
+  const uint16_t* p = img + row * RS + ((((col >> 3) ^ (row & 7)) << 3) | (col & 7));
+  const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+  return __builtin_bit_cast(uint2, v);
+}
+
+// Per-lane fragment offsets inside one 16-row tile (tiles start at multiples of 16 rows, so the swizzle term is
+// tile-invariant): computed once, every access is then `image + tile*16*RS + offset` (an immediate for unrolled
+// tile loops).
+struct FragOff {
+  int a[2];     // ds_read_b128 fragment of row (lane & 15): channels ks*32 + (lane>>4)*8 .. +7, ks = 0, 1
+  int tr[4];    // transpose-read fragment: rows (lane>>4)*4 .. +3 at channel dt*16 + (lane & 15), dt = 0..3
+};
+__device__ __forceinline__ FragOff frag_offsets(int lane) {
+  FragOff f;
+  const int c = lane & 15, g = lane >> 4, m = c;
+  f.a[0] = c * RS + ((g ^ (c & 7)) << 3);
+  f.a[1] = c * RS + (((4 + g) ^ (c & 7)) << 3);
+  const int rsub = g * 4 + (m >> 2);
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+    f.tr[dt] = rsub * RS + ((((2 * dt + ((m & 3) >> 1)) ^ (rsub & 7)) << 3) | ((m & 1) << 2));
+  return f;
+}
+__device__ __forceinline__ uint4 tile_frag(const uint16_t* img, int tile, int off) {
+  return *reinterpret_cast<const uint4*>(img + tile * 16 * RS + off);
+}
+__device__ __forceinline__ uint2 tile_frag_tr(const uint16_t* img, int tile, int off) {
+  const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4*)(img + tile * 16 * RS + off));
+  return __builtin_bit_cast(uint2, v);
+}
+
+// Cooperative staging of two row sets A and B (`nrows` rows of 64 bf16 each; row r at srcA(r) / srcB(r)) into
+// swizzled row-major images; rows in [nrows, rows_pad) are zero-filled. NT threads, 8 lanes per row,
+// MAXP >= ceil(rows_pad / (NT/8)) passes. ALL global loads are issued before the first LDS write so that the
+// passes overlap in flight instead of paying one HBM latency each.
 template <int NT, int MAXP, typename SrcA, typename SrcB>
-__device__ __forceinline__ void stage_rows2(uint16_t* rmA, uint16_t* trA, SrcA srcA, uint16_t* rmB, uint16_t* trB,
-                                            SrcB srcB, int LD, int rows_pad, int nrows, int tid) {
+__device__ __forceinline__ void stage_rows2(uint16_t* imgA, SrcA srcA, uint16_t* imgB, SrcB srcB, int rows_pad,
+                                            int nrows, int tid) {
   constexpr int RPP = NT / 8;
   const int c8 = tid & 7, r_in = tid >> 3;
   uint4 va[MAXP], vb[MAXP];
@@ -67,10 +93,10 @@ __device__ __forceinline__ void stage_rows2(uint16_t* rmA, uint16_t* trA, SrcA s
   }
 #pragma unroll
   for (int p = 0; p < MAXP; ++p) {
-    if (p * RPP < rows_pad) {           // wave-uniform
-      const int r = p * RPP + r_in;
-      stage_write(rmA, trA, LD, rows_pad, r, c8, va[p]);
-      stage_write(rmB, trB, LD, rows_pad, r, c8, vb[p]);
+    const int r = p * RPP + r_in;
+    if (r < rows_pad) {
+      *reinterpret_cast<uint4*>(imgA + img_off(r, c8)) = va[p];
+      *reinterpret_cast<uint4*>(imgB + img_off(r, c8)) = vb[p];
     }
   }
 }

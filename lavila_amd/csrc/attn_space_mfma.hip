@@ -3,10 +3,10 @@
 // One 512-thread workgroup (8 waves) per (sample b, frame f, head h): N patch queries x (1 cls + N patch)
 // keys, head dim 64 (timesformer.py:116-131 with the '(b f) n d' grouping :300-301). All keys of the group
 // are LDS-resident, so the softmax is exact single-pass (no online rescale):
-//   stage   K rows -> Ks[key][80]      (row-major, 160-B stride: conflict-free ds_read_b128 A-fragments)
-//           V rows -> Vt[d][keys+8]    (transposed, written as packed row pairs; B-fragments of P.V are
-//                                       two conflict-free ds_read_b64 of 4 consecutive keys)
-//           every global load of the staging is issued before the first LDS write (one HBM latency, not seven)
+//   stage   K and V rows -> swizzled row-major LDS images (attn_mfma_common.h): A-fragments of QK^T are
+//           ds_read_b128, B-fragments of P.V are ds_read_b64_tr_b16 transpose reads of the SAME kind of image
+//           (no transposed copy is ever built); every global load of the staging is issued before the first
+//           LDS write (one HBM latency, not seven)
 //   S^T = K . Q^T per 16-query tile (v_mfma_f32_16x16x32_bf16; Q fragments straight from HBM, prefetched one
 //           tile ahead: each query row is used by exactly one wave). In the C layout every lane owns ONE
 //           query column, so max/sum are in-lane plus two xor-shuffles, and the exponentiated tile is already
@@ -30,10 +30,9 @@ constexpr int NT = 512, NW = 8;
 
 template <int NKT> struct SpaceLds {
   static constexpr int KROWS = NKT * 16;
-  static constexpr int LDK = NKT * 16 + 8;              // LDK/2 = 4*odd: conflict-free b64 reads
   static constexpr int ks_off = 0;                                       // bytes
-  static constexpr int vt_off = ks_off + KROWS * KS * 2;
-  static constexpr int qc_off = vt_off + 64 * LDK * 2;                   // f32[64]
+  static constexpr int vs_off = ks_off + KROWS * RS * 2;
+  static constexpr int qc_off = vs_off + KROWS * RS * 2;                 // f32[64]
   static constexpr int ot_off = qc_off + 64 * 4;                         // 8 waves x [16][OS] bf16 ...
   // ... aliased (after a barrier) by the CLS-phase scratch: sc f32[KROWS], red f32[4][64] + f32[16]
   static constexpr int sc_off = ot_off;
@@ -50,10 +49,9 @@ __global__ __launch_bounds__(NT, (NKT <= 13 ? 4 : 2)) void space_fwd_kernel(cons
                                                           float* __restrict__ lse, float* __restrict__ cls_ws, int F,
                                                           int N, int H) {
   using L = SpaceLds<NKT>;
-  constexpr int LDK = L::LDK;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint16_t* Ks = reinterpret_cast<uint16_t*>(smem + L::ks_off);
-  uint16_t* Vt = reinterpret_cast<uint16_t*>(smem + L::vt_off);
+  uint16_t* Vs = reinterpret_cast<uint16_t*>(smem + L::vs_off);
   uint16_t* Ot = reinterpret_cast<uint16_t*>(smem + L::ot_off);
   float* qc = reinterpret_cast<float*>(smem + L::qc_off);
   float* sc = reinterpret_cast<float*>(smem + L::sc_off);
@@ -76,15 +74,16 @@ __global__ __launch_bounds__(NT, (NKT <= 13 ? 4 : 2)) void space_fwd_kernel(cons
   uint4 qn0 = *reinterpret_cast<const uint4*>(q_ptr(qt_first)), qn1 = *reinterpret_cast<const uint4*>(q_ptr(qt_first) + 32);
 
   stage_rows2<NT, (L::KROWS + 63) / 64>(
-      Ks, nullptr, [&](int r) { return base + (size_t)(TEXT ? r : (r == 0 ? 0 : tok0 + r - 1)) * tstride + D; },
-      nullptr, Vt, [&](int r) { return base + (size_t)(TEXT ? r : (r == 0 ? 0 : tok0 + r - 1)) * tstride + 2 * D; },
-      LDK, L::KROWS, nkeys, tid);
+      Ks, [&](int r) { return base + (size_t)(TEXT ? r : (r == 0 ? 0 : tok0 + r - 1)) * tstride + D; },
+      Vs, [&](int r) { return base + (size_t)(TEXT ? r : (r == 0 ? 0 : tok0 + r - 1)) * tstride + 2 * D; },
+      L::KROWS, nkeys, tid);
   if (!TEXT && tid < 64) qc[tid] = bf16_to_f32(base[tid]) * 0.125f;     // cls query of this head, pre-scaled
   __syncthreads();
 
   // ---- patch queries: one 16-query tile per wave at a time ------------------------------------------------
   constexpr float kScale = 0.125f, kExp2 = 0.125f * 1.4426950408889634f;     // exp(x*scale) = exp2(x*kExp2)
   uint16_t* ot = Ot + wave * 16 * OS;
+  const FragOff fo = frag_offsets(lane);
 #pragma unroll 1
   for (int qt = wave; qt * 16 < N; qt += NW) {
     const int qrow = qt * 16 + c;
@@ -98,12 +97,12 @@ __global__ __launch_bounds__(NT, (NKT <= 13 ? 4 : 2)) void space_fwd_kernel(cons
     f32x4 acc[NKT];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
-      const bf16x8 a0 = as_bf16x8(*reinterpret_cast<const uint4*>(Ks + (kt * 16 + c) * KS + g * 8));
+      const bf16x8 a0 = as_bf16x8(tile_frag(Ks, kt, fo.a[0]));
       acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, qf0, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
     }
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
-      const bf16x8 a1 = as_bf16x8(*reinterpret_cast<const uint4*>(Ks + (kt * 16 + c) * KS + g * 8 + 32));
+      const bf16x8 a1 = as_bf16x8(tile_frag(Ks, kt, fo.a[1]));
       acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, qf1, acc[kt], 0, 0, 0);
     }
     // acc[kt][r] = raw S[query c][key kt*16 + g*4 + r]. Space/time groups: NKT = ceil(nkeys/16) exactly, so
@@ -151,10 +150,9 @@ __global__ __launch_bounds__(NT, (NKT <= 13 ? 4 : 2)) void space_fwd_kernel(cons
       pa.w = 2 * j + 1 <= last ? pack_bf16x2(acc[j1][2], acc[j1][3]) : 0u;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        const uint16_t* vp = Vt + (size_t)(dt * 16 + c) * LDK + 2 * j * 16 + g * 4;
-        const uint2 lo = *reinterpret_cast<const uint2*>(vp);
+        const uint2 lo = tile_frag_tr(Vs, 2 * j, fo.tr[dt]);
         uint2 hi = make_uint2(0, 0);
-        if (2 * j + 1 <= last) hi = *reinterpret_cast<const uint2*>(vp + 16);
+        if (2 * j + 1 <= last) hi = tile_frag_tr(Vs, 2 * j + 1, fo.tr[dt]);
         o[dt] = mfma(pa, make_uint4(lo.x, lo.y, hi.x, hi.y), o[dt]);
       }
     }
@@ -182,11 +180,10 @@ __global__ __launch_bounds__(NT, (NKT <= 13 ? 4 : 2)) void space_fwd_kernel(cons
   float s = -INFINITY;
   if (tid < nkeys && (tid > 0 || f == 0)) {
     s = 0.f;
-    const uint16_t* kp = Ks + tid * KS;
 #pragma unroll
     for (int d8 = 0; d8 < 8; ++d8) {
       float kv[8];
-      Elem<bf16_t>::load8(reinterpret_cast<const bf16_t*>(kp + d8 * 8), kv);
+      Elem<bf16_t>::load8(reinterpret_cast<const bf16_t*>(Ks + img_off(tid, d8)), kv);
 #pragma unroll
       for (int e = 0; e < 8; ++e) s = fmaf(qc[d8 * 8 + e], kv[e], s);
     }
@@ -206,16 +203,9 @@ __global__ __launch_bounds__(NT, (NKT <= 13 ? 4 : 2)) void space_fwd_kernel(cons
     // acc[d] = sum_j p_j V[j][d]; thread (d = lane, quarter = wave) walks a quarter of the key rows
     constexpr int QK = L::KROWS / 4;
     float a = 0.f;
-    const uint16_t* vrow = Vt + (size_t)lane * LDK + wave * QK;
 #pragma unroll 4
-    for (int j = 0; j < QK; j += 4) {
-      const uint2 v4 = *reinterpret_cast<const uint2*>(vrow + j);
-      const float4 p4 = *reinterpret_cast<const float4*>(sc + wave * QK + j);
-      a = fmaf(p4.x, __uint_as_float(v4.x << 16), a);
-      a = fmaf(p4.y, __uint_as_float(v4.x & 0xffff0000u), a);
-      a = fmaf(p4.z, __uint_as_float(v4.y << 16), a);
-      a = fmaf(p4.w, __uint_as_float(v4.y & 0xffff0000u), a);
-    }
+    for (int j = wave * QK; j < (wave + 1) * QK; ++j)       // one 128-B row per step, lanes = channels
+      a = fmaf(sc[j], bf16_to_f32(Vs[img_off(j, lane >> 3) + (lane & 7)]), a);
     red[wave * 64 + lane] = a;
   }
   __syncthreads();
