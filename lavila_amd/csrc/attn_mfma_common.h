@@ -71,24 +71,32 @@ __device__ __forceinline__ uint2 tile_frag_tr(const uint16_t* img, int tile, int
   return __builtin_bit_cast(uint2, v);
 }
 
-// Cooperative staging of two row sets A and B (`nrows` rows of 64 bf16 each; row r at srcA(r) / srcB(r)) into
-// swizzled row-major images; rows in [nrows, rows_pad) are zero-filled. NT threads, 8 lanes per row,
-// MAXP >= ceil(rows_pad / (NT/8)) passes. ALL global loads are issued before the first LDS write so that the
-// passes overlap in flight instead of paying one HBM latency each.
-template <int NT, int MAXP, typename SrcA, typename SrcB>
-__device__ __forceinline__ void stage_rows2(uint16_t* imgA, SrcA srcA, uint16_t* imgB, SrcB srcB, int rows_pad,
-                                            int nrows, int tid) {
+// Cooperative staging of two row sets A and B (`nrows` rows of 64 bf16 each) into swizzled row-major images;
+// rows in [nrows, rows_pad) are zero-filled. NT threads, 8 lanes per row, MAXP >= ceil(rows_pad / (NT/8))
+// passes. Row r of set X lives at pX + r * strideX (elements), except row 0 when p0X != nullptr (the cls token
+// in front of a frame's patch rows). One pointer per thread + a constant stride per pass keeps the address
+// arithmetic out of the way, and ALL global loads are issued before the first LDS write so that the passes
+// overlap in flight instead of paying one HBM latency each.
+template <int NT, int MAXP>
+__device__ __forceinline__ void stage_rows2(uint16_t* imgA, const uint16_t* pA, size_t strideA, const uint16_t* p0A,
+                                            uint16_t* imgB, const uint16_t* pB, size_t strideB, const uint16_t* p0B,
+                                            int rows_pad, int nrows, int tid) {
   constexpr int RPP = NT / 8;
   const int c8 = tid & 7, r_in = tid >> 3;
+  const uint16_t* ra = pA + (size_t)r_in * strideA + c8 * 8;
+  const uint16_t* rb = pB + (size_t)r_in * strideB + c8 * 8;
   uint4 va[MAXP], vb[MAXP];
 #pragma unroll
   for (int p = 0; p < MAXP; ++p) {
     const int r = p * RPP + r_in;
+    const bool first = p == 0 && r_in == 0;
+    const uint16_t* sa = (first && p0A != nullptr) ? p0A + c8 * 8 : ra + (size_t)p * RPP * strideA;
+    const uint16_t* sb = (first && p0B != nullptr) ? p0B + c8 * 8 : rb + (size_t)p * RPP * strideB;
     va[p] = make_uint4(0, 0, 0, 0);
     vb[p] = make_uint4(0, 0, 0, 0);
     if (r < nrows) {
-      va[p] = *reinterpret_cast<const uint4*>(srcA(r) + c8 * 8);
-      vb[p] = *reinterpret_cast<const uint4*>(srcB(r) + c8 * 8);
+      va[p] = *reinterpret_cast<const uint4*>(sa);
+      vb[p] = *reinterpret_cast<const uint4*>(sb);
     }
   }
 #pragma unroll

@@ -67,10 +67,11 @@ __global__ __launch_bounds__(512, (NKT <= 13 ? 4 : 2)) void space_bwd_dq_kernel(
   };
   load_frags(wave * 16 < N ? wave : 0);
 
-  stage_rows2<512, (L::KROWS + 63) / 64>(
-      Ks, [&](int r) { return base + (size_t)(TEXT ? r : (r == 0 ? 0 : tok0 + r - 1)) * ts + D; },
-      Vs, [&](int r) { return base + (size_t)(TEXT ? r : (r == 0 ? 0 : tok0 + r - 1)) * ts + 2 * D; },
-      L::KROWS, nkeys, tid);
+  {   // key row r = token tok0 + r - 1 (r >= 1) or the cls token (r = 0); text: token r
+    const uint16_t* krow0 = base + (size_t)(TEXT ? 0 : tok0 - 1) * ts + D;
+    stage_rows2<512, (L::KROWS + 63) / 64>(Ks, krow0, ts, TEXT ? nullptr : base + D, Vs, krow0 + D, ts,
+                                          TEXT ? nullptr : base + 2 * D, L::KROWS, nkeys, tid);
+  }
   __syncthreads();
 
   uint16_t* ot = Ot + wave * 16 * OS;
@@ -226,8 +227,8 @@ __global__ __launch_bounds__(512, 4) void space_bwd_dkv_kernel(
   };
   load_kv(wave < nkt ? wave : 0);
 
-  stage_rows2<512, 4>(Qs, [&](int r) { return base + (size_t)(tok0 + r) * ts; },
-                      dOs, [&](int r) { return dobase + (size_t)(tok0 + r) * D; }, QROWS, N, tid);
+  stage_rows2<512, 4>(Qs, base + (size_t)tok0 * ts, ts, nullptr, dOs, dobase + (size_t)tok0 * D, (size_t)D, nullptr,
+                      QROWS, N, tid);
   for (int q = tid; q < QROWS; q += 512) {
     lse_s[q] = q < N ? lrow[tok0 + q] * kLog2e : INFINITY;      // log2 units; padded queries: exp2(-inf) = 0
     del_s[q] = q < N ? drow[tok0 + q] : 0.f;

@@ -13,9 +13,10 @@
 //           the A operand of O = P.V (k-order permuted identically on the V side): no cross-lane traffic.
 //           exp is one v_fma + one v_exp (scale and log2e folded), bf16 packing is v_cvt_pk_bf16_f32.
 //   O tile -> per-wave LDS transpose -> 16-B row-contiguous stores.
-// The CLS query (token 0) attends to ALL keys; each workgroup adds the flash-style partial
-// (max, sum, acc[64]) over its own frame's keys from the same LDS image (the cls key itself is taken
-// by frame 0), and a tiny combine kernel merges the F partials: K and V are read from HBM once.
+// The CLS query (token 0) attends to ALL keys; each workgroup runs it as one extra query "tile" through the
+// same MFMA path and emits the flash-style partial (max, sum, un-normalised acc[64]) over its own frame's keys
+// (the cls key itself is taken by frame 0); a tiny combine kernel merges the F partials: K and V are read from
+// HBM once and no separate pass or barrier is spent on the CLS row.
 //
 // Roofline: algorithmic HBM bytes per (b,f,h) = 4 * N * 64 * 2 (q,k,v in, o out); MFMA work is ~1/3 of
 // the HBM time at 8 TB/s on TSF-B, so the kernel is built to stream: 2
@@ -32,30 +33,21 @@ template <int NKT> struct SpaceLds {
   static constexpr int KROWS = NKT * 16;
   static constexpr int ks_off = 0;                                       // bytes
   static constexpr int vs_off = ks_off + KROWS * RS * 2;
-  static constexpr int qc_off = vs_off + KROWS * RS * 2;                 // f32[64]
-  static constexpr int ot_off = qc_off + 64 * 4;                         // 8 waves x [16][OS] bf16 ...
-  // ... aliased (after a barrier) by the CLS-phase scratch: sc f32[KROWS], red f32[4][64] + f32[16]
-  static constexpr int sc_off = ot_off;
-  static constexpr int red_off = sc_off + KROWS * 4;
-  static constexpr int scratch = NW * 16 * OS * 2 > KROWS * 4 + (4 * 64 + 16) * 4 ? NW * 16 * OS * 2
-                                                                                  : KROWS * 4 + (4 * 64 + 16) * 4;
-  static constexpr int total = ot_off + scratch;
+  static constexpr int ot_off = vs_off + KROWS * RS * 2;                 // 8 waves x [16][OS] bf16
+  static constexpr int total = ot_off + NW * 16 * OS * 2;
 };
 
 // TEXT = true reuses the kernel for the causal text tower (openai_model.py:196-198): one group per (b, h),
 // L queries x L keys, no cls row, key j visible to query i iff j <= i, no CLS partial.
 template <int NKT, bool TEXT>
-__global__ __launch_bounds__(NT, (NKT <= 13 ? 4 : 2)) void space_fwd_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
-                                                          float* __restrict__ lse, float* __restrict__ cls_ws, int F,
-                                                          int N, int H) {
+__global__ __launch_bounds__(NT, (NKT <= 13 ? 4 : 2)) void space_fwd_kernel(
+    const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, float* __restrict__ lse,
+    float* __restrict__ cls_ws, int F, int N, int H) {
   using L = SpaceLds<NKT>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint16_t* Ks = reinterpret_cast<uint16_t*>(smem + L::ks_off);
   uint16_t* Vs = reinterpret_cast<uint16_t*>(smem + L::vs_off);
   uint16_t* Ot = reinterpret_cast<uint16_t*>(smem + L::ot_off);
-  float* qc = reinterpret_cast<float*>(smem + L::qc_off);
-  float* sc = reinterpret_cast<float*>(smem + L::sc_off);
-  float* red = reinterpret_cast<float*>(smem + L::red_off);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = blockIdx.x % H, f = (blockIdx.x / H) % F, b = blockIdx.x / (H * F);
@@ -64,31 +56,36 @@ __global__ __launch_bounds__(NT, (NKT <= 13 ? 4 : 2)) void space_fwd_kernel(cons
   const uint16_t* base = qkv + (size_t)b * T * tstride + h * 64;      // + token*3D (+D: k, +2D: v)
   const int tok0 = TEXT ? 0 : 1 + f * N;                               // token of query 0 (and of key row 1)
   const int c = lane & 15, g = lane >> 4;
+  // query tiles: nqt patch tiles; in the space/time towers one more "tile" holds the CLS query (token 0), whose
+  // flash-style partial over this frame's keys comes out of the very same MFMA path (column 0 of that tile)
+  const int nqt = (N + 15) / 16, ntiles = TEXT ? nqt : nqt + 1;
 
   // Q fragments of this wave's first tile go out before the staging loads
   auto q_ptr = [&](int qt) {
     const int qr = qt * 16 + c;
-    return base + (size_t)(tok0 + (qr < N ? qr : N - 1)) * tstride + g * 8;
+    const int tok = (!TEXT && qt == nqt) ? 0 : tok0 + (qr < N ? qr : N - 1);
+    return base + (size_t)tok * tstride + g * 8;
   };
-  const int qt_first = wave * 16 < N ? wave : 0;
+  const int qt_first = wave < ntiles ? wave : 0;
   uint4 qn0 = *reinterpret_cast<const uint4*>(q_ptr(qt_first)), qn1 = *reinterpret_cast<const uint4*>(q_ptr(qt_first) + 32);
 
-  stage_rows2<NT, (L::KROWS + 63) / 64>(
-      Ks, [&](int r) { return base + (size_t)(TEXT ? r : (r == 0 ? 0 : tok0 + r - 1)) * tstride + D; },
-      Vs, [&](int r) { return base + (size_t)(TEXT ? r : (r == 0 ? 0 : tok0 + r - 1)) * tstride + 2 * D; },
-      L::KROWS, nkeys, tid);
-  if (!TEXT && tid < 64) qc[tid] = bf16_to_f32(base[tid]) * 0.125f;     // cls query of this head, pre-scaled
+  // K and V rows -> LDS images. Key row r is token tok0 + r - 1 (r >= 1) or the cls token (r = 0).
+  {
+    const uint16_t* krow0 = base + (size_t)(TEXT ? 0 : tok0 - 1) * tstride + D;
+    stage_rows2<NT, (L::KROWS + 63) / 64>(Ks, krow0, tstride, TEXT ? nullptr : base + D, Vs, krow0 + D, tstride,
+                                          TEXT ? nullptr : base + 2 * D, L::KROWS, nkeys, tid);
+  }
   __syncthreads();
 
-  // ---- patch queries: one 16-query tile per wave at a time ------------------------------------------------
   constexpr float kScale = 0.125f, kExp2 = 0.125f * 1.4426950408889634f;     // exp(x*scale) = exp2(x*kExp2)
   uint16_t* ot = Ot + wave * 16 * OS;
   const FragOff fo = frag_offsets(lane);
 #pragma unroll 1
-  for (int qt = wave; qt * 16 < N; qt += NW) {
+  for (int qt = wave; qt < ntiles; qt += NW) {
+    const bool cls_tile = !TEXT && qt == nqt;
     const int qrow = qt * 16 + c;
     const bf16x8 qf0 = as_bf16x8(qn0), qf1 = as_bf16x8(qn1);
-    if ((qt + NW) * 16 < N) {           // prefetch the next tile's Q fragments under this tile's MFMAs
+    if (qt + NW < ntiles) {             // prefetch the next tile's Q fragments under this tile's MFMAs
       qn0 = *reinterpret_cast<const uint4*>(q_ptr(qt + NW));
       qn1 = *reinterpret_cast<const uint4*>(q_ptr(qt + NW) + 32);
     }
@@ -105,8 +102,10 @@ __global__ __launch_bounds__(NT, (NKT <= 13 ? 4 : 2)) void space_fwd_kernel(cons
       const bf16x8 a1 = as_bf16x8(tile_frag(Ks, kt, fo.a[1]));
       acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, qf1, acc[kt], 0, 0, 0);
     }
-    // acc[kt][r] = raw S[query c][key kt*16 + g*4 + r]. Space/time groups: NKT = ceil(nkeys/16) exactly, so
-    // only the last tile can hold padded keys (compile-time); text: causal mask on every tile.
+    // acc[kt][r] = raw S[query c][key kt*16 + g*4 + r]. Space groups: NKT = ceil(nkeys/16) exactly, so only the
+    // last tile can hold padded keys (compile-time); text: causal mask on every tile. The CLS query sees the
+    // cls key (row 0) only in frame 0, so that the F partials count it once.
+    if (cls_tile && f != 0 && g == 0) acc[0][0] = -INFINITY;
     float m = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
@@ -156,7 +155,18 @@ __global__ __launch_bounds__(NT, (NKT <= 13 ? 4 : 2)) void space_fwd_kernel(cons
         o[dt] = mfma(pa, make_uint4(lo.x, lo.y, hi.x, hi.y), o[dt]);
       }
     }
-    // o[dt][r] = O[query g*4+r][d = dt*16 + c]; normalise, transpose through LDS, store whole rows
+    // o[dt][r] = O[query g*4+r][d = dt*16 + c]
+    if (cls_tile) {
+      // record of the CLS query over this frame's keys: (max, sum, un-normalised acc[64]) = column/row 0
+      float* rec = cls_ws + (((size_t)b * H + h) * F + f) * CLS_REC;
+      if (g == 0) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) rec[2 + dt * 16 + c] = o[dt][0];
+        if (c == 0) { rec[0] = m * kScale; rec[1] = l; }
+      }
+      continue;
+    }
+    // normalise, transpose through LDS, store whole rows
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float linv = __builtin_amdgcn_rcpf(__shfl(l, g * 4 + r, 64));
@@ -172,53 +182,6 @@ __global__ __launch_bounds__(NT, (NKT <= 13 ? 4 : 2)) void space_fwd_kernel(cons
       if (q < N) *reinterpret_cast<uint4*>(out + ((size_t)b * T + tok0 + q) * D + h * 64 + ch * 8) = v;
     }
     if (g == 0 && qrow < N) lse[((size_t)b * H + h) * T + tok0 + qrow] = m * kScale + __logf(l);
-  }
-
-  if constexpr (TEXT) return;
-  // ---- CLS query partial over this frame's keys (key row 0 = the cls key itself: frame 0 only) -----------
-  __syncthreads();                    // every wave is done with its Ot tile: the scratch below aliases it
-  float s = -INFINITY;
-  if (tid < nkeys && (tid > 0 || f == 0)) {
-    s = 0.f;
-#pragma unroll
-    for (int d8 = 0; d8 < 8; ++d8) {
-      float kv[8];
-      Elem<bf16_t>::load8(reinterpret_cast<const bf16_t*>(Ks + img_off(tid, d8)), kv);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) s = fmaf(qc[d8 * 8 + e], kv[e], s);
-    }
-  }
-  const float mw = wave_max(s);
-  if (lane == 0) red[256 + wave] = mw;
-  __syncthreads();
-  float M = red[256];
-#pragma unroll
-  for (int w = 1; w < NW; ++w) M = fmaxf(M, red[256 + w]);
-  const float p = s == -INFINITY ? 0.f : __expf(s - M);
-  if (tid < L::KROWS) sc[tid] = p;
-  const float lw = wave_sum(p);
-  if (lane == 0) red[264 + wave] = lw;
-  __syncthreads();
-  if (wave < 4) {
-    // acc[d] = sum_j p_j V[j][d]; thread (d = lane, quarter = wave) walks a quarter of the key rows
-    constexpr int QK = L::KROWS / 4;
-    float a = 0.f;
-#pragma unroll 4
-    for (int j = wave * QK; j < (wave + 1) * QK; ++j)       // one 128-B row per step, lanes = channels
-      a = fmaf(sc[j], bf16_to_f32(Vs[img_off(j, lane >> 3) + (lane & 7)]), a);
-    red[wave * 64 + lane] = a;
-  }
-  __syncthreads();
-  if (tid < 64) {
-    float* rec = cls_ws + (((size_t)b * H + h) * F + f) * CLS_REC;
-    rec[2 + tid] = red[tid] + red[64 + tid] + red[128 + tid] + red[192 + tid];
-    if (tid == 0) {
-      float ls = 0.f;
-#pragma unroll
-      for (int w = 0; w < NW; ++w) ls += red[264 + w];
-      rec[0] = M;
-      rec[1] = ls;
-    }
   }
 }
 
@@ -243,7 +206,6 @@ template <int NKT, bool TEXT = false>
 int launch_space_fwd(const void* qkv, void* out, float* lse, float* ws, int B, int F, int N, int H, hipStream_t st) {
   using L = SpaceLds<NKT>;
   static_assert(L::total <= 160 * 1024, "LDS per CU");   // <= 80 KB (NKT <= 13) keeps 2 workgroups per CU
-  static_assert(NKT * 16 <= NT, "CLS phase: one key per thread");
   static bool attr_set = false;
   if (L::total > 64 * 1024 && !attr_set) {
     (void)hipFuncSetAttribute((const void*)space_fwd_kernel<NKT, TEXT>, hipFuncAttributeMaxDynamicSharedMemorySize,
