@@ -101,11 +101,10 @@ def load_reference():
     for k in saved:
         del sys.modules[k]
     sys.modules.update(stubs)
-    # a regular package (our shim has __init__.py) shadows the reference's namespace package wherever it sits
-    # on sys.path, so hide every path entry that holds a `lavila/__init__.py` while importing the reference
+    # `lavila` is a namespace package in both trees (no __init__.py): the first sys.path entry that holds
+    # lavila/models/<module>.py wins, so the reference root goes first while its modules are imported
     saved_path = list(sys.path)
-    sys.path[:] = [REFERENCE_ROOT] + [p for p in saved_path
-                                      if not os.path.isfile(os.path.join(p or os.getcwd(), 'lavila', '__init__.py'))]
+    sys.path.insert(0, REFERENCE_ROOT)
     try:
         ns = types.SimpleNamespace()
         ns.timesformer = importlib.import_module("lavila.models.timesformer")

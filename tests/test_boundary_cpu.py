@@ -113,3 +113,23 @@ def test_checkpoint_helpers_match_reference():
         assert torch.equal(a['visual.temporal_embed'], b['visual.temporal_embed'])
     with pytest.raises(NotImplementedError):
         inflate_positional_embeds({'visual.pos_embed': torch.zeros(1, 5, 8)}, {'visual.pos_embed': torch.zeros(1, 10, 8)})
+
+
+@pytest.mark.skipif(not reference_available(), reason='reference only exists in the build container')
+def test_drop_in_coexists_with_reference_tree():
+    """With this repo ahead of the reference on sys.path, the hot-path modules resolve to lavila_amd while every
+    other reference module (meters, schedulers, ...) still comes from the reference tree."""
+    import subprocess
+    import sys
+    from oracle.ref_import import REFERENCE_ROOT
+    code = (
+        "import sys; sys.path[:0] = [%r, %r]\n"
+        "import lavila.models.models as m, lavila.models.loss as l, lavila.models.timesformer as t\n"
+        "import lavila.utils.meter as meter, lavila.utils.scheduler as sch, lavila.utils.distributed as d\n"
+        "assert m.__name__ == 'lavila_amd.models' and l.__name__ == 'lavila_amd.loss' and t.__name__ == 'lavila_amd.timesformer'\n"
+        "assert meter.__file__.startswith(%r) and sch.__file__.startswith(%r), meter.__file__\n"
+        "assert d.__file__.startswith(%r)\n"
+        "assert hasattr(m, 'CLIP_OPENAI_TIMESFORMER_BASE') and hasattr(m.loss, 'CLIPLoss')\n"
+        "print('ok')\n" % (ROOT, REFERENCE_ROOT, REFERENCE_ROOT, REFERENCE_ROOT, ROOT))
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and 'ok' in out.stdout, out.stderr[-2000:]
