@@ -133,6 +133,20 @@ int lvl_clip_loss_bwd(const void* img_all, const void* txt_all, const float* lse
                       const float* scale, const float* upstream, float coef, int B, int G, int E,
                       int row0, float* dimg, float* dtxt, int dtype, void* stream);
 
+/* ---- contrastive head with per-pair temperature (SSLCLIPLoss, loss.py:121-217) ---------------------------
+ * Same slab structure as lvl_clip_loss_*; ind_all: [G] int32 gt_indicators in rank order (1 = ground-truth
+ * narration, 0 = pseudo-label); scales3: DEVICE pointer to {pseudo, sqrt(pseudo*real), real}; the pair (i,j)
+ * uses scales3[ind[i] + ind[j]] (loss.py:160-166,172-178).
+ * stats: [2,B,8] f32 = {lse, diag logit, E0, E1, E2, diag dot, max logit, 0} with
+ * Ek = sum_{j: ind[i]+ind[j]==k} softmax_j * (a_i . b_j): d(loss)/d(scales3[k]) follows without another pass. */
+int lvl_ssl_clip_loss_fwd(const void* img_all, const void* txt_all, const int32_t* ind_all,
+                          const float* scales3, int B, int G, int E, int row0, float* stats,
+                          int32_t* argmax, float* logits, int dtype, void* stream);
+int lvl_ssl_clip_loss_bwd(const void* img_all, const void* txt_all, const int32_t* ind_all,
+                          const float* lse_all, const float* scales3, const float* upstream, float coef,
+                          int B, int G, int E, int row0, float* dimg, float* dtxt, int dtype,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif

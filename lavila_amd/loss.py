@@ -146,9 +146,110 @@ def gather_features(image_features, text_features, local_loss=False, gather_with
     return all_img, all_txt
 
 
-class SSLCLIPLoss(nn.Module):
-    """loss.py:121-217 (pseudo-label temperature matrix). Next row of the scope table."""
+class _SSLContrastiveFn(torch.autograd.Function):
+    """Slab-parallel SSLCLIPLoss: same exchange plan as _ContrastiveFn (one fused all-gather of [img|txt|ind], one
+    small all-gather of row LSEs + partial sums, no backward collective)."""
 
-    def __init__(self, *args, **kwargs):
+    @staticmethod
+    def forward(ctx, image_embed, text_embed, logit_scale, scale_pseudo, indicators, crit):
+        W, rank = crit.world_size, crit.rank
+        B, E = image_embed.shape
+        dev = image_embed.device
+        dt = image_embed.dtype if (image_embed.dtype == text_embed.dtype and
+                                   image_embed.dtype in (torch.float32, torch.bfloat16)) else torch.float32
+        img, txt = image_embed.detach().to(dt), text_embed.detach().to(dt)
+        ind = indicators.detach().to(dev).reshape(-1)
+        real, pseudo = logit_scale.detach().float().reshape(()), scale_pseudo.detach().float().reshape(())
+        scales3 = torch.stack([pseudo, torch.sqrt(pseudo * real), real]).contiguous()
+        if W > 1:
+            both = all_gather_rows(torch.cat([img.float(), txt.float(), ind.float()[:, None]], dim=1))
+            img_all, txt_all = both[:, :E].to(dt).contiguous(), both[:, E:2 * E].to(dt).contiguous()
+            ind_all = both[:, 2 * E].round().to(torch.int32).contiguous()
+        else:
+            img_all, txt_all, ind_all = img.contiguous(), txt.contiguous(), ind.to(torch.int32).contiguous()
+        G = img_all.shape[0]
+        row0 = rank * B if W > 1 else 0
+
+        stats, argmax = crit._slab_forward(img_all, txt_all, ind_all, scales3, B, row0)     # [2,B,8], [2,B]
+        lse, diag_l, diag_z = stats[..., 0], stats[..., 1], stats[..., 5]
+        ind_loc = ind_all[row0:row0 + B]
+        labels = torch.arange(row0, row0 + B, device=dev, dtype=torch.int32)
+        ok = (argmax[0] == labels)
+        bucket_diag = 2 * ind_loc                                                            # mask of (i,i)
+        ds = [(stats[..., 2 + k] - diag_z * (bucket_diag == k).float()[None]).sum() for k in range(3)]
+        part = torch.stack([(lse - diag_l).sum(), ds[0], ds[1], ds[2], ok.sum().float(),
+                            (ok & (ind_loc == 1)).sum().float(), (ok & (ind_loc == 0)).sum().float()])
+        if W > 1:
+            allp = all_gather_rows(torch.cat([lse.reshape(-1), part])[None])               # [W, 2B+7]
+            lse_all = allp[:, :2 * B].reshape(W, 2, B).permute(1, 0, 2).reshape(2, G).contiguous()
+            sums = allp[:, 2 * B:].sum(0)
+        else:
+            lse_all, sums = lse.contiguous(), part
+        num_gt = (ind_all == 1).sum().float()
+        num_pseudo = (ind_all == 0).sum().float()
+        loss = sums[0] / (2 * G)
+        acc = 100.0 * sums[4] / G
+        acc_gt = 100.0 * sums[5] / num_gt
+        acc_pseudo = 100.0 * sums[6] / num_pseudo
+        ctx.save_for_backward(img_all, txt_all, ind_all, lse_all, scales3, sums)
+        ctx.cfg = (B, G, row0, W, crit, image_embed.dtype, text_embed.dtype, logit_scale.dtype, scale_pseudo.dtype)
+        ctx.mark_non_differentiable(acc, acc_gt, acc_pseudo, num_gt, num_pseudo)
+        return loss, acc, acc_gt, acc_pseudo, num_gt, num_pseudo
+
+    @staticmethod
+    def backward(ctx, dloss, *unused):
+        img_all, txt_all, ind_all, lse_all, scales3, sums = ctx.saved_tensors
+        B, G, row0, W, crit, idt, tdt, sdt, pdt = ctx.cfg
+        mult = float(W) if crit.use_vissl else 1.0
+        up = dloss.detach().float().reshape(1).contiguous()
+        dimg, dtxt = crit._slab_backward(img_all, txt_all, ind_all, lse_all, scales3, up, mult / (2 * G), B, row0)
+        pseudo, geo, real = scales3[0], scales3[1], scales3[2]
+        d0, d1, d2 = (up[0] * sums[1 + k] / (2 * G) for k in range(3))     # d loss / d scales3[k]
+        dreal = d2 + d1 * 0.5 * geo / real                                   # d sqrt(p r)/dr = sqrt(p r) / (2 r)
+        dpseudo = d0 + d1 * 0.5 * geo / pseudo
+        return dimg.to(idt), dtxt.to(tdt), dreal.to(sdt), dpseudo.to(pdt), None, None
+
+
+class SSLCLIPLoss(nn.Module):
+    """InfoNCE with per-pair temperature for pseudo-labelled narrations -- loss.py:121-217. `forward(outputs,
+    gt_indicators)`; same constructor, same output dict (loss, clip_loss, num_gt, num_pseudo, clip_acc, clip_acc_gt,
+    clip_acc_pseudo) and the learnable `logit_scale_pseudo` parameter."""
+
+    def __init__(self, use_vissl=False, local_loss=False, gather_with_grad=False, cache_labels=False, rank=0,
+                 world_size=1, scale_init=0.08, freeze_scale=False):
         super().__init__()
-        raise NotImplementedError('SSLCLIPLoss is scheduled after the CLIPLoss path (SURVEY.md section 8f)')
+        import numpy as np
+        if local_loss:
+            raise NotImplementedError('local_loss=True is not built (never enabled by the reference drivers)')
+        self.use_vissl = use_vissl
+        self.local_loss = local_loss
+        self.gather_with_grad = gather_with_grad
+        self.cache_labels = cache_labels
+        self.rank = rank
+        self.world_size = world_size
+        self.logit_scale_pseudo = nn.Parameter(torch.ones([]) * np.log(1 / scale_init))
+        if freeze_scale:
+            self.logit_scale_pseudo.requires_grad = False
+        self.prev_num_logits = 0
+        self.labels = {}
+
+    # -- kernel hooks (tests override these two with the CPU oracle to exercise the collectives on gloo) ---
+    def _slab_forward(self, img_all, txt_all, ind_all, scales3, B, row0):
+        stats, argmax, _ = ops.ssl_clip_loss_fwd_raw(img_all, txt_all, ind_all, scales3, B, row0)
+        return stats, argmax
+
+    def _slab_backward(self, img_all, txt_all, ind_all, lse_all, scales3, upstream, coef, B, row0):
+        return ops.ssl_clip_loss_bwd_raw(img_all, txt_all, ind_all, lse_all, scales3, upstream, coef, B, row0)
+
+    def forward(self, outputs, gt_indicators):
+        if self.world_size > 1:
+            if not self.use_vissl:
+                raise NotImplementedError      # as the reference (loss.py:167-168)
+            if not (dist.is_available() and dist.is_initialized()):
+                raise RuntimeError('SSLCLIPLoss(world_size>1) needs an initialised torch.distributed process group')
+        loss, acc, acc_gt, acc_pseudo, num_gt, num_pseudo = _SSLContrastiveFn.apply(
+            outputs['image_embed'], outputs['text_embed'], outputs['logit_scale'], self.logit_scale_pseudo.exp(),
+            gt_indicators, self)
+        return {'loss': loss, 'clip_loss': loss, 'num_gt': num_gt.reshape(1).long().cpu(),
+                'num_pseudo': num_pseudo.reshape(1).long().cpu(), 'clip_acc': acc, 'clip_acc_gt': acc_gt,
+                'clip_acc_pseudo': acc_pseudo}

@@ -355,3 +355,28 @@ def clip_loss_bwd_raw(img_all, txt_all, lse_all, scale, upstream, coef: float, B
                                       float(coef), B, G, E, row0, C.ptr(dimg), C.ptr(dtxt), C.dtype_code(img_all),
                                       C.stream_ptr()), 'lvl_clip_loss_bwd')
     return dimg, dtxt
+
+
+def ssl_clip_loss_fwd_raw(img_all, txt_all, ind_all, scales3, B: int, row0: int, want_logits=False):
+    """ind_all: [G] int32 device tensor; scales3: [3] float32 device tensor {pseudo, sqrt(pseudo*real), real}."""
+    C.require_device(img_all, txt_all, ind_all, scales3)
+    G, E = img_all.shape
+    dev = img_all.device
+    stats = torch.empty(2, B, 8, dtype=torch.float32, device=dev)
+    argmax = torch.empty(2, B, dtype=torch.int32, device=dev)
+    logits = torch.empty(2, B, G, dtype=torch.float32, device=dev) if want_logits else None
+    C.check(C.lib().lvl_ssl_clip_loss_fwd(C.ptr(img_all), C.ptr(txt_all), C.ptr(ind_all), C.ptr(scales3), B, G, E, row0,
+                                          C.ptr(stats), C.ptr(argmax), C.ptr(logits), C.dtype_code(img_all),
+                                          C.stream_ptr()), 'lvl_ssl_clip_loss_fwd')
+    return stats, argmax, logits
+
+
+def ssl_clip_loss_bwd_raw(img_all, txt_all, ind_all, lse_all, scales3, upstream, coef: float, B: int, row0: int):
+    C.require_device(img_all, txt_all, ind_all, lse_all, scales3, upstream)
+    G, E = img_all.shape
+    dimg = torch.empty(B, E, dtype=torch.float32, device=img_all.device)
+    dtxt = torch.empty(B, E, dtype=torch.float32, device=img_all.device)
+    C.check(C.lib().lvl_ssl_clip_loss_bwd(C.ptr(img_all), C.ptr(txt_all), C.ptr(ind_all), C.ptr(lse_all),
+                                          C.ptr(scales3), C.ptr(upstream), float(coef), B, G, E, row0, C.ptr(dimg),
+                                          C.ptr(dtxt), C.dtype_code(img_all), C.stream_ptr()), 'lvl_ssl_clip_loss_bwd')
+    return dimg, dtxt

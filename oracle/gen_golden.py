@@ -195,6 +195,57 @@ def run_multirank_loss_golden():
                os.path.join(GOLDEN, 'clip_loss_multirank.pt'))
 
 
+_ssl_inputs = O.ssl_synthetic_inputs
+
+
+def _ssl_rank_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    ref = load_reference()
+    E, Bl = 16, 4
+    img, txt, ind = _ssl_inputs(world * Bl, E, 91)
+    sl = slice(rank * Bl, (rank + 1) * Bl)
+    li, lt = img[sl].clone().requires_grad_(True), txt[sl].clone().requires_grad_(True)
+    scale = torch.tensor(14.285714).requires_grad_(True)
+    crit = ref.loss.SSLCLIPLoss(use_vissl=True, cache_labels=True, rank=rank, world_size=world, scale_init=0.08)
+    out = crit({'image_embed': li, 'text_embed': lt, 'logit_scale': scale}, ind[sl].clone())
+    out['loss'].backward()
+    q.put((rank, {k: float(v) for k, v in out.items()}, li.grad.tolist(), lt.grad.tolist(), scale.grad.item(),
+           crit.logit_scale_pseudo.grad.item()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def run_ssl_loss_golden(ref):
+    """SSLCLIPLoss (loss.py:121-217): single process, and 2 gloo ranks with use_vissl=True."""
+    import torch.multiprocessing as mp
+    img, txt, ind = _ssl_inputs(12, 16, 91)
+    li, lt = img.clone().requires_grad_(True), txt.clone().requires_grad_(True)
+    scale = torch.tensor(14.285714).requires_grad_(True)
+    crit = ref.loss.SSLCLIPLoss(use_vissl=False, cache_labels=True, rank=0, world_size=1, scale_init=0.08)
+    out = crit({'image_embed': li, 'text_embed': lt, 'logit_scale': scale}, ind.clone())
+    out['loss'].backward()
+    single = {'out': {k: float(v) for k, v in out.items()}, 'dimg': li.grad.clone(), 'dtxt': lt.grad.clone(),
+              'dscale': scale.grad.item(), 'dpseudo_param': crit.logit_scale_pseudo.grad.item()}
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    world = 2
+    procs = [ctx.Process(target=_ssl_rank_worker, args=(r, world, 29655, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join()
+    multi = {'world': world, 'B_local': 4, 'out': [g[1] for g in got],
+             'dimg': torch.cat([torch.tensor(g[2]) for g in got]), 'dtxt': torch.cat([torch.tensor(g[3]) for g in got]),
+             'dscale': [g[4] for g in got], 'dpseudo_param': [g[5] for g in got]}
+    torch.save({'E': 16, 'seed': 91, 'scale': 14.285714, 'scale_init': 0.08, 'single_G': 12, 'single': single,
+                'multi': multi}, os.path.join(GOLDEN, 'ssl_clip_loss.pt'))
+    print(f"[golden] ssl_clip_loss: single loss={single['out']['loss']:.6f} multi loss={multi['out'][0]['loss']:.6f}")
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     torch.set_num_threads(8)
@@ -207,6 +258,8 @@ def main():
             run_model_golden(ref, name, c)
     if not only or 'multirank' in only:
         run_multirank_loss_golden()
+    if not only or 'ssl' in only:
+        run_ssl_loss_golden(ref)
 
 
 if __name__ == '__main__':

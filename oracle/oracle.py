@@ -241,6 +241,43 @@ def clip_loss(all_img: Tensor, all_txt: Tensor, logit_scale: Tensor) -> Dict[str
             'labels': labels, 'pred': pred}
 
 
+def ssl_scale_matrix(ind: Tensor, logit_scale: Tensor, logit_scale_pseudo: Tensor) -> Tensor:
+    """Per-pair temperature of SSLCLIPLoss (loss.py:160-166 / 172-178): with mask[i][j] = ind[i] + ind[j]
+    (gt_indicators: 1 = ground-truth narration, 0 = pseudo-label), scale = pseudo (mask 0),
+    sqrt(pseudo * real) (mask 1), real (mask 2)."""
+    mask = ind[:, None] + ind[None, :]
+    geo = torch.sqrt(logit_scale_pseudo * logit_scale)
+    one = torch.ones((), dtype=logit_scale.dtype)
+    return torch.where(mask == 0, logit_scale_pseudo * one, torch.where(mask == 1, geo * one, logit_scale * one))
+
+
+def ssl_clip_loss(all_img: Tensor, all_txt: Tensor, ind: Tensor, logit_scale: Tensor,
+                  logit_scale_pseudo: Tensor) -> Dict[str, Tensor]:
+    """SSLCLIPLoss.forward on the rank-ordered concatenation (loss.py:146-217): logits =
+    scale_matrix * (img @ txt^T), symmetric InfoNCE, accuracy split by indicator."""
+    li = ssl_scale_matrix(ind, logit_scale, logit_scale_pseudo) * (all_img @ all_txt.t())
+    G = li.shape[0]
+    labels = torch.arange(G, dtype=torch.long)
+    loss = (F.cross_entropy(li, labels) + F.cross_entropy(li.t(), labels)) / 2
+    pred = li.argmax(-1)
+    ok = pred == labels
+    gt, ps = ind == 1, ind == 0
+    return {'loss': loss, 'clip_loss': loss, 'clip_acc': 100.0 * ok.sum() / G,
+            'clip_acc_gt': 100.0 * ok[gt].sum() / gt.sum(), 'clip_acc_pseudo': 100.0 * ok[ps].sum() / ps.sum(),
+            'num_gt': gt.sum(), 'num_pseudo': ps.sum(), 'logits_per_image': li, 'pred': pred, 'labels': labels}
+
+
+def ssl_synthetic_inputs(G: int, E: int, seed: int):
+    """Seeded SSLCLIPLoss inputs shared by the golden generator and the tests: unit-norm image/text rows
+    (text correlated with its image), indicators ~Bernoulli(0.5) with both kinds forced present."""
+    g = torch.Generator().manual_seed(seed)
+    img = l2_normalize(torch.randn(G, E, generator=g))
+    txt = l2_normalize(torch.randn(G, E, generator=g) + 0.7 * img)
+    ind = (torch.rand(G, generator=g) < 0.5).long()
+    ind[0], ind[1] = 1, 0
+    return img, txt, ind
+
+
 # --------------------------------------------------------------------------------------
 # deterministic synthetic weights / inputs shared by the golden generator, tests and bench
 # --------------------------------------------------------------------------------------

@@ -59,3 +59,35 @@ def oracle_slab_backward(img_all, txt_all, lse_all, scale, upstream, coef, B, ro
         gi, gt = torch.autograd.grad(loss, [ia, ta])
     k = coef * upstream.reshape(()) * 2 * G
     return (k * gi[row0:row0 + B]).contiguous(), (k * gt[row0:row0 + B]).contiguous()
+
+
+def oracle_ssl_slab_forward(img_all, txt_all, ind_all, scales3, B, row0):
+    """CPU restatement of lvl_ssl_clip_loss_fwd: stats [2,B,8] = {lse, diag logit, E0, E1, E2, diag dot, max, 0}
+    with E_k = sum_j softmax_ij * dot_ij * [ind_i + ind_j == k]; argmax [2,B]."""
+    ind = ind_all.long()
+    bucket = ind[:, None] + ind[None, :]
+    dots = img_all.float() @ txt_all.float().t()
+    li = scales3.float()[bucket] * dots
+    idx = torch.arange(row0, row0 + B)
+    rows = torch.arange(B)
+    out = []
+    for L, D, Bk in ((li[row0:row0 + B], dots[row0:row0 + B], bucket[row0:row0 + B]),
+                     (li.t()[row0:row0 + B], dots.t()[row0:row0 + B], bucket.t()[row0:row0 + B])):
+        p = torch.softmax(L, -1)
+        ek = [(p * D * (Bk == k)).sum(-1) for k in range(3)]
+        out.append(torch.stack([torch.logsumexp(L, -1), L[rows, idx], ek[0], ek[1], ek[2], D[rows, idx],
+                                L.max(-1).values, torch.zeros(B)], -1))
+    slabs = torch.stack([li[row0:row0 + B], li.t()[row0:row0 + B]])
+    return torch.stack(out), slabs.argmax(-1).to(torch.int32)
+
+
+def oracle_ssl_slab_backward(img_all, txt_all, ind_all, lse_all, scales3, upstream, coef, B, row0):
+    """CPU restatement of lvl_ssl_clip_loss_bwd via autograd on oracle.ssl_clip_loss (scales3 = {pseudo, geo, real})."""
+    G = img_all.shape[0]
+    with torch.enable_grad():
+        ia = img_all.float().clone().requires_grad_(True)
+        ta = txt_all.float().clone().requires_grad_(True)
+        loss = O.ssl_clip_loss(ia, ta, ind_all.long(), scales3[2].float(), scales3[0].float())['loss']
+        gi, gt = torch.autograd.grad(loss, [ia, ta])
+    k = coef * upstream.reshape(()) * 2 * G
+    return (k * gi[row0:row0 + B]).contiguous(), (k * gt[row0:row0 + B]).contiguous()

@@ -80,3 +80,71 @@ def test_sharded_loss_matches_reference_multirank(world, use_vissl):
         exp_rows = torch.cat([torch.arange(Bl * 2, dtype=torch.float32).reshape(Bl, 2) + 100 * k for k in range(world)])
         assert torch.equal(torch.tensor(gx), exp_rows)
         assert torch.equal(torch.tensor(dx), torch.full((Bl, 2), float(sum(range(1, world + 1)))))
+
+
+def _ssl_worker(rank, world, port, fx, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    if world > 1:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    from helpers import oracle_ssl_slab_backward, oracle_ssl_slab_forward
+    from lavila.models.loss import SSLCLIPLoss
+    from oracle import oracle as O
+
+    class OracleBackedSSL(SSLCLIPLoss):        # kernel hooks -> CPU oracle (test-only)
+        def _slab_forward(self, *a):
+            return oracle_ssl_slab_forward(*a)
+
+        def _slab_backward(self, *a):
+            return oracle_ssl_slab_backward(*a)
+
+    Bl = fx['B_local']
+    img, txt, ind = O.ssl_synthetic_inputs(world * Bl, fx['E'], fx['seed'])
+    sl = slice(rank * Bl, (rank + 1) * Bl)
+    li, lt = img[sl].clone().requires_grad_(True), txt[sl].clone().requires_grad_(True)
+    scale = torch.tensor(fx['scale']).requires_grad_(True)
+    crit = OracleBackedSSL(use_vissl=world > 1, cache_labels=True, rank=rank, world_size=world,
+                           scale_init=fx['scale_init'])
+    out = crit({'image_embed': li, 'text_embed': lt, 'logit_scale': scale}, ind[sl].clone())
+    out['loss'].backward()
+    q.put((rank, {k: float(v) for k, v in out.items()}, li.grad.tolist(), lt.grad.tolist(), scale.grad.item(),
+           crit.logit_scale_pseudo.grad.item()))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [1, 2])
+def test_ssl_loss_matches_reference(world):
+    """SSLCLIPLoss exchange layer (fused [img|txt|ind] gather, LSE + partial-sum gather, scale gradients) against the
+    reference's own single-process and 2-rank vissl outputs (tests/golden/ssl_clip_loss.pt)."""
+    fx = load_golden('ssl_clip_loss.pt')
+    want = fx['single'] if world == 1 else fx['multi']
+    Bl = fx['single_G'] if world == 1 else fx['multi']['B_local']
+    light = {'seed': fx['seed'], 'E': fx['E'], 'scale': fx['scale'], 'scale_init': fx['scale_init'], 'B_local': Bl}
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ssl_worker, args=(r, world, 29760 + world, light, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    for r, (rank, out, dimg, dtxt, dscale, dpseudo) in enumerate(got):
+        wo = want['out'][r] if world > 1 else want['out']
+        for k in ('loss', 'clip_loss', 'clip_acc', 'clip_acc_gt', 'clip_acc_pseudo', 'num_gt', 'num_pseudo'):
+            assert abs(out[k] - wo[k]) < 1e-4, (k, out[k], wo[k])
+        assert abs(dscale - (want['dscale'][r] if world > 1 else want['dscale'])) < 1e-5
+        assert abs(dpseudo - (want['dpseudo_param'][r] if world > 1 else want['dpseudo_param'])) < 1e-5
+        torch.testing.assert_close(torch.tensor(dimg), want['dimg'][r * Bl:(r + 1) * Bl], atol=1e-6, rtol=1e-4)
+        torch.testing.assert_close(torch.tensor(dtxt), want['dtxt'][r * Bl:(r + 1) * Bl], atol=1e-6, rtol=1e-4)
+
+
+def test_ssl_loss_multirank_requires_vissl():
+    from lavila.models.loss import SSLCLIPLoss
+    crit = SSLCLIPLoss(use_vissl=False, world_size=2)
+    with pytest.raises(NotImplementedError):           # loss.py:167-168
+        crit({'image_embed': torch.zeros(2, 4), 'text_embed': torch.zeros(2, 4), 'logit_scale': torch.ones(())},
+             torch.ones(2, dtype=torch.long))

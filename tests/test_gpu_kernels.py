@@ -227,6 +227,53 @@ def test_clip_loss_slabs(dt, B, G, E, row0):
     torch.testing.assert_close(dtx.cpu(), dt_o, atol=2e-5, rtol=1e-3)
 
 
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('B,G,E,row0', [(4, 4, 64, 0), (3, 12, 32, 6), (32, 256, 256, 64), (5, 300, 8, 295)])
+def test_ssl_clip_loss_slabs(dt, B, G, E, row0):
+    """lvl_ssl_clip_loss_fwd/bwd (per-pair temperature InfoNCE, loss.py:121-217) against the oracle."""
+    from helpers import oracle_ssl_slab_backward, oracle_ssl_slab_forward
+    from lavila_amd import ops
+    img, txt, ind = O.ssl_synthetic_inputs(G, E, G + E)
+    img, txt = _r(img, dt), _r(txt, dt)
+    real, pseudo = torch.tensor(14.285714), torch.tensor(12.5)
+    scales3 = torch.stack([pseudo, torch.sqrt(pseudo * real), real])
+    li = O.ssl_scale_matrix(ind, real, pseudo) * (img @ txt.t())
+    lse_all = torch.stack([torch.logsumexp(li, 1), torch.logsumexp(li, 0)])
+    st_o, am_o = oracle_ssl_slab_forward(img, txt, ind, scales3, B, row0)
+    up = torch.tensor([0.7])
+    di_o, dt_o = oracle_ssl_slab_backward(img, txt, ind, lse_all, scales3, up, 3.0 / (2 * G), B, row0)
+    ig, tg, ing = img.to(DEV, dt), txt.to(DEV, dt), ind.to(DEV, torch.int32)
+    st, am, lg = ops.ssl_clip_loss_fwd_raw(ig, tg, ing, scales3.to(DEV), B, row0, want_logits=True)
+    want_logits = torch.stack([li[row0:row0 + B], li.t()[row0:row0 + B]])
+    torch.testing.assert_close(lg.cpu(), want_logits, atol=1e-4, rtol=1e-4)
+    torch.testing.assert_close(st.cpu()[..., :7], st_o[..., :7], atol=1e-4, rtol=1e-4)
+    assert torch.equal(am.cpu(), am_o)
+    di, dtx = ops.ssl_clip_loss_bwd_raw(ig, tg, ing, lse_all.to(DEV), scales3.to(DEV), up.to(DEV), 3.0 / (2 * G), B,
+                                        row0)
+    torch.testing.assert_close(di.cpu(), di_o, atol=2e-5, rtol=1e-3)
+    torch.testing.assert_close(dtx.cpu(), dt_o, atol=2e-5, rtol=1e-3)
+
+
+def test_ssl_clip_loss_module_matches_reference_golden():
+    """SSLCLIPLoss on the GPU through the C ABI against the reference's own outputs (tests/golden/ssl_clip_loss.pt)."""
+    from conftest import load_golden
+    from lavila.models.loss import SSLCLIPLoss
+    fx = load_golden('ssl_clip_loss.pt')
+    want = fx['single']
+    img, txt, ind = O.ssl_synthetic_inputs(fx['single_G'], fx['E'], fx['seed'])
+    li, lt = img.to(DEV).requires_grad_(True), txt.to(DEV).requires_grad_(True)
+    scale = torch.tensor(fx['scale'], device=DEV).requires_grad_(True)
+    crit = SSLCLIPLoss(scale_init=fx['scale_init']).to(DEV)
+    out = crit({'image_embed': li, 'text_embed': lt, 'logit_scale': scale}, ind)       # indicators arrive on the CPU
+    out['loss'].backward()
+    for k in ('loss', 'clip_loss', 'clip_acc', 'clip_acc_gt', 'clip_acc_pseudo', 'num_gt', 'num_pseudo'):
+        assert abs(float(out[k]) - want['out'][k]) < 1e-4, (k, float(out[k]), want['out'][k])
+    assert abs(scale.grad.item() - want['dscale']) < 1e-5
+    assert abs(crit.logit_scale_pseudo.grad.item() - want['dpseudo_param']) < 1e-5
+    torch.testing.assert_close(li.grad.cpu(), want['dimg'], atol=1e-6, rtol=1e-4)
+    torch.testing.assert_close(lt.grad.cpu(), want['dtxt'], atol=1e-6, rtol=1e-4)
+
+
 def test_kernel_argument_errors_are_loud():
     from lavila_amd import ops
     from lavila_amd._cabi import HipExtensionError

@@ -68,3 +68,29 @@ def test_multirank_loss_equals_single_process_on_concatenation():
         mult = world if use_vissl else 1
         torch.testing.assert_close(r['dimg'], mult * img.grad, atol=1e-6, rtol=1e-5)
         torch.testing.assert_close(r['dtxt'], mult * txt.grad, atol=1e-6, rtol=1e-5)
+
+
+def test_ssl_clip_loss_matches_reference():
+    """SSLCLIPLoss (loss.py:121-217): single process and the 2-rank vissl run (every rank = loss on the
+    rank-ordered concatenation; local grads = W x the global-loss slice; scale grads = full derivative)."""
+    import math
+    fx = load_golden('ssl_clip_loss.pt')
+    for G, want, mult in ((fx['single_G'], fx['single'], 1), (fx['multi']['world'] * fx['multi']['B_local'], fx['multi'], fx['multi']['world'])):
+        img, txt, ind = O.ssl_synthetic_inputs(G, fx['E'], fx['seed'])
+        img.requires_grad_(True), txt.requires_grad_(True)
+        scale = torch.tensor(fx['scale']).requires_grad_(True)
+        pparam = torch.tensor(math.log(1 / fx['scale_init'])).requires_grad_(True)
+        ld = O.ssl_clip_loss(img, txt, ind, scale, pparam.exp())
+        ld['loss'].backward()
+        outs = want['out'] if isinstance(want['out'], list) else [want['out']]
+        for o in outs:
+            for k in ('loss', 'clip_acc', 'clip_acc_gt', 'clip_acc_pseudo', 'num_gt', 'num_pseudo'):
+                assert abs(o[k] - float(ld[k])) < 1e-4, (k, o[k], float(ld[k]))
+        torch.testing.assert_close(want['dimg'], mult * img.grad, atol=1e-6, rtol=1e-5)
+        torch.testing.assert_close(want['dtxt'], mult * txt.grad, atol=1e-6, rtol=1e-5)
+        ds = want['dscale'] if isinstance(want['dscale'], list) else [want['dscale']]
+        dp = want['dpseudo_param'] if isinstance(want['dpseudo_param'], list) else [want['dpseudo_param']]
+        for a in ds:
+            assert abs(a - scale.grad.item()) < 1e-6
+        for a in dp:
+            assert abs(a - pparam.grad.item()) < 1e-6
