@@ -95,7 +95,8 @@ template <> struct Elem<bf16_t> {
   }
 };
 
-// W consecutive elements (W = 4 or 8)
+// W consecutive elements (W = 4 or 8). `Raw` is the packed register image of one vector: loads can be issued rows
+// ahead (software prefetch) at half the register cost of unpacked f32 for bf16.
 template <typename T, int W> struct VecIO;
 template <typename T> struct VecIO<T, 8> {
   static __device__ __forceinline__ void load(const T* p, float (&v)[8]) { Elem<T>::load8(p, v); }
@@ -106,20 +107,73 @@ template <typename T> struct VecIO<T, 4> {
   static __device__ __forceinline__ void store(T* p, const float (&v)[4]) { Elem<T>::store4(p, v); }
 };
 
+template <typename T, int W> struct RawVec;
+template <int W> struct RawVec<float, W> {
+  float w[W];
+  __device__ __forceinline__ void load(const float* p) {
+#pragma unroll
+    for (int k = 0; k < W; k += 4) {
+      const float4 a = *reinterpret_cast<const float4*>(p + k);
+      w[k] = a.x; w[k + 1] = a.y; w[k + 2] = a.z; w[k + 3] = a.w;
+    }
+  }
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int k = 0; k < W; ++k) w[k] = 0.f;
+  }
+  __device__ __forceinline__ void unpack(float (&v)[W]) const {
+#pragma unroll
+    for (int k = 0; k < W; ++k) v[k] = w[k];
+  }
+};
+template <> struct RawVec<bf16_t, 4> {
+  uint2 w;
+  __device__ __forceinline__ void load(const bf16_t* p) { w = *reinterpret_cast<const uint2*>(p); }
+  __device__ __forceinline__ void zero() { w = make_uint2(0, 0); }
+  __device__ __forceinline__ void unpack(float (&v)[4]) const {
+    v[0] = __uint_as_float(w.x << 16); v[1] = __uint_as_float(w.x & 0xffff0000u);
+    v[2] = __uint_as_float(w.y << 16); v[3] = __uint_as_float(w.y & 0xffff0000u);
+  }
+};
+template <> struct RawVec<bf16_t, 8> {
+  uint4 w;
+  __device__ __forceinline__ void load(const bf16_t* p) { w = *reinterpret_cast<const uint4*>(p); }
+  __device__ __forceinline__ void zero() { w = make_uint4(0, 0, 0, 0); }
+  __device__ __forceinline__ void unpack(float (&v)[8]) const {
+    v[0] = __uint_as_float(w.x << 16); v[1] = __uint_as_float(w.x & 0xffff0000u);
+    v[2] = __uint_as_float(w.y << 16); v[3] = __uint_as_float(w.y & 0xffff0000u);
+    v[4] = __uint_as_float(w.z << 16); v[5] = __uint_as_float(w.z & 0xffff0000u);
+    v[6] = __uint_as_float(w.w << 16); v[7] = __uint_as_float(w.w & 0xffff0000u);
+  }
+};
+
 __device__ __forceinline__ void load8_f32(const float* p, float (&v)[8]) { Elem<float>::load8(p, v); }
 
 // ---------------------------------------------------------------------------------------------
-// wave-level (64-lane) reductions; every lane receives the result
+// wave-level (64-lane) reductions; every lane receives the result.
+// DPP within the 16-lane rows (quad xor 1, xor 2, half-mirror, mirror: 4 VALU ops, no LDS crossbar), then the four
+// row results travel through SGPRs (v_readlane). ~10 issue slots instead of 6 dependent ds_bpermute round trips.
 // ---------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float read_lane(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_move<0xB1>(v);     // quad_perm [1,0,3,2]
+  v += dpp_move<0x4E>(v);     // quad_perm [2,3,0,1]
+  v += dpp_move<0x141>(v);    // row_half_mirror
+  v += dpp_move<0x140>(v);    // row_mirror
+  return (read_lane(v, 0) + read_lane(v, 16)) + (read_lane(v, 32) + read_lane(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, dpp_move<0xB1>(v));
+  v = fmaxf(v, dpp_move<0x4E>(v));
+  v = fmaxf(v, dpp_move<0x141>(v));
+  v = fmaxf(v, dpp_move<0x140>(v));
+  return fmaxf(fmaxf(read_lane(v, 0), read_lane(v, 16)), fmaxf(read_lane(v, 32), read_lane(v, 48)));
 }
 
 // dispatch on the runtime dtype tag

@@ -7,13 +7,15 @@ int lvl_launch_column_reduce(const float* part, int nparts, int width, int seg, 
 
 namespace {
 
-constexpr int kGeluBwdRowBlocks = 256;   // partial dbias slabs
+constexpr int kGeluBwdRowBlocks = 1024;   // partial dbias slabs
+constexpr int kGeluUnroll = 4;            // rows in flight per thread (all loads issued before the math)
 
-__device__ __forceinline__ float sigmoidf_fast(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float sigmoidf_fast(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 // ---- a = (u+b) * sigmoid(1.702 (u+b)) -----------------------------------------------------------
 // 2-D mapping: thread owns one 8-wide vector column, walks rows with stride gridDim.y, so the bias
-// vector is loaded once and (in bwd) the per-column dbias partial stays in registers.
+// vector is loaded once and (in bwd) the per-column dbias partial stays in registers. kGeluUnroll rows are
+// loaded back-to-back before any arithmetic: 4-8 outstanding 16-B loads per lane keep HBM busy.
 template <typename T>
 __global__ __launch_bounds__(128) void bias_gelu_fwd_kernel(const T* __restrict__ u, const float* __restrict__ bias,
                                                             T* __restrict__ a, int64_t rows, int cols) {
@@ -21,7 +23,24 @@ __global__ __launch_bounds__(128) void bias_gelu_fwd_kernel(const T* __restrict_
   if (vc * 8 >= cols) return;
   float b[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (bias) load8_f32(bias + vc * 8, b);
-  for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
+  const int64_t stride = gridDim.y;
+  int64_t r = blockIdx.y;
+  for (; r + (kGeluUnroll - 1) * stride < rows; r += kGeluUnroll * stride) {
+    float x[kGeluUnroll][8];
+#pragma unroll
+    for (int k = 0; k < kGeluUnroll; ++k) Elem<T>::load8(u + (r + k * stride) * cols + vc * 8, x[k]);
+#pragma unroll
+    for (int k = 0; k < kGeluUnroll; ++k) {
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float y = x[k][j] + b[j];
+        o[j] = y * sigmoidf_fast(1.702f * y);
+      }
+      Elem<T>::store8(a + (r + k * stride) * cols + vc * 8, o);
+    }
+  }
+  for (; r < rows; r += stride) {
     float x[8], o[8];
     Elem<T>::load8(u + r * cols + vc * 8, x);
 #pragma unroll
@@ -42,10 +61,8 @@ __global__ __launch_bounds__(128) void bias_gelu_bwd_kernel(const T* __restrict_
   if (vc * 8 >= cols) return;
   float b[8] = {0, 0, 0, 0, 0, 0, 0, 0}, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (bias) load8_f32(bias + vc * 8, b);
-  for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
-    float x[8], g[8], o[8];
-    Elem<T>::load8(u + r * cols + vc * 8, x);
-    Elem<T>::load8(da + r * cols + vc * 8, g);
+  auto one_row = [&](const float (&x)[8], const float (&g)[8], int64_t r) {
+    float o[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float y = x[j] + b[j];
@@ -54,6 +71,24 @@ __global__ __launch_bounds__(128) void bias_gelu_bwd_kernel(const T* __restrict_
       acc[j] += Elem<T>::round(o[j]);      // dbias sums what the weight-grad GEMM will see
     }
     Elem<T>::store8(du + r * cols + vc * 8, o);
+  };
+  const int64_t stride = gridDim.y;
+  int64_t r = blockIdx.y;
+  for (; r + (kGeluUnroll - 1) * stride < rows; r += kGeluUnroll * stride) {
+    float x[kGeluUnroll][8], g[kGeluUnroll][8];
+#pragma unroll
+    for (int k = 0; k < kGeluUnroll; ++k) {
+      Elem<T>::load8(u + (r + k * stride) * cols + vc * 8, x[k]);
+      Elem<T>::load8(da + (r + k * stride) * cols + vc * 8, g[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < kGeluUnroll; ++k) one_row(x[k], g[k], r + k * stride);
+  }
+  for (; r < rows; r += stride) {
+    float x[8], g[8];
+    Elem<T>::load8(u + r * cols + vc * 8, x);
+    Elem<T>::load8(da + r * cols + vc * 8, g);
+    one_row(x, g, r);
   }
   if (part) {
 #pragma unroll

@@ -11,7 +11,7 @@
 namespace {
 
 constexpr int kRowsPerBlock = 4;          // 4 waves per 256-thread workgroup
-constexpr int kLnBwdParts = 1024;         // partial dgamma/dbeta/dxsum slabs (one per workgroup)
+constexpr int kLnBwdParts = 768;          // partial dgamma/dbeta/dxsum slabs (one per workgroup)
 
 template <int W>
 __device__ __forceinline__ void load_f32(const float* p, float (&v)[W]) { VecIO<float, W>::load(p, v); }
@@ -36,6 +36,23 @@ __device__ __forceinline__ void load_sum(const T* __restrict__ x, const T* __res
 }
 
 template <typename T, int VPL, int W>
+struct LnFwdRow {
+  RawVec<T, W> x[VPL], x2[VPL];
+  __device__ __forceinline__ void load(const T* __restrict__ px, const T* __restrict__ px2, int64_t row, int cols,
+                                       int lane, int nvec) {
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int c = lane + i * 64;
+      if (c < nvec) {
+        x[i].load(px + row * cols + c * W);
+        if (px2 != nullptr) x2[i].load(px2 + row * cols + c * W);
+      }
+    }
+  }
+};
+
+// software-pipelined like the backward: the next row's packed operands are requested before this row is reduced
+template <typename T, int VPL, int W>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(
     const T* __restrict__ x, const T* __restrict__ x2, const float* __restrict__ bias,
     const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ s_out,
@@ -44,15 +61,31 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nvec = cols / W;
   const float inv_cols = 1.0f / (float)cols;
-  for (int64_t row = (int64_t)blockIdx.x * kRowsPerBlock + wave; row < rows;
-       row += (int64_t)gridDim.x * kRowsPerBlock) {
+  const int64_t stride = (int64_t)gridDim.x * kRowsPerBlock;
+  int64_t row = (int64_t)blockIdx.x * kRowsPerBlock + wave;
+  LnFwdRow<T, VPL, W> cur, nxt;
+  if (row < rows) cur.load(x, x2, row, cols, lane, nvec);
+  for (; row < rows; row += stride) {
+    if (row + stride < rows) nxt.load(x, x2, row + stride, cols, lane, nvec);
     float v[VPL][W];
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
       const int c = lane + i * 64;
       if (c < nvec) {
-        load_sum<T, W>(x, x2, bias, row * cols + c * W, c * W, v[i]);
+        cur.x[i].unpack(v[i]);
+        if (x2 != nullptr) {
+          float w[W];
+          cur.x2[i].unpack(w);
+#pragma unroll
+          for (int j = 0; j < W; ++j) v[i][j] += w[j];
+        }
+        if (bias != nullptr) {
+          float bb[W];
+          load_f32<W>(bias + c * W, bb);
+#pragma unroll
+          for (int j = 0; j < W; ++j) v[i][j] += bb[j];
+        }
         if (s_out != nullptr) {
           // the sum is what downstream residuals read: round it once, then normalise the rounded value
           VecIO<T, W>::store(s_out + row * cols + c * W, v[i]);
@@ -89,13 +122,41 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(
       if (mean) mean[row] = mu;
       if (rstd) rstd[row] = rs;
     }
+    cur = nxt;
   }
 }
 
 // dx = rstd * (dy*g - mean(dy*g) - shat * mean(dy*g*shat)) (+ dadd);
 // per-workgroup partial slabs [3][cols] = {sum dy*shat, sum dy, sum dx}
+// The row loop is software-pipelined: the packed operands of the NEXT row (and its mean/rstd) are requested before
+// the current row is reduced, so each wave keeps two rows of loads in flight (4 waves/SIMD would otherwise leave
+// HBM idle during the two cross-lane reductions).
 template <typename T, int VPL, int W>
-__global__ __launch_bounds__(256, (VPL * W <= 12 ? 4 : 1)) void ln_bwd_kernel(
+struct LnBwdRow {
+  RawVec<T, W> dy[VPL], x[VPL], x2[VPL], dadd[VPL];
+  float mu, rs;
+  __device__ __forceinline__ void load(const T* __restrict__ pdy, const T* __restrict__ px,
+                                       const T* __restrict__ px2, const T* __restrict__ pdadd,
+                                       const float* __restrict__ mean, const float* __restrict__ rstd, int64_t row,
+                                       int cols, int lane, int nvec) {
+    mu = mean[row];
+    rs = rstd[row];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int c = lane + i * 64;
+      if (c < nvec) {
+        const int64_t off = row * cols + c * W;
+        dy[i].load(pdy + off);
+        x[i].load(px + off);
+        if (px2 != nullptr) x2[i].load(px2 + off);
+        if (pdadd != nullptr) dadd[i].load(pdadd + off);
+      }
+    }
+  }
+};
+
+template <typename T, int VPL, int W>
+__global__ __launch_bounds__(256, (VPL * W <= 12 ? (sizeof(T) == 2 ? 3 : 2) : 1)) void ln_bwd_kernel(
     const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ x2,
     const float* __restrict__ bias, const float* __restrict__ gamma, const float* __restrict__ mean,
     const float* __restrict__ rstd, const T* __restrict__ dadd, T* __restrict__ dx,
@@ -112,25 +173,53 @@ __global__ __launch_bounds__(256, (VPL * W <= 12 ? 4 : 1)) void ln_bwd_kernel(
     for (int j = 0; j < W; ++j) { ag[i][j] = 0.f; ab[i][j] = 0.f; ax[i][j] = 0.f; g[i][j] = 0.f; }
     if (c < nvec) load_f32<W>(gamma + c * W, g[i]);
   }
-  for (int64_t row = (int64_t)blockIdx.x * kRowsPerBlock + wave; row < rows;
-       row += (int64_t)gridDim.x * kRowsPerBlock) {
-    const float mu = mean[row], rs = rstd[row];
-    float xh[VPL][W], dg[VPL][W];
+  float bb[VPL][W];     // residual-branch bias (recompute variant only)
+  if (bias != nullptr) {
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int c = lane + i * 64;
+#pragma unroll
+      for (int j = 0; j < W; ++j) bb[i][j] = 0.f;
+      if (c < nvec) load_f32<W>(bias + c * W, bb[i]);
+    }
+  }
+  const int64_t stride = (int64_t)gridDim.x * kRowsPerBlock;
+  int64_t row = (int64_t)blockIdx.x * kRowsPerBlock + wave;
+  LnBwdRow<T, VPL, W> cur, nxt;
+  if (row < rows) cur.load(dy, x, x2, dadd, mean, rstd, row, cols, lane, nvec);
+  for (; row < rows; row += stride) {
+    if (row + stride < rows) nxt.load(dy, x, x2, dadd, mean, rstd, row + stride, cols, lane, nvec);
+    const float mu = cur.mu, rs = cur.rs;
+    // normalised input of vector i, rebuilt from the packed operands (cheaper than holding it across the reduction)
+    auto xhat = [&](int i, int c, float (&xh)[W]) {
+      cur.x[i].unpack(xh);
+      if (x2 != nullptr) {
+        float w[W];
+        cur.x2[i].unpack(w);
+#pragma unroll
+        for (int j = 0; j < W; ++j) xh[j] += w[j];
+      }
+      if (bias != nullptr) {
+#pragma unroll
+        for (int j = 0; j < W; ++j) xh[j] += bb[i][j];
+      }
+#pragma unroll
+      for (int j = 0; j < W; ++j) xh[j] = (xh[j] - mu) * rs;
+    };
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
       const int c = lane + i * 64;
       if (c < nvec) {
-        float xv[W], dv[W];
-        load_sum<T, W>(x, x2, bias, row * cols + c * W, c * W, xv);
-        VecIO<T, W>::load(dy + row * cols + c * W, dv);
+        float xh[W], dv[W];
+        xhat(i, c, xh);
+        cur.dy[i].unpack(dv);
 #pragma unroll
         for (int j = 0; j < W; ++j) {
-          xh[i][j] = (xv[j] - mu) * rs;
-          dg[i][j] = dv[j] * g[i][j];
-          s1 += dg[i][j];
-          s2 += dg[i][j] * xh[i][j];
-          ag[i][j] += dv[j] * xh[i][j];
+          const float dgj = dv[j] * g[i][j];
+          s1 += dgj;
+          s2 += dgj * xh[j];
+          ag[i][j] += dv[j] * xh[j];
           ab[i][j] += dv[j];
         }
       }
@@ -140,12 +229,14 @@ __global__ __launch_bounds__(256, (VPL * W <= 12 ? 4 : 1)) void ln_bwd_kernel(
     for (int i = 0; i < VPL; ++i) {
       const int c = lane + i * 64;
       if (c < nvec) {
-        float o[W];
+        float xh[W], dv[W], o[W];
+        xhat(i, c, xh);
+        cur.dy[i].unpack(dv);
 #pragma unroll
-        for (int j = 0; j < W; ++j) o[j] = rs * (dg[i][j] - c1 - xh[i][j] * c2);
+        for (int j = 0; j < W; ++j) o[j] = rs * (dv[j] * g[i][j] - c1 - xh[j] * c2);
         if (dadd != nullptr) {
           float e[W];
-          VecIO<T, W>::load(dadd + row * cols + c * W, e);
+          cur.dadd[i].unpack(e);
 #pragma unroll
           for (int j = 0; j < W; ++j) o[j] += e[j];
         }
@@ -154,6 +245,7 @@ __global__ __launch_bounds__(256, (VPL * W <= 12 ? 4 : 1)) void ln_bwd_kernel(
         VecIO<T, W>::store(dx + row * cols + c * W, o);
       }
     }
+    cur = nxt;
   }
   // combine the 4 waves of this workgroup, then one partial slab per workgroup
   if (wave > 0) {
@@ -264,7 +356,7 @@ extern "C" int lvl_layernorm_fwd(const void* x, const void* x2, const float* xbi
               "layernorm_fwd: pointers must be 16-byte aligned");
   if (rows == 0) return LVL_OK;
   int64_t blocks = (rows + kRowsPerBlock - 1) / kRowsPerBlock;
-  if (blocks > 8192) blocks = 8192;
+  if (blocks > 3072) blocks = 3072;     // 2 x the resident workgroups at 6 waves/SIMD: long per-wave row chains
 #define LN_FWD_T(TT, VPL, W)                                                                                  \
   hipLaunchKernelGGL((ln_fwd_kernel<TT, VPL, W>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,   \
                      (const TT*)x, (const TT*)x2, xbias, gamma, beta, (TT*)s_out, (TT*)y, mean, rstd, rows, cols, eps)
