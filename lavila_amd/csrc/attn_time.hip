@@ -54,13 +54,14 @@ __device__ __forceinline__ float dotp(const float (&a)[DPL], const typename Vec<
   return s;
 }
 
-// sum over the 64/DPL lanes of one problem
+// sum over the 64/DPL lanes of one problem (an aligned 8- or 16-lane group inside a DPP row): quad xor 1, xor 2,
+// half-mirror, mirror -- plain VALU DPP operands, no LDS crossbar round trips
 template <int DPL>
 __device__ __forceinline__ float group_sum(float v) {
-  v += __shfl_xor(v, 1, 64);
-  v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 4, 64);
-  if (DPL == 4) v += __shfl_xor(v, 8, 64);
+  v += dpp_move<0xB1>(v);
+  v += dpp_move<0x4E>(v);
+  v += dpp_move<0x141>(v);
+  if (DPL == 4) v += dpp_move<0x140>(v);
   return v;
 }
 
@@ -191,7 +192,8 @@ __global__ __launch_bounds__(256, (F <= 4 ? 4 : 2)) void time_fwd_kernel(const u
 
 // ---- backward ------------------------------------------------------------------------------------------------
 // Everything of a (b, n, h) problem is thread-group local: the softmax is recomputed from the F+1 keys in
-// registers (no saved statistics needed), dq/dk/dv rows of the patch tokens are written exactly once.
+// registers (no saved statistics needed, and delta = sum_j P dP needs no O rows: `out` is only read for the cls
+// row), dq/dk/dv rows of the patch tokens are written exactly once. HBM: 5 row reads + 3 row writes per token.
 template <int F, int DPL>
 __global__ __launch_bounds__(256, (F <= 2 ? 4 : (F <= 4 ? 3 : 2))) void time_bwd_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out,
                                                        const uint16_t* __restrict__ dout, const float* __restrict__ lse,
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(256, (F <= 2 ? 4 : (F <= 4 ? 3 : 2))) void time_bwd
   const int n_end = min(N, (chunk + 1) * NCH);
 #pragma unroll 1
   for (int n = chunk * NCH + n_sub; n < n_end; n += NPB) {
-    vec_t kk[F], vv[F], qq[F], gg[F], yy[F];
+    vec_t kk[F], vv[F], qq[F], gg[F];
 #pragma unroll
     for (int f = 0; f < F; ++f) {
       const int tok = 1 + f * N + n;
@@ -253,14 +255,6 @@ __global__ __launch_bounds__(256, (F <= 2 ? 4 : (F <= 4 ? 3 : 2))) void time_bwd
       kk[f] = *reinterpret_cast<const vec_t*>(p + D);
       vv[f] = *reinterpret_cast<const vec_t*>(p + 2 * D);
       gg[f] = *reinterpret_cast<const vec_t*>(dobase + (size_t)tok * D);
-      yy[f] = *reinterpret_cast<const vec_t*>(obase + (size_t)tok * D);
-    }
-    float dlts[F];        // delta_q = dO_q . O_q, reduced right away so that the O rows can be dropped
-#pragma unroll
-    for (int f = 0; f < F; ++f) {
-      float a[DPL];
-      V::unpack(gg[f], a);
-      dlts[f] = group_sum<DPL>(dotp<DPL>(a, yy[f]));
     }
     float dk[F][DPL], dv[F][DPL];
     // CLS-row terms for this location's F keys
@@ -289,7 +283,6 @@ __global__ __launch_bounds__(256, (F <= 2 ? 4 : (F <= 4 ? 3 : 2))) void time_bwd
       float q[DPL], go[DPL];
       V::unpack(qq[fq], q);
       V::unpack(gg[fq], go);
-      const float dlt = dlts[fq];
       float s[F + 1], dp[F + 1];
       {
         float a = 0.f, d = 0.f;
@@ -309,6 +302,11 @@ __global__ __launch_bounds__(256, (F <= 2 ? 4 : (F <= 4 ? 3 : 2))) void time_bwd
 #pragma unroll
       for (int j = 0; j <= F; ++j) { s[j] = __builtin_amdgcn_exp2f(s[j] - mx); l += s[j]; }
       const float linv = __builtin_amdgcn_rcpf(l);
+      // delta_q = dO_q . O_q = sum_j P_qj dP_qj: all F+1 keys are in registers, the O rows are never read
+      float dlt = 0.f;
+#pragma unroll
+      for (int j = 0; j <= F; ++j) dlt = fmaf(s[j], dp[j], dlt);
+      dlt *= linv;
       float dq[DPL];
       {
         const float p = s[0] * linv, ds = p * (dp[0] - dlt) * 0.125f;

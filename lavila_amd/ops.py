@@ -5,6 +5,7 @@ Each `*_raw` function is a 1:1 call of one C entry point on torch device tensors
 reference's training loop (loss.backward(), DDP hooks, AdamW) works unchanged. Parameters
 (gamma/beta/bias/embeddings) are always passed to the kernels as float32.
 """
+import os
 from typing import Optional
 
 import torch
@@ -21,6 +22,9 @@ def _f32(p: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     return p.contiguous()
 
 
+_DGRAD_TN = os.environ.get('LAVILA_DGRAD_TN', '1') != '0'
+
+
 def _rows_cols(x: torch.Tensor):
     cols = x.shape[-1]
     return x.numel() // cols, cols
@@ -32,7 +36,7 @@ def _rows_cols(x: torch.Tensor):
 class _LinearFn(torch.autograd.Function):
     """y = x W^T (+ b) for token-major activations [rows, in] with rows ~ 2e5.
 
-    Forward and input-gradient are plain library GEMMs. The weight gradient dW[out,in] = dY^T X contracts over
+    Forward and input-gradient are plain library GEMMs (the input gradient against a transposed weight copy). The weight gradient dW[out,in] = dY^T X contracts over
     the ~2e5 rows and writes a tiny output (9..36 tiles of 256x256): the library's stream-K kernels reach only
     0.3-0.9 PF/s there. Splitting the rows into S batches (one bmm, S x more output tiles, all 256 CUs busy)
     and summing the S partial products in f32 measured 1.3-2.3x faster on MI355X (tools/probe_wgrad.py) with the
@@ -54,7 +58,14 @@ class _LinearFn(torch.autograd.Function):
         with torch.autocast('cuda', enabled=False):
             dy2 = dy.reshape(-1, dy.shape[-1])
             x2 = x.reshape(-1, x.shape[-1])
-            dx = (dy2 @ w).reshape(x.shape) if ctx.needs_input_grad[0] else None
+            dx = None
+            if ctx.needs_input_grad[0]:
+                if _DGRAD_TN and dy2.shape[0] >= 32768:
+                    # both operands contraction-contiguous ("TN", the layout of the forward GEMM): 8-18 % faster than
+                    # dy @ W on MI355X (tools/probe_gemm_layouts.py); the transposed weight copy is ~10 us
+                    dx = torch.nn.functional.linear(dy2, w.t().contiguous()).reshape(x.shape)
+                else:
+                    dx = (dy2 @ w).reshape(x.shape)
             dw = None
             if ctx.needs_input_grad[1]:
                 rows, n_out, n_in = dy2.shape[0], dy2.shape[1], x2.shape[1]
@@ -62,7 +73,7 @@ class _LinearFn(torch.autograd.Function):
                 if rows >= 32768 and rows % split == 0 and dy2.is_contiguous() and x2.is_contiguous():
                     part = torch.bmm(dy2.view(split, rows // split, n_out).transpose(1, 2),
                                      x2.view(split, rows // split, n_in))
-                    dw = part.float().sum(0).to(wdt)
+                    dw = part.sum(0, dtype=torch.float32).to(wdt)
                 else:
                     dw = (dy2.t() @ x2).to(wdt)
             db = dy2.sum(0).to(bdt) if (bdt is not None and ctx.needs_input_grad[2]) else None
