@@ -147,6 +147,15 @@ int lvl_ssl_clip_loss_bwd(const void* img_all, const void* txt_all, const int32_
                           int B, int G, int E, int row0, float* dimg, float* dtxt, int dtype,
                           void* stream);
 
+/* ---- Linear-layer weight gradient ------------------------------------------------------------------------
+ * dW[N,K] = dY[M,N]^T X[M,K], dbias[N] (nullable) = column sums of dY: what torch.autograd computes for the weight
+ * and bias of every nn.Linear on the path (qkv/proj: timesformer.py:96-99, Mlp fc1/fc2: timesformer.py:47-50) when
+ * `loss.backward()` runs (main_pretrain.py:520). dy: [M,N], x: [M,K] bf16 row-major; dw: [N,K] f32; dbias: [N] f32.
+ * Tiled for N, K multiples of 192/288/384 (TSF-B/L widths); other shapes return LVL_ENOSYS and the caller keeps
+ * the library GEMM. Workspace: lvl_workspace_floats("linear_wgrad", N, K) floats (-1 = unsupported shape). */
+int lvl_linear_wgrad(const void* dy, const void* x, float* dw, float* dbias, float* ws, int64_t M, int N, int K,
+                     int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,341 @@
+// Weight gradient of the token-major Linear layers: dW[N,K] = dY[M,N]^T X[M,K] (+ dbias[N] = column sums of dY),
+// bf16 operands, f32 accumulation, gfx950 MFMA.
+//
+// Shape of the problem on this path: M = B*T ~ 2e5 rows, N,K in {768, 2304, 3072}: a tiny output contracted over
+// a huge row count, with BOTH operands stored row-major over the contraction index (the layout a library GEMM
+// likes least: every MFMA fragment needs a transpose). Here:
+//   * the output is cut into tiles of (96*WN) x (96*WK), the rows into S splits; one workgroup (WN*WK waves, each
+//     owning a 96x96 block = 6x6 MFMA tiles in registers) per (tile, split), all of them resident at once;
+//   * blockIdx -> (split, tile) is XCD-aware: workgroup i runs on XCD i%8, and XCD x is given a contiguous range
+//     of the split-major (split, tile) pairs, so the ~32 workgroups of an XCD stream the SAME dY/X rows through
+//     that XCD's L2 (each row is fetched from HBM about once instead of once per tile);
+//   * rows are staged 32 at a time as row-major LDS images (row stride padded by 32 B -> an odd number of 32-B
+//     bank groups, conflict-free for the reads below; SQ_LDS_BANK_CONFLICT = 0) by LDS-DMA
+//     (global_load_lds_dwordx4, no VGPR round trip) into a 4-deep ring: fills run 2-3 steps ahead, one bare
+//     s_barrier per step placed mid-step so that neither fill nor LDS latency separates two steps' MFMAs;
+//   * both MFMA operands are read with ds_read_b64_tr_b16 (the gfx950 LDS transpose read): lane c of a 16-lane
+//     group receives 4 consecutive ROWS at column c, two reads give the 8 contraction elements of a
+//     v_mfma_f32_16x16x32_bf16 operand. A and B use the same row permutation, so no data is ever transposed;
+//   * dbias rides along: v_dot2_f32_bf16 of the A fragments with (1,1).
+// Partial tiles [S,N,K] f32 are reduced by wgrad_reduce_kernel (deterministic, no atomics).
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 wg_bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 wg_bf16x2;
+typedef __attribute__((ext_vector_type(4))) float wg_f32x4;
+typedef __attribute__((ext_vector_type(4))) short wg_s16x4;
+
+namespace {
+
+constexpr int MS = 32;          // rows per step (one MFMA contraction)
+constexpr int WT = 6;           // wave tile: WT x WT MFMA tiles (96 x 96)
+
+__device__ __forceinline__ uint2 tr_read(const uint16_t* p) {
+  const wg_s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wg_s16x4*)p);
+  return __builtin_bit_cast(uint2, v);
+}
+__device__ __forceinline__ wg_f32x4 mfma16(uint4 a, uint4 b, wg_f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(wg_bf16x8, a), __builtin_bit_cast(wg_bf16x8, b),
+                                                 c, 0, 0, 0);
+}
+
+template <int WN, int WK>
+struct Geo {
+  static constexpr int NW = WN * WK, NT = 64 * NW;
+  static constexpr int TN = 96 * WN, TK = 96 * WK;
+  static constexpr int SA = TN + 16, SB = TK + 16;            // image row strides in elements (+32 B)
+  // LDS-DMA plan: one global_load_lds_dwordx4 fills 64 consecutive 16-B chunks (1 KiB) of a stage. An image of
+  // MS rows x (stride/8) chunks is exactly IA (IB) such fills; the pad chunks of a row carry don't-care data.
+  static constexpr int IA = MS * (SA / 8) / 64, IB = MS * (SB / 8) / 64;      // = 6*WN + 1, 6*WK + 1
+  static constexpr int NI = (IA + IB + NW - 1) / NW;                          // fills per wave per step
+  static constexpr int STAGE = MS * (SA + SB) + (NI * NW - IA - IB) * 512;    // elements per stage (+ dump area)
+  static constexpr int NSTAGE = (4 * STAGE * 2 <= 160 * 1024) ? 4 : 3;   // ring depth: fills run NSTAGE-1 steps ahead
+  static_assert(MS * (SA / 8) % 64 == 0 && MS * (SB / 8) % 64 == 0, "images must be whole 1-KiB fills");
+};
+
+template <int WN, int WK, bool BIAS>
+__global__ __launch_bounds__(64 * WN * WK) void wgrad_kernel(const uint16_t* __restrict__ dy,
+                                                             const uint16_t* __restrict__ x, float* __restrict__ part,
+                                                             float* __restrict__ bpart, int64_t M, int N, int K,
+                                                             int tiles_k, int ntiles, int S) {
+  using G = Geo<WN, WK>;
+  extern __shared__ __attribute__((aligned(16))) uint16_t smem[];     // [NSTAGE][A image | B image | dump]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave % WN, wk = wave / WN;
+  // XCD-aware decode: consecutive block ids alternate XCDs, so XCD x = bid % 8 is given the contiguous range
+  // [x*P/8, (x+1)*P/8) of the split-major (split, tile) pairs, P = ntiles*S: the workgroups that stream the same
+  // rows sit behind the same L2
+  const int bid = blockIdx.x;
+  const int pair = (bid & 7) * ((ntiles * S) >> 3) + (bid >> 3);
+  const int split = pair / ntiles, tile = pair % ntiles;
+  const int n0 = (tile / tiles_k) * G::TN, k0 = (tile % tiles_k) * G::TK;
+  const int64_t steps_total = M / MS;      // full row blocks; the < 32 tail rows are added by wgrad_reduce_kernel
+  const int64_t s_begin = steps_total * split / S, s_end = steps_total * (split + 1) / S;
+  const int nsteps = (int)(s_end - s_begin);
+
+  // ---- staging plan (LDS-DMA, no VGPR round trip) ---------------------------------------------------------------
+  // Fill f (0 .. NI*NW-1) of a step is issued by wave f % NW; lane l of the fill lands at stage byte f*1024 + l*16.
+  // Fills 0..IA-1 tile the A image, IA..IA+IB-1 the B image, the rest (so that every wave issues exactly NI fills
+  // and one s_waitcnt immediate fits all) land in a dump area behind the images. Pad chunks and dump chunks read
+  // chunk 0 of their row. Per-lane source pointers advance by one row block per step.
+  const uint16_t* src[G::NI];
+  int64_t src_step[G::NI];
+  int dst_off[G::NI];             // element offset of the fill inside a stage (wave-uniform)
+#pragma unroll
+  for (int q = 0; q < G::NI; ++q) {
+    const int f = wave + q * G::NW;
+    dst_off[q] = f * 512;
+    const int chunk = f * 64 + lane;
+    if (f < G::IA) {
+      const int row = chunk / (G::SA / 8), c8 = chunk % (G::SA / 8);
+      src[q] = dy + (s_begin * MS + row) * (int64_t)N + n0 + (c8 < G::TN / 8 ? c8 : 0) * 8;
+      src_step[q] = (int64_t)MS * N;
+    } else {
+      const int cb = f < G::IA + G::IB ? chunk - G::IA * 64 : lane;
+      const int row = cb / (G::SB / 8), c8 = cb % (G::SB / 8);
+      src[q] = x + (s_begin * MS + row) * (int64_t)K + k0 + (c8 < G::TK / 8 ? c8 : 0) * 8;
+      src_step[q] = (int64_t)MS * K;
+    }
+  }
+  // Fills are issued through inline asm: the compiler's LDS-DMA alias tracking would otherwise put s_waitcnt
+  // vmcnt(0) in front of every LDS read and drain the run-ahead fills. Steps at or beyond `last_step` (run-ahead
+  // past the end of the matrix) re-read the last full row block.
+  const int last_step = (int)(steps_total - 1 - s_begin);
+  int issued = 0;                 // steps issued so far; src[] points at step min(issued, last_step)
+  auto issue_loads = [&](int stage) {
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(smem + stage * G::STAGE) ;
+#pragma unroll
+    for (int q = 0; q < G::NI; ++q) {
+      const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds_base + (uint32_t)dst_off[q] * 2u);
+      asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(src[q]) : "memory", "m0");
+      if (issued < last_step) src[q] += src_step[q];
+    }
+    ++issued;
+  };
+
+  // ---- per-lane fragment offsets -----------------------------------------------------------------------------
+  // tr read: lane (g = lane>>4, mm = lane&15) points at row rb + g*4 + mm/4, columns col0 + 4*(mm%4)..+3 and
+  // receives rows rb + g*4 .. +3 at column col0 + mm. rb = 0 and 16 -> contraction order (g*4+e | 16+g*4+e).
+  const int g = lane >> 4, mm = lane & 15;
+  const int rsub = g * 4 + (mm >> 2), csub = (mm & 3) * 4;
+  const int offA = rsub * G::SA + wn * 96 + csub;                  // + i*16 (+ 16*SA for the second half)
+  const int offB = MS * G::SA + rsub * G::SB + wk * 96 + csub;
+
+  wg_f32x4 acc[WT][WT];
+#pragma unroll
+  for (int i = 0; i < WT; ++i)
+#pragma unroll
+    for (int j = 0; j < WT; ++j) acc[i][j] = wg_f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum[WT];
+#pragma unroll
+  for (int i = 0; i < WT; ++i) bsum[i] = 0.f;
+  const wg_bf16x2 ones = {(__bf16)1.0f, (__bf16)1.0f};
+
+  // NSTAGE-deep ring with the barrier in the MIDDLE of a step. Step s multiplies stage s%NSTAGE in two halves of
+  // WT/2 A-tiles each. Between the halves: wait until this wave's fills of step s+1 have landed (vmcnt counts them
+  // in order), s_barrier (=> step s+1 is complete for everybody, and everybody is done with step s-1), issue the
+  // fills of step s+NSTAGE-1 into the stage step s-1 used, then read the B fragments of step s+1 into a second
+  // register set while the second half's MFMAs run. No LDS latency and no fill latency sits between the last MFMA
+  // of one step and the first of the next. The barrier is the bare s_barrier: a fence would drain the run-ahead.
+  static_assert(G::NSTAGE == 4, "the mid-step schedule is written for a 4-deep ring");
+  auto read_b = [&](const uint16_t* img, uint4 (&bf)[WT]) {
+#pragma unroll
+    for (int j = 0; j < WT; ++j) {
+      const uint2 lo = tr_read(img + offB + j * 16), hi = tr_read(img + offB + j * 16 + 16 * G::SB);
+      bf[j] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+    }
+  };
+  auto read_a = [&](const uint16_t* img, int i) {
+    const uint2 lo = tr_read(img + offA + i * 16), hi = tr_read(img + offA + i * 16 + 16 * G::SA);
+    return make_uint4(lo.x, lo.y, hi.x, hi.y);
+  };
+  auto bias_dot = [&](int i, const uint4& af) {
+    if (BIAS && (i % WK) == wk) {       // dbias: this wave's share of the n-tiles
+      float b = bsum[i];
+      b = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(wg_bf16x2, af.x), ones, b, false);
+      b = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(wg_bf16x2, af.y), ones, b, false);
+      b = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(wg_bf16x2, af.z), ones, b, false);
+      b = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(wg_bf16x2, af.w), ones, b, false);
+      bsum[i] = b;
+    }
+  };
+  uint4 bf[WT], bf_next[WT], af_next;
+  if (nsteps > 0) {
+    issue_loads(0);
+    issue_loads(1);
+    issue_loads(2);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G::NI) : "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    read_b(smem, bf);
+    af_next = read_a(smem, 0);
+  }
+  int stage = 0;
+  for (int step = 0; step < nsteps; ++step) {
+    const uint16_t* img = smem + stage * G::STAGE;
+    const int nstage = stage == G::NSTAGE - 1 ? 0 : stage + 1;
+    const uint16_t* img_next = smem + nstage * G::STAGE;
+#pragma unroll
+    for (int i = 0; i < WT / 2; ++i) {
+      const uint4 af = af_next;
+      af_next = read_a(img, i + 1);
+      bias_dot(i, af);
+#pragma unroll
+      for (int j = 0; j < WT; ++j) acc[i][j] = mfma16(af, bf[j], acc[i][j]);
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::NI) : "memory");      // fills of step+1 landed (step+2 may be in flight)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    issue_loads(stage == 0 ? G::NSTAGE - 1 : stage - 1);               // step+3 -> the stage step-1 used
+    read_b(img_next, bf_next);
+#pragma unroll
+    for (int i = WT / 2; i < WT; ++i) {
+      const uint4 af = af_next;
+      af_next = i + 1 < WT ? read_a(img, i + 1) : read_a(img_next, 0);
+      bias_dot(i, af);
+#pragma unroll
+      for (int j = 0; j < WT; ++j) acc[i][j] = mfma16(af, bf[j], acc[i][j]);
+    }
+#pragma unroll
+    for (int j = 0; j < WT; ++j) bf[j] = bf_next[j];
+    stage = nstage;
+  }
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the run-ahead fills before this workgroup's LDS is freed
+
+  // ---- epilogue: partial tile of this split -------------------------------------------------------------------
+  float* out = part + ((size_t)split * N + n0 + wn * 96) * K + k0 + wk * 96;
+#pragma unroll
+  for (int i = 0; i < WT; ++i)
+#pragma unroll
+    for (int j = 0; j < WT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out[(size_t)(i * 16 + g * 4 + r) * K + j * 16 + mm] = acc[i][j][r];
+  if (BIAS && k0 == 0) {
+#pragma unroll
+    for (int i = 0; i < WT; ++i) {
+      if ((i % WK) == wk) {
+        float b = bsum[i];
+        b += __shfl_xor(b, 16, 64);
+        b += __shfl_xor(b, 32, 64);
+        if (g == 0) bpart[(size_t)split * N + n0 + wn * 96 + i * 16 + mm] = b;
+      }
+    }
+  }
+}
+
+// dw[e] = sum_s part[s][e] (+ the < 32 tail rows m >= M_main, which the tiled kernel skips), db[n] likewise
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part,
+                                                           const float* __restrict__ bpart,
+                                                           const uint16_t* __restrict__ dy,
+                                                           const uint16_t* __restrict__ x, float* __restrict__ dw,
+                                                           float* __restrict__ db, int64_t M_main, int64_t M, int N,
+                                                           int K, int S) {
+  const int64_t NK = (int64_t)N * K;
+  const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v * 4 < NK) {
+    float4 a = *reinterpret_cast<const float4*>(part + v * 4);
+    for (int s = 1; s < S; ++s) {
+      const float4 b = *reinterpret_cast<const float4*>(part + (size_t)s * NK + v * 4);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    const int n = (int)((v * 4) / K), k = (int)((v * 4) % K);
+    for (int64_t m = M_main; m < M; ++m) {
+      const float d = bf16_to_f32(dy[m * N + n]);
+      const uint2 xr = *reinterpret_cast<const uint2*>(x + m * K + k);
+      a.x = fmaf(d, __uint_as_float(xr.x << 16), a.x);
+      a.y = fmaf(d, __uint_as_float(xr.x & 0xffff0000u), a.y);
+      a.z = fmaf(d, __uint_as_float(xr.y << 16), a.z);
+      a.w = fmaf(d, __uint_as_float(xr.y & 0xffff0000u), a.w);
+    }
+    *reinterpret_cast<float4*>(dw + v * 4) = a;
+  }
+  if (db != nullptr && v < N) {
+    float a = 0.f;
+    for (int s = 0; s < S; ++s) a += bpart[(size_t)s * N + v];
+    for (int64_t m = M_main; m < M; ++m) a += bf16_to_f32(dy[m * N + v]);
+    db[v] = a;
+  }
+}
+
+struct Plan { int wn, wk, tiles_k, ntiles, S; bool ok; };
+
+Plan make_plan(int N, int K) {
+  static const int cand[][2] = {{4, 2}, {2, 4}, {3, 2}, {2, 3}, {2, 2}};
+  Plan best{};
+  int best_fill = 0;
+  for (auto& c : cand) {
+    const int tn = 96 * c[0], tk = 96 * c[1];
+    if (N % tn || K % tk) continue;
+    const int ntiles = (N / tn) * (K / tk);
+    if (ntiles > 256) continue;
+    // one resident workgroup per CU: S * ntiles <= 256 and a multiple of 8 (XCD mapping); best fill wins, ties go
+    // to the earlier (larger-tile) candidate
+    int S = 256 / ntiles;
+    while (S > 1 && (ntiles * S) % 8) --S;
+    if ((ntiles * S) % 8) continue;
+    const int fill = ntiles * S * ((c[0] * c[1]) % 4 == 0 ? 4 : 3);   // 6 waves load the 4 SIMDs 2:2:1:1
+    if (fill > best_fill) {
+      best_fill = fill;
+      best = Plan{c[0], c[1], K / tk, ntiles, S, true};
+    }
+  }
+  return best;
+}
+
+template <int WN, int WK>
+int launch(const Plan& p, const void* dy, const void* x, float* part, float* bpart, int64_t M, int N, int K,
+           hipStream_t st) {
+  using G = Geo<WN, WK>;
+  const size_t shmem = (size_t)G::NSTAGE * G::STAGE * sizeof(uint16_t);
+  const dim3 grid((unsigned)(p.ntiles * p.S)), block(G::NT);
+  if (bpart != nullptr) {
+    (void)hipFuncSetAttribute((const void*)wgrad_kernel<WN, WK, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)shmem);
+    hipLaunchKernelGGL((wgrad_kernel<WN, WK, true>), grid, block, shmem, st, (const uint16_t*)dy, (const uint16_t*)x,
+                       part, bpart, M, N, K, p.tiles_k, p.ntiles, p.S);
+  } else {
+    (void)hipFuncSetAttribute((const void*)wgrad_kernel<WN, WK, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)shmem);
+    hipLaunchKernelGGL((wgrad_kernel<WN, WK, false>), grid, block, shmem, st, (const uint16_t*)dy, (const uint16_t*)x,
+                       part, bpart, M, N, K, p.tiles_k, p.ntiles, p.S);
+  }
+  LVL_CHECK_LAUNCH("linear_wgrad");
+  return LVL_OK;
+}
+
+}  // namespace
+
+int64_t lvl_wgrad_workspace_floats(int64_t N, int64_t K) {
+  const Plan p = make_plan((int)N, (int)K);
+  if (!p.ok) return -1;
+  return (int64_t)p.S * N * K + (int64_t)p.S * N;
+}
+
+extern "C" int lvl_linear_wgrad(const void* dy, const void* x, float* dw, float* dbias, float* ws, int64_t M, int N,
+                                int K, int dtype, void* stream) {
+  LVL_REQUIRE(dy && x && dw && ws, "linear_wgrad: null pointer");
+  LVL_REQUIRE(dtype == LVL_BF16, "linear_wgrad: bf16 operands only (dtype=%d)", dtype);
+  LVL_REQUIRE(M > 0 && N > 0 && K > 0, "linear_wgrad: empty problem");
+  LVL_REQUIRE(lvl_aligned16(dy) && lvl_aligned16(x) && lvl_aligned16(dw) && lvl_aligned16(ws),
+              "linear_wgrad: pointers must be 16-byte aligned");
+  const Plan p = make_plan(N, K);
+  if (!p.ok) return lvl_fail(LVL_ENOSYS, "linear_wgrad: no tiling for N=%d K=%d (multiples of 192/288/384 needed)", N, K);
+  hipStream_t st = (hipStream_t)stream;
+  float* part = ws;
+  float* bpart = dbias ? ws + (size_t)p.S * N * K : nullptr;
+  int rc = LVL_OK;
+  if (p.wn == 4 && p.wk == 2) rc = launch<4, 2>(p, dy, x, part, bpart, M, N, K, st);
+  else if (p.wn == 2 && p.wk == 4) rc = launch<2, 4>(p, dy, x, part, bpart, M, N, K, st);
+  else if (p.wn == 3 && p.wk == 2) rc = launch<3, 2>(p, dy, x, part, bpart, M, N, K, st);
+  else if (p.wn == 2 && p.wk == 3) rc = launch<2, 3>(p, dy, x, part, bpart, M, N, K, st);
+  else rc = launch<2, 2>(p, dy, x, part, bpart, M, N, K, st);
+  if (rc != LVL_OK) return rc;
+  const int64_t NK = (int64_t)N * K;
+  int64_t nthreads = (NK + 3) / 4;
+  if (nthreads < N) nthreads = N;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, part, bpart,
+                     (const uint16_t*)dy, (const uint16_t*)x, dw, dbias, (M / MS) * MS, M, N, K, p.S);
+  LVL_CHECK_LAUNCH("linear_wgrad_reduce");
+  return LVL_OK;
+}

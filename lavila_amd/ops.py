@@ -23,6 +23,7 @@ def _f32(p: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
 
 
 _DGRAD_TN = os.environ.get('LAVILA_DGRAD_TN', '1') != '0'
+_WGRAD_MFMA = os.environ.get('LAVILA_WGRAD_MFMA', '1') != '0'
 
 
 def _rows_cols(x: torch.Tensor):
@@ -66,18 +67,46 @@ class _LinearFn(torch.autograd.Function):
                     dx = torch.nn.functional.linear(dy2, w.t().contiguous()).reshape(x.shape)
                 else:
                     dx = (dy2 @ w).reshape(x.shape)
-            dw = None
+            dw = db = None
+            want_db = bdt is not None and ctx.needs_input_grad[2]
             if ctx.needs_input_grad[1]:
                 rows, n_out, n_in = dy2.shape[0], dy2.shape[1], x2.shape[1]
-                split = 32 if n_out >= 3 * n_in else 16
-                if rows >= 32768 and rows % split == 0 and dy2.is_contiguous() and x2.is_contiguous():
-                    part = torch.bmm(dy2.view(split, rows // split, n_out).transpose(1, 2),
-                                     x2.view(split, rows // split, n_in))
-                    dw = part.sum(0, dtype=torch.float32).to(wdt)
+                ws_floats = -1
+                if (_WGRAD_MFMA and rows >= 32768 and dy2.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16
+                        and dy2.is_contiguous() and x2.is_contiguous() and dy2.is_cuda):
+                    ws_floats = C.lib().lvl_workspace_floats(b'linear_wgrad', n_out, n_in)
+                if ws_floats >= 0:
+                    # dbias stays a separate column reduction: fused (v_dot2 beside the MFMAs) it costs the tiled
+                    # kernel 0.11-0.19 ms, the stand-alone reduction 0.13 ms (tools/probe_wgrad_mfma.py)
+                    dw = linear_wgrad_raw(dy2, x2, False, int(ws_floats))[0].to(wdt)
                 else:
-                    dw = (dy2.t() @ x2).to(wdt)
-            db = dy2.sum(0).to(bdt) if (bdt is not None and ctx.needs_input_grad[2]) else None
+                    split = 32 if n_out >= 3 * n_in else 16
+                    if rows >= 32768 and rows % split == 0 and dy2.is_contiguous() and x2.is_contiguous():
+                        part = torch.bmm(dy2.view(split, rows // split, n_out).transpose(1, 2),
+                                         x2.view(split, rows // split, n_in))
+                        dw = part.sum(0, dtype=torch.float32).to(wdt)
+                    else:
+                        dw = (dy2.t() @ x2).to(wdt)
+            if want_db:
+                db = dy2.sum(0).to(bdt)
         return dx, dw, db
+
+
+def linear_wgrad_raw(dy, x, want_dbias: bool, ws_floats: int = -1):
+    """dW [N,K] f32 = dy[M,N]^T x[M,K] (+ dbias [N] f32) through lvl_linear_wgrad (bf16 operands)."""
+    C.require_device(dy, x)
+    M, N = dy.shape
+    K = x.shape[1]
+    if ws_floats < 0:
+        ws_floats = C.lib().lvl_workspace_floats(b'linear_wgrad', N, K)
+        if ws_floats < 0:
+            raise C.HipExtensionError(f'lvl_linear_wgrad: no tiling for N={N} K={K}')
+    ws = torch.empty(int(ws_floats), dtype=torch.float32, device=dy.device)
+    dw = torch.empty(N, K, dtype=torch.float32, device=dy.device)
+    db = torch.empty(N, dtype=torch.float32, device=dy.device) if want_dbias else None
+    C.check(C.lib().lvl_linear_wgrad(C.ptr(dy), C.ptr(x), C.ptr(dw), C.ptr(db), C.ptr(ws), M, N, K, C.dtype_code(dy),
+                                     C.stream_ptr()), 'lvl_linear_wgrad')
+    return dw, db
 
 
 def linear(x, weight, bias=None):

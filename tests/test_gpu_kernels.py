@@ -274,6 +274,31 @@ def test_ssl_clip_loss_module_matches_reference_golden():
     torch.testing.assert_close(lt.grad.cpu(), want['dtxt'], atol=1e-6, rtol=1e-4)
 
 
+@pytest.mark.parametrize('M,N,K', [(4096, 768, 768), (1000, 2304, 768), (2053, 3072, 768), (4100, 768, 3072),
+                                   (300, 576, 576), (33, 768, 768)])
+def test_linear_wgrad_mfma(M, N, K):
+    """lvl_linear_wgrad: dW = dY^T X and dbias = column sums of dY (bf16 operands, f32 accumulate) against a torch
+    f32 reference on the same bf16-rounded inputs; ragged M (not a multiple of the 32-row step) included."""
+    from lavila_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    dy = torch.randn(M, N, generator=g).bfloat16()
+    x = torch.randn(M, K, generator=g).bfloat16()
+    want = dy.float().t() @ x.float()
+    dw, db = ops.linear_wgrad_raw(dy.to(DEV), x.to(DEV), True)
+    torch.testing.assert_close(dw.cpu(), want, atol=2e-3, rtol=2e-5)
+    torch.testing.assert_close(db.cpu(), dy.float().sum(0), atol=1e-3, rtol=1e-5)
+    dw2, none = ops.linear_wgrad_raw(dy.to(DEV), x.to(DEV), False)
+    assert none is None and torch.equal(dw2, dw)                     # deterministic (no atomics)
+
+
+def test_linear_wgrad_unsupported_shape_is_loud():
+    from lavila_amd import ops
+    from lavila_amd._cabi import HipExtensionError
+    with pytest.raises(HipExtensionError):
+        ops.linear_wgrad_raw(torch.zeros(64, 512, device=DEV, dtype=torch.bfloat16),
+                             torch.zeros(64, 512, device=DEV, dtype=torch.bfloat16), False)
+
+
 def test_kernel_argument_errors_are_loud():
     from lavila_amd import ops
     from lavila_amd._cabi import HipExtensionError
