@@ -11,9 +11,12 @@ One step = forward (TimeSformer-B/16 video tower on 4x224^2 clips + CLIP text to
 weights with the temporal attention randomised so it is live. Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
-  roofline     -- the dominant hand-written kernel (space-mode divided attention forward, lvl_divided_attn_fwd):
-                  algorithmic bytes per launch / its average duration, measured with HIP events on the launch
-                  stream inside the timed region, against the 8 TB/s HBM peak.
+  roofline     -- the dominant hand-written kernel: the MFMA weight-gradient GEMM of the Linear layers
+                  (lvl_linear_wgrad, ~20 % of the step), on its most frequent shape (the MLP weights, N*K = 3072*768):
+                  algorithmic flops per launch (2*M*N*K) / its average duration, measured with HIP events on the
+                  launch stream inside the timed region, against the 2.5 PFLOP/s dense bf16 MFMA peak.
+  roofline_hbm -- the dominant HBM-bound hand-written kernel (space-mode divided attention forward,
+                  lvl_divided_attn_fwd): algorithmic bytes per launch / average duration against 8 TB/s.
   cpu_baseline -- the CPU oracle (oracle/oracle.py, kind "port") timed on this box's host cores on a bounded
                   sample (one fwd+loss+bwd of a small batch of the same shapes), rank 0 at N=1 only.
 """
@@ -53,6 +56,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 (the 2:1-sparsity headline figure is never used)
 
 
 def parse():
@@ -162,6 +166,9 @@ def main():
     from lavila.models.loss import CLIPLoss
     timer = KernelTimer()
     ops.divided_attention = timer.wrap(ops.divided_attention, lambda qkv, f, n, h, mode: mode == 'space')
+    wtimer = KernelTimer()          # MLP-shaped weight gradients (fc1: N=4D,K=D; fc2: N=D,K=4D)
+    ops.linear_wgrad_raw = wtimer.wrap(
+        ops.linear_wgrad_raw, lambda dy, x, *a, **k: dy.shape[1] * x.shape[1] == 4 * min(dy.shape[1], x.shape[1]) ** 2)
 
     model = build_model(args, device)
     img = model.visual.patch_embed.img_size[0]
@@ -195,13 +202,13 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    timer.enabled = not args.no_events
+    timer.enabled = wtimer.enabled = not args.no_events
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     fence()
     elapsed = time.perf_counter() - t0
-    timer.enabled = False
+    timer.enabled = wtimer.enabled = False
     t = torch.tensor([elapsed], device=device, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -216,17 +223,31 @@ def main():
         esize = 2 if amp is not None else 4
         alg_bytes = B * (T * 3 * D + T * D) * esize            # read packed qkv once, write out once
         kms = timer.mean_ms()
-        roofline = None
+        roofline_hbm = None
         traffic = None
         tfile = os.path.join(ROOT, 'profiles', 'r01_traffic_space_fwd.json')   # PMC pass of the same kernel/shape
         if os.path.isfile(tfile) and (B, Fr, N, D) == (256, 4, 196, 768) and amp is not None:
             traffic = json.load(open(tfile))['traffic_bytes_per_launch']
         if kms:
             achieved = alg_bytes / (kms * 1e-3) / 1e9
-            roofline = {'bound': 'hbm', 'kernel': 'lvl_divided_attn_fwd[space]', 'achieved': round(achieved, 1),
-                        'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
-                        'traffic': traffic, 'avg_ms': round(kms, 4), 'launches': len(timer.pairs),
-                        'alg_bytes_per_launch': alg_bytes}
+            roofline_hbm = {'bound': 'hbm', 'kernel': 'lvl_divided_attn_fwd[space]', 'achieved': round(achieved, 1),
+                            'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
+                            'traffic': traffic, 'avg_ms': round(kms, 4), 'launches': len(timer.pairs),
+                            'alg_bytes_per_launch': alg_bytes}
+        # dominant kernel: MFMA weight gradient on the MLP shapes; algorithmic flops = 2*M*N*K per launch
+        roofline = roofline_hbm
+        wms = wtimer.mean_ms()
+        if wms:
+            flops = 2.0 * (B * T) * D * (4 * D)
+            wtraffic = None
+            wfile = os.path.join(ROOT, 'profiles', 'r01_traffic_wgrad.json')
+            if os.path.isfile(wfile) and (B, Fr, N, D) == (256, 4, 196, 768):
+                wtraffic = json.load(open(wfile))['traffic_bytes_per_launch']
+            ach = flops / (wms * 1e-3) / 1e12
+            roofline = {'bound': 'mfma', 'kernel': 'lvl_linear_wgrad[MLP weights, N*K=4D*D]', 'achieved': round(ach, 1),
+                        'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(ach / MFMA_PEAK_TFLOPS, 4),
+                        'traffic': wtraffic, 'avg_ms': round(wms, 4), 'launches': len(wtimer.pairs),
+                        'alg_flops_per_launch': flops}
         line = {
             'metric': 'clip-text pairs/s (whole node), TSF-B/16 4x224^2 + CLIP text tower, fwd+loss+bwd+AdamW',
             'value': round(world * B * args.steps / elapsed, 2), 'unit': 'clip-text pairs/s', 'n_gpus': world,
@@ -238,6 +259,7 @@ def main():
                        'global_batch': world * B, 'parallelism': f'dp{world}', 'final_loss': round(final_loss, 4),
                        'tuned_gemm_table': TUNED_GEMMS},
             'roofline': roofline,
+            'roofline_hbm': roofline_hbm,
         }
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args, model, img)

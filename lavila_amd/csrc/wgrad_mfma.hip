@@ -171,7 +171,8 @@ __global__ __launch_bounds__(64 * WN * WK) void wgrad_kernel(const uint16_t* __r
     af_next = read_a(smem, 0);
   }
   int stage = 0;
-  for (int step = 0; step < nsteps; ++step) {
+  // one step; `cur` holds this step's B fragments, `nxt` receives the next step's (ping-pong: no register copies)
+  auto do_step = [&](uint4 (&cur)[WT], uint4 (&nxt)[WT]) {
     const uint16_t* img = smem + stage * G::STAGE;
     const int nstage = stage == G::NSTAGE - 1 ? 0 : stage + 1;
     const uint16_t* img_next = smem + nstage * G::STAGE;
@@ -181,25 +182,29 @@ __global__ __launch_bounds__(64 * WN * WK) void wgrad_kernel(const uint16_t* __r
       af_next = read_a(img, i + 1);
       bias_dot(i, af);
 #pragma unroll
-      for (int j = 0; j < WT; ++j) acc[i][j] = mfma16(af, bf[j], acc[i][j]);
+      for (int j = 0; j < WT; ++j) acc[i][j] = mfma16(af, cur[j], acc[i][j]);
     }
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::NI) : "memory");      // fills of step+1 landed (step+2 may be in flight)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     issue_loads(stage == 0 ? G::NSTAGE - 1 : stage - 1);               // step+3 -> the stage step-1 used
-    read_b(img_next, bf_next);
+    read_b(img_next, nxt);
 #pragma unroll
     for (int i = WT / 2; i < WT; ++i) {
       const uint4 af = af_next;
       af_next = i + 1 < WT ? read_a(img, i + 1) : read_a(img_next, 0);
       bias_dot(i, af);
 #pragma unroll
-      for (int j = 0; j < WT; ++j) acc[i][j] = mfma16(af, bf[j], acc[i][j]);
+      for (int j = 0; j < WT; ++j) acc[i][j] = mfma16(af, cur[j], acc[i][j]);
     }
-#pragma unroll
-    for (int j = 0; j < WT; ++j) bf[j] = bf_next[j];
     stage = nstage;
+  };
+  int step = 0;
+  for (; step + 1 < nsteps; step += 2) {
+    do_step(bf, bf_next);
+    do_step(bf_next, bf);
   }
+  if (step < nsteps) do_step(bf, bf_next);
 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the run-ahead fills before this workgroup's LDS is freed
 
