@@ -10,6 +10,7 @@ import torch  # noqa: E402
 from lavila_amd import ops  # noqa: E402
 
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 256 * 785
+only = sys.argv[2:]          # optional layer names (qkv proj fc1 fc2)
 
 
 def bench(fn, n=8):
@@ -24,6 +25,8 @@ def bench(fn, n=8):
 
 
 for name, (N, K) in {'qkv': (2304, 768), 'proj': (768, 768), 'fc1': (3072, 768), 'fc2': (768, 3072)}.items():
+    if only and name not in only:
+        continue
     x = torch.randn(M, K, device='cuda', dtype=torch.bfloat16)
     dy = torch.randn(M, N, device='cuda', dtype=torch.bfloat16)
     fl = 2.0 * M * N * K
