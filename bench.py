@@ -171,7 +171,7 @@ def main():
     from lavila_amd import ops
     from lavila.models.loss import CLIPLoss
     timer = KernelTimer()
-    ops.divided_attention = timer.wrap(ops.divided_attention, lambda qkv, f, n, h, mode: mode == 'space')
+    ops.divided_attn_fwd_raw = timer.wrap(ops.divided_attn_fwd_raw, lambda qkv, f, n, h, mode: mode == 0)   # space
     wtimer = KernelTimer()          # every launch of the MFMA weight-gradient kernel (qkv, proj, fc1, fc2, patch embed)
     ops.linear_wgrad_raw = wtimer.wrap(ops.linear_wgrad_raw, lambda dy, x, *a, **k: True,
                                        work=lambda dy, x, *a, **k: 2.0 * dy.shape[0] * dy.shape[1] * x.shape[1])

@@ -20,6 +20,9 @@
 // Partial tiles [S,N,K] f32 are reduced by wgrad_reduce_kernel (deterministic, no atomics).
 #include "common.h"
 
+// the LDS-DMA fills set M0 inside inline asm and say so in the clobber list; this kernel has no other M0 user
+#pragma clang diagnostic ignored "-Winline-asm"
+
 typedef __attribute__((ext_vector_type(8))) __bf16 wg_bf16x8;
 typedef __attribute__((ext_vector_type(2))) __bf16 wg_bf16x2;
 typedef __attribute__((ext_vector_type(4))) float wg_f32x4;

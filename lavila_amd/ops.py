@@ -308,11 +308,7 @@ class _DividedAttnFn(torch.autograd.Function):
         if D != heads * 64 or T != 1 + frames * n_per_frame:
             raise C.HipExtensionError(f'divided attention: qkv {tuple(qkv.shape)} inconsistent with heads={heads} '
                                       f'(head dim must be 64), frames={frames}, patches/frame={n_per_frame}')
-        out = torch.empty(B, T, D, dtype=qkv.dtype, device=qkv.device)
-        lse = torch.empty(B, heads, T, dtype=torch.float32, device=qkv.device)
-        ws = C.workspace('divided_attn_fwd', B * heads, T, qkv.device)
-        C.check(C.lib().lvl_divided_attn_fwd(C.ptr(qkv), C.ptr(out), C.ptr(lse), C.ptr(ws), B, frames, n_per_frame,
-                                             heads, mode, C.dtype_code(qkv), C.stream_ptr()), 'lvl_divided_attn_fwd')
+        out, lse = divided_attn_fwd_raw(qkv, frames, n_per_frame, heads, mode)
         ctx.save_for_backward(qkv, out, lse)
         ctx.cfg = (B, frames, n_per_frame, heads, mode)
         return out
@@ -328,6 +324,17 @@ class _DividedAttnFn(torch.autograd.Function):
                                              B, Fr, N, H, mode, C.dtype_code(qkv), C.stream_ptr()),
                 'lvl_divided_attn_bwd')
         return dqkv, None, None, None, None
+
+
+def divided_attn_fwd_raw(qkv, frames, n_per_frame, heads, mode):
+    """One lvl_divided_attn_fwd call: (out [B,T,D], lse [B,H,T])."""
+    B, T, D3 = qkv.shape
+    out = torch.empty(B, T, D3 // 3, dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty(B, heads, T, dtype=torch.float32, device=qkv.device)
+    ws = C.workspace('divided_attn_fwd', B * heads, T, qkv.device)
+    C.check(C.lib().lvl_divided_attn_fwd(C.ptr(qkv), C.ptr(out), C.ptr(lse), C.ptr(ws), B, frames, n_per_frame,
+                                         heads, mode, C.dtype_code(qkv), C.stream_ptr()), 'lvl_divided_attn_fwd')
+    return out, lse
 
 
 def divided_attention(qkv, frames, n_per_frame, heads, mode):
