@@ -4,8 +4,10 @@
 // Shape of the problem on this path: M = B*T ~ 2e5 rows, N,K in {768, 2304, 3072}: a tiny output contracted over
 // a huge row count, with BOTH operands stored row-major over the contraction index (the layout a library GEMM
 // likes least: every MFMA fragment needs a transpose). Here:
-//   * the output is cut into tiles of (96*WN) x (96*WK), the rows into S splits; one workgroup (WN*WK waves, each
-//     owning a 96x96 block = 6x6 MFMA tiles in registers) per (tile, split), all of them resident at once;
+//   * the output is cut into tiles, the rows into S splits; one workgroup of WN*WK waves per (tile, split), all of
+//     them resident at once. A wave owns TA x TB MFMA tiles in registers: 6x6 (96x96; workgroup tile 384x192,
+//     192x384, 288x192 ... for the 768-family widths) or 8x4 (128x64; workgroup tile 256x256, 256x128, 128x256 for
+//     the 512- and 1024-family widths);
 //   * blockIdx -> (split, tile) is XCD-aware: workgroup i runs on XCD i%8, and XCD x is given a contiguous range
 //     of the split-major (split, tile) pairs, so the ~32 workgroups of an XCD stream the SAME dY/X rows through
 //     that XCD's L2 (each row is fetched from HBM about once instead of once per tile);
@@ -31,7 +33,6 @@ typedef __attribute__((ext_vector_type(4))) short wg_s16x4;
 namespace {
 
 constexpr int MS = 32;          // rows per step (one MFMA contraction)
-constexpr int WT = 6;           // wave tile: WT x WT MFMA tiles (96 x 96)
 
 __device__ __forceinline__ uint2 tr_read(const uint16_t* p) {
   const wg_s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wg_s16x4*)p);
@@ -42,26 +43,27 @@ __device__ __forceinline__ wg_f32x4 mfma16(uint4 a, uint4 b, wg_f32x4 c) {
                                                  c, 0, 0, 0);
 }
 
-template <int WN, int WK>
+template <int WN, int WK, int TA, int TB>
 struct Geo {
   static constexpr int NW = WN * WK, NT = 64 * NW;
-  static constexpr int TN = 96 * WN, TK = 96 * WK;
+  static constexpr int TN = 16 * TA * WN, TK = 16 * TB * WK;     // workgroup tile (rows of dW x columns of dW)
   static constexpr int SA = TN + 16, SB = TK + 16;            // image row strides in elements (+32 B)
   // LDS-DMA plan: one global_load_lds_dwordx4 fills 64 consecutive 16-B chunks (1 KiB) of a stage. An image of
   // MS rows x (stride/8) chunks is exactly IA (IB) such fills; the pad chunks of a row carry don't-care data.
-  static constexpr int IA = MS * (SA / 8) / 64, IB = MS * (SB / 8) / 64;      // = 6*WN + 1, 6*WK + 1
+  static constexpr int IA = MS * (SA / 8) / 64, IB = MS * (SB / 8) / 64;      // = TA*WN + 1, TB*WK + 1
   static constexpr int NI = (IA + IB + NW - 1) / NW;                          // fills per wave per step
   static constexpr int STAGE = MS * (SA + SB) + (NI * NW - IA - IB) * 512;    // elements per stage (+ dump area)
   static constexpr int NSTAGE = (4 * STAGE * 2 <= 160 * 1024) ? 4 : 3;   // ring depth: fills run NSTAGE-1 steps ahead
   static_assert(MS * (SA / 8) % 64 == 0 && MS * (SB / 8) % 64 == 0, "images must be whole 1-KiB fills");
 };
 
-template <int WN, int WK, bool BIAS>
+template <int WN, int WK, int TA, int TB, bool BIAS>
 __global__ __launch_bounds__(64 * WN * WK) void wgrad_kernel(const uint16_t* __restrict__ dy,
                                                              const uint16_t* __restrict__ x, float* __restrict__ part,
                                                              float* __restrict__ bpart, int64_t M, int N, int K,
                                                              int tiles_k, int ntiles, int S) {
-  using G = Geo<WN, WK>;
+  using G = Geo<WN, WK, TA, TB>;
+  static_assert(TA % 2 == 0, "the mid-step barrier splits the A tiles in two halves");
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];     // [NSTAGE][A image | B image | dump]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave % WN, wk = wave / WN;
@@ -121,29 +123,29 @@ __global__ __launch_bounds__(64 * WN * WK) void wgrad_kernel(const uint16_t* __r
   // receives rows rb + g*4 .. +3 at column col0 + mm. rb = 0 and 16 -> contraction order (g*4+e | 16+g*4+e).
   const int g = lane >> 4, mm = lane & 15;
   const int rsub = g * 4 + (mm >> 2), csub = (mm & 3) * 4;
-  const int offA = rsub * G::SA + wn * 96 + csub;                  // + i*16 (+ 16*SA for the second half)
-  const int offB = MS * G::SA + rsub * G::SB + wk * 96 + csub;
+  const int offA = rsub * G::SA + wn * (16 * TA) + csub;                  // + i*16 (+ 16*SA for the second half)
+  const int offB = MS * G::SA + rsub * G::SB + wk * (16 * TB) + csub;
 
-  wg_f32x4 acc[WT][WT];
+  wg_f32x4 acc[TA][TB];
 #pragma unroll
-  for (int i = 0; i < WT; ++i)
+  for (int i = 0; i < TA; ++i)
 #pragma unroll
-    for (int j = 0; j < WT; ++j) acc[i][j] = wg_f32x4{0.f, 0.f, 0.f, 0.f};
-  float bsum[WT];
+    for (int j = 0; j < TB; ++j) acc[i][j] = wg_f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum[TA];
 #pragma unroll
-  for (int i = 0; i < WT; ++i) bsum[i] = 0.f;
+  for (int i = 0; i < TA; ++i) bsum[i] = 0.f;
   const wg_bf16x2 ones = {(__bf16)1.0f, (__bf16)1.0f};
 
   // NSTAGE-deep ring with the barrier in the MIDDLE of a step. Step s multiplies stage s%NSTAGE in two halves of
-  // WT/2 A-tiles each. Between the halves: wait until this wave's fills of step s+1 have landed (vmcnt counts them
+  // TA/2 A-tiles each. Between the halves: wait until this wave's fills of step s+1 have landed (vmcnt counts them
   // in order), s_barrier (=> step s+1 is complete for everybody, and everybody is done with step s-1), issue the
   // fills of step s+NSTAGE-1 into the stage step s-1 used, then read the B fragments of step s+1 into a second
   // register set while the second half's MFMAs run. No LDS latency and no fill latency sits between the last MFMA
   // of one step and the first of the next. The barrier is the bare s_barrier: a fence would drain the run-ahead.
   static_assert(G::NSTAGE == 4, "the mid-step schedule is written for a 4-deep ring");
-  auto read_b = [&](const uint16_t* img, uint4 (&bf)[WT]) {
+  auto read_b = [&](const uint16_t* img, uint4 (&bf)[TB]) {
 #pragma unroll
-    for (int j = 0; j < WT; ++j) {
+    for (int j = 0; j < TB; ++j) {
       const uint2 lo = tr_read(img + offB + j * 16), hi = tr_read(img + offB + j * 16 + 16 * G::SB);
       bf[j] = make_uint4(lo.x, lo.y, hi.x, hi.y);
     }
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(64 * WN * WK) void wgrad_kernel(const uint16_t* __r
       bsum[i] = b;
     }
   };
-  uint4 bf[WT], bf_next[WT], af_next;
+  uint4 bf[TB], bf_next[TB], af_next;
   if (nsteps > 0) {
     issue_loads(0);
     issue_loads(1);
@@ -175,17 +177,17 @@ __global__ __launch_bounds__(64 * WN * WK) void wgrad_kernel(const uint16_t* __r
   }
   int stage = 0;
   // one step; `cur` holds this step's B fragments, `nxt` receives the next step's (ping-pong: no register copies)
-  auto do_step = [&](uint4 (&cur)[WT], uint4 (&nxt)[WT]) {
+  auto do_step = [&](uint4 (&cur)[TB], uint4 (&nxt)[TB]) {
     const uint16_t* img = smem + stage * G::STAGE;
     const int nstage = stage == G::NSTAGE - 1 ? 0 : stage + 1;
     const uint16_t* img_next = smem + nstage * G::STAGE;
 #pragma unroll
-    for (int i = 0; i < WT / 2; ++i) {
+    for (int i = 0; i < TA / 2; ++i) {
       const uint4 af = af_next;
       af_next = read_a(img, i + 1);
       bias_dot(i, af);
 #pragma unroll
-      for (int j = 0; j < WT; ++j) acc[i][j] = mfma16(af, cur[j], acc[i][j]);
+      for (int j = 0; j < TB; ++j) acc[i][j] = mfma16(af, cur[j], acc[i][j]);
     }
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::NI) : "memory");      // fills of step+1 landed (step+2 may be in flight)
     __builtin_amdgcn_s_barrier();
@@ -193,12 +195,12 @@ __global__ __launch_bounds__(64 * WN * WK) void wgrad_kernel(const uint16_t* __r
     issue_loads(stage == 0 ? G::NSTAGE - 1 : stage - 1);               // step+3 -> the stage step-1 used
     read_b(img_next, nxt);
 #pragma unroll
-    for (int i = WT / 2; i < WT; ++i) {
+    for (int i = TA / 2; i < TA; ++i) {
       const uint4 af = af_next;
-      af_next = i + 1 < WT ? read_a(img, i + 1) : read_a(img_next, 0);
+      af_next = i + 1 < TA ? read_a(img, i + 1) : read_a(img_next, 0);
       bias_dot(i, af);
 #pragma unroll
-      for (int j = 0; j < WT; ++j) acc[i][j] = mfma16(af, cur[j], acc[i][j]);
+      for (int j = 0; j < TB; ++j) acc[i][j] = mfma16(af, cur[j], acc[i][j]);
     }
     stage = nstage;
   };
@@ -212,21 +214,21 @@ __global__ __launch_bounds__(64 * WN * WK) void wgrad_kernel(const uint16_t* __r
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the run-ahead fills before this workgroup's LDS is freed
 
   // ---- epilogue: partial tile of this split -------------------------------------------------------------------
-  float* out = part + ((size_t)split * N + n0 + wn * 96) * K + k0 + wk * 96;
+  float* out = part + ((size_t)split * N + n0 + wn * (16 * TA)) * K + k0 + wk * (16 * TB);
 #pragma unroll
-  for (int i = 0; i < WT; ++i)
+  for (int i = 0; i < TA; ++i)
 #pragma unroll
-    for (int j = 0; j < WT; ++j)
+    for (int j = 0; j < TB; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) out[(size_t)(i * 16 + g * 4 + r) * K + j * 16 + mm] = acc[i][j][r];
   if (BIAS && k0 == 0) {
 #pragma unroll
-    for (int i = 0; i < WT; ++i) {
+    for (int i = 0; i < TA; ++i) {
       if ((i % WK) == wk) {
         float b = bsum[i];
         b += __shfl_xor(b, 16, 64);
         b += __shfl_xor(b, 32, 64);
-        if (g == 0) bpart[(size_t)split * N + n0 + wn * 96 + i * 16 + mm] = b;
+        if (g == 0) bpart[(size_t)split * N + n0 + wn * (16 * TA) + i * 16 + mm] = b;
       }
     }
   }
@@ -266,47 +268,54 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
-struct Plan { int wn, wk, tiles_k, ntiles, S; bool ok; };
+struct Plan { int cfg, tiles_k, ntiles, S; bool ok; };
+
+// workgroup shapes: {WN, WK, TA, TB}; tile = (16*TA*WN) x (16*TB*WK)
+constexpr int kCfg[][4] = {{4, 2, 6, 6}, {2, 4, 6, 6}, {3, 2, 6, 6}, {2, 3, 6, 6}, {2, 2, 6, 6},
+                           {2, 4, 8, 4}, {2, 2, 8, 4}, {1, 4, 8, 4}};
+constexpr int kNumCfg = sizeof(kCfg) / sizeof(kCfg[0]);
 
 Plan make_plan(int N, int K) {
-  static const int cand[][2] = {{4, 2}, {2, 4}, {3, 2}, {2, 3}, {2, 2}};
   Plan best{};
-  int best_fill = 0;
-  for (auto& c : cand) {
-    const int tn = 96 * c[0], tk = 96 * c[1];
+  int64_t best_score = 0;
+  for (int ci = 0; ci < kNumCfg; ++ci) {
+    const int* c = kCfg[ci];
+    const int tn = 16 * c[2] * c[0], tk = 16 * c[3] * c[1];
     if (N % tn || K % tk) continue;
     const int ntiles = (N / tn) * (K / tk);
     if (ntiles > 256) continue;
-    // one resident workgroup per CU: S * ntiles <= 256 and a multiple of 8 (XCD mapping); best fill wins, ties go
-    // to the earlier (larger-tile) candidate
+    // one resident workgroup per CU: S * ntiles <= 256 and a multiple of 8 (XCD mapping)
     int S = 256 / ntiles;
     while (S > 1 && (ntiles * S) % 8) --S;
     if ((ntiles * S) % 8) continue;
-    const int fill = ntiles * S * ((c[0] * c[1]) % 4 == 0 ? 4 : 3);   // 6 waves load the 4 SIMDs 2:2:1:1
-    if (fill > best_fill) {
-      best_fill = fill;
-      best = Plan{c[0], c[1], K / tk, ntiles, S, true};
+    // score = busy SIMD slots x tile area: 6 waves load the 4 SIMDs 2:2:1:1, 4 waves leave every SIMD one wave
+    const int waves = c[0] * c[1];
+    const int64_t eff = waves % 4 == 0 ? (waves >= 8 ? 4 : 3) : 3;
+    const int64_t score = (int64_t)ntiles * S * eff * 1000 + (int64_t)tn * tk / 64;
+    if (score > best_score) {
+      best_score = score;
+      best = Plan{ci, K / tk, ntiles, S, true};
     }
   }
   return best;
 }
 
-template <int WN, int WK>
+template <int WN, int WK, int TA, int TB>
 int launch(const Plan& p, const void* dy, const void* x, float* part, float* bpart, int64_t M, int N, int K,
            hipStream_t st) {
-  using G = Geo<WN, WK>;
+  using G = Geo<WN, WK, TA, TB>;
   const size_t shmem = (size_t)G::NSTAGE * G::STAGE * sizeof(uint16_t);
   const dim3 grid((unsigned)(p.ntiles * p.S)), block(G::NT);
   if (bpart != nullptr) {
-    (void)hipFuncSetAttribute((const void*)wgrad_kernel<WN, WK, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)shmem);
-    hipLaunchKernelGGL((wgrad_kernel<WN, WK, true>), grid, block, shmem, st, (const uint16_t*)dy, (const uint16_t*)x,
-                       part, bpart, M, N, K, p.tiles_k, p.ntiles, p.S);
+    (void)hipFuncSetAttribute((const void*)wgrad_kernel<WN, WK, TA, TB, true>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    hipLaunchKernelGGL((wgrad_kernel<WN, WK, TA, TB, true>), grid, block, shmem, st, (const uint16_t*)dy,
+                       (const uint16_t*)x, part, bpart, M, N, K, p.tiles_k, p.ntiles, p.S);
   } else {
-    (void)hipFuncSetAttribute((const void*)wgrad_kernel<WN, WK, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)shmem);
-    hipLaunchKernelGGL((wgrad_kernel<WN, WK, false>), grid, block, shmem, st, (const uint16_t*)dy, (const uint16_t*)x,
-                       part, bpart, M, N, K, p.tiles_k, p.ntiles, p.S);
+    (void)hipFuncSetAttribute((const void*)wgrad_kernel<WN, WK, TA, TB, false>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    hipLaunchKernelGGL((wgrad_kernel<WN, WK, TA, TB, false>), grid, block, shmem, st, (const uint16_t*)dy,
+                       (const uint16_t*)x, part, bpart, M, N, K, p.tiles_k, p.ntiles, p.S);
   }
   LVL_CHECK_LAUNCH("linear_wgrad");
   return LVL_OK;
@@ -328,16 +337,21 @@ extern "C" int lvl_linear_wgrad(const void* dy, const void* x, float* dw, float*
   LVL_REQUIRE(lvl_aligned16(dy) && lvl_aligned16(x) && lvl_aligned16(dw) && lvl_aligned16(ws),
               "linear_wgrad: pointers must be 16-byte aligned");
   const Plan p = make_plan(N, K);
-  if (!p.ok) return lvl_fail(LVL_ENOSYS, "linear_wgrad: no tiling for N=%d K=%d (multiples of 192/288/384 needed)", N, K);
+  if (!p.ok) return lvl_fail(LVL_ENOSYS, "linear_wgrad: no tiling for N=%d K=%d (multiples of 192/288/384 or 128/256 needed)", N, K);
   hipStream_t st = (hipStream_t)stream;
   float* part = ws;
   float* bpart = dbias ? ws + (size_t)p.S * N * K : nullptr;
   int rc = LVL_OK;
-  if (p.wn == 4 && p.wk == 2) rc = launch<4, 2>(p, dy, x, part, bpart, M, N, K, st);
-  else if (p.wn == 2 && p.wk == 4) rc = launch<2, 4>(p, dy, x, part, bpart, M, N, K, st);
-  else if (p.wn == 3 && p.wk == 2) rc = launch<3, 2>(p, dy, x, part, bpart, M, N, K, st);
-  else if (p.wn == 2 && p.wk == 3) rc = launch<2, 3>(p, dy, x, part, bpart, M, N, K, st);
-  else rc = launch<2, 2>(p, dy, x, part, bpart, M, N, K, st);
+  switch (p.cfg) {
+    case 0: rc = launch<4, 2, 6, 6>(p, dy, x, part, bpart, M, N, K, st); break;
+    case 1: rc = launch<2, 4, 6, 6>(p, dy, x, part, bpart, M, N, K, st); break;
+    case 2: rc = launch<3, 2, 6, 6>(p, dy, x, part, bpart, M, N, K, st); break;
+    case 3: rc = launch<2, 3, 6, 6>(p, dy, x, part, bpart, M, N, K, st); break;
+    case 4: rc = launch<2, 2, 6, 6>(p, dy, x, part, bpart, M, N, K, st); break;
+    case 5: rc = launch<2, 4, 8, 4>(p, dy, x, part, bpart, M, N, K, st); break;
+    case 6: rc = launch<2, 2, 8, 4>(p, dy, x, part, bpart, M, N, K, st); break;
+    default: rc = launch<1, 4, 8, 4>(p, dy, x, part, bpart, M, N, K, st); break;
+  }
   if (rc != LVL_OK) return rc;
   const int64_t NK = (int64_t)N * K;
   int64_t nthreads = (NK + 3) / 4;

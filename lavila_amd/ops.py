@@ -72,7 +72,7 @@ class _LinearFn(torch.autograd.Function):
             if ctx.needs_input_grad[1]:
                 rows, n_out, n_in = dy2.shape[0], dy2.shape[1], x2.shape[1]
                 ws_floats = -1
-                if (_WGRAD_MFMA and rows >= 32768 and dy2.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16
+                if (_WGRAD_MFMA and rows >= 4096 and dy2.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16
                         and dy2.is_contiguous() and x2.is_contiguous() and dy2.is_cuda):
                     ws_floats = C.lib().lvl_workspace_floats(b'linear_wgrad', n_out, n_in)
                 if ws_floats >= 0:

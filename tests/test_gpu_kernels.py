@@ -275,7 +275,9 @@ def test_ssl_clip_loss_module_matches_reference_golden():
 
 
 @pytest.mark.parametrize('M,N,K', [(4096, 768, 768), (1000, 2304, 768), (2053, 3072, 768), (4100, 768, 3072),
-                                   (300, 576, 576), (33, 768, 768)])
+                                   (300, 576, 576), (33, 768, 768), (3000, 1024, 1024), (2100, 1536, 512),
+                                   (1500, 512, 2048), (777, 512, 512), (640, 4096, 1024), (900, 256, 128),
+                                   (500, 128, 256)])
 def test_linear_wgrad_mfma(M, N, K):
     """lvl_linear_wgrad: dW = dY^T X and dbias = column sums of dY (bf16 operands, f32 accumulate) against a torch
     f32 reference on the same bf16-rounded inputs; ragged M (not a multiple of the 32-row step) included."""
@@ -295,8 +297,8 @@ def test_linear_wgrad_unsupported_shape_is_loud():
     from lavila_amd import ops
     from lavila_amd._cabi import HipExtensionError
     with pytest.raises(HipExtensionError):
-        ops.linear_wgrad_raw(torch.zeros(64, 512, device=DEV, dtype=torch.bfloat16),
-                             torch.zeros(64, 512, device=DEV, dtype=torch.bfloat16), False)
+        ops.linear_wgrad_raw(torch.zeros(64, 200, device=DEV, dtype=torch.bfloat16),
+                             torch.zeros(64, 200, device=DEV, dtype=torch.bfloat16), False)
 
 
 def test_kernel_argument_errors_are_loud():

@@ -24,8 +24,11 @@ def bench(fn, n=8):
     return (time.perf_counter() - t0) / n * 1e3
 
 
-for name, (N, K) in {'qkv': (2304, 768), 'proj': (768, 768), 'fc1': (3072, 768), 'fc2': (768, 3072)}.items():
-    if only and name not in only:
+SHAPES = {'qkv': (2304, 768), 'proj': (768, 768), 'fc1': (3072, 768), 'fc2': (768, 3072),
+          'Lqkv': (3072, 1024), 'Lproj': (1024, 1024), 'Lfc1': (4096, 1024), 'Lfc2': (1024, 4096),
+          'tqkv': (1536, 512), 'tproj': (512, 512), 'tfc1': (2048, 512), 'tfc2': (512, 2048)}
+for name, (N, K) in SHAPES.items():
+    if (only and name not in only) or (not only and name[0] in 'Lt'):
         continue
     x = torch.randn(M, K, device='cuda', dtype=torch.bfloat16)
     dy = torch.randn(M, N, device='cuda', dtype=torch.bfloat16)
