@@ -332,7 +332,7 @@ __global__ __launch_bounds__(512, 4) void space_bwd_dkv_kernel(
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         float v = dsc * kf[i];
-        v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+        v = row16_sum(v);           // DPP row reduction over the 16 key lanes (no LDS crossbar)
         if (c == 0) atomicAdd(dqc + hh * 32 + g * 8 + i, v);
       }
     }

@@ -161,6 +161,14 @@ __device__ __forceinline__ float dpp_move(float v) {
 __device__ __forceinline__ float read_lane(float v, int l) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
+// sum over each aligned group of 16 lanes (one DPP row); every lane of the group receives it
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_move<0xB1>(v);
+  v += dpp_move<0x4E>(v);
+  v += dpp_move<0x141>(v);
+  v += dpp_move<0x140>(v);
+  return v;
+}
 __device__ __forceinline__ float wave_sum(float v) {
   v += dpp_move<0xB1>(v);     // quad_perm [1,0,3,2]
   v += dpp_move<0x4E>(v);     // quad_perm [2,3,0,1]
