@@ -31,6 +31,9 @@ def _amp_region():
         yield
 
 
+_TEXT_STREAM = os.environ.get('LAVILA_TEXT_STREAM', '1') != '0'
+
+
 class CLIP(nn.Module):
     def __init__(self,
                  embed_dim: int,
@@ -101,6 +104,23 @@ class CLIP(nn.Module):
             return x @ self.text_projection
 
     def forward(self, image, text, use_checkpoint=False, norm_embed=False):
+        if _TEXT_STREAM and image.is_cuda:
+            # The two towers are independent until the loss: the (small) text tower runs on a second HIP stream so that
+            # its short kernels fill the tails of the video tower's launches. Autograd replays each tower's backward on
+            # the stream its forward ran on and joins the streams at the end of backward().
+            main = torch.cuda.current_stream()
+            side = self._text_stream = getattr(self, '_text_stream', None) or torch.cuda.Stream(device=image.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                text_embed = self.encode_text(text, use_checkpoint=use_checkpoint)
+                if norm_embed:
+                    text_embed = F.normalize(text_embed.float(), dim=-1)
+            image_embed = self.encode_image(image, use_checkpoint=use_checkpoint)
+            if norm_embed:
+                image_embed = F.normalize(image_embed.float(), dim=-1)
+            main.wait_stream(side)
+            text_embed.record_stream(main)
+            return {'image_embed': image_embed, 'text_embed': text_embed, 'logit_scale': self.logit_scale.exp()}
         image_embed = self.encode_image(image, use_checkpoint=use_checkpoint)
         text_embed = self.encode_text(text, use_checkpoint=use_checkpoint)
         if norm_embed:

@@ -88,7 +88,7 @@ class _LinearFn(torch.autograd.Function):
                     else:
                         dw = (dy2.t() @ x2).to(wdt)
             if want_db:
-                db = dy2.sum(0).to(bdt)
+                db = dy2.sum(0, dtype=torch.float32).to(bdt)      # f32 accumulation AND f32 result
         return dx, dw, db
 
 

@@ -293,6 +293,36 @@ def test_linear_wgrad_mfma(M, N, K):
     assert none is None and torch.equal(dw2, dw)                     # deterministic (no atomics)
 
 
+@pytest.mark.parametrize('rows,n_in,n_out', [(8192, 768, 2304), (6000, 3072, 768), (5000, 512, 1536), (300, 768, 768)])
+def test_linear_layer_bf16_training_path(rows, n_in, n_out):
+    """ops.linear as the towers call it under bf16 autocast: forward GEMM, input gradient against the transposed
+    weight copy, weight gradient through lvl_linear_wgrad (>= 4096 rows) or the library (fewer), bias gradient --
+    against an f32 torch reference on the same bf16-rounded operands."""
+    from lavila_amd import ops
+    g = torch.Generator().manual_seed(rows + n_in)
+    x = torch.randn(rows, n_in, generator=g).bfloat16()
+    w = (torch.randn(n_out, n_in, generator=g) * 0.03)
+    b = torch.randn(n_out, generator=g) * 0.1
+    dy = torch.randn(rows, n_out, generator=g).bfloat16()
+    xr = x.float().requires_grad_(True)
+    wr = w.bfloat16().float().requires_grad_(True)
+    br = b.bfloat16().float().requires_grad_(True)
+    yr = torch.nn.functional.linear(xr, wr, br)
+    yr.backward(dy.float())
+    xg = x.to(DEV).requires_grad_(True)
+    wg = w.to(DEV).requires_grad_(True)             # f32 master weights, cast per GEMM like autocast does
+    bg = b.to(DEV).requires_grad_(True)
+    y = ops.linear(xg, wg, bg)
+    assert y.dtype == torch.bfloat16
+    y.backward(dy.to(DEV))
+    torch.testing.assert_close(y.float().cpu(), yr.detach(), atol=3e-2, rtol=2e-2)            # bf16 output rounding
+    torch.testing.assert_close(xg.grad.float().cpu(), xr.grad, atol=3e-2, rtol=2e-2)
+    scale = wr.grad.abs().max().item()
+    assert wg.grad.dtype == torch.float32
+    assert (wg.grad.cpu() - wr.grad).abs().max().item() < 4e-3 * scale + 1e-3               # f32 accumulation
+    torch.testing.assert_close(bg.grad.cpu(), br.grad, atol=2e-2, rtol=1e-3)
+
+
 def test_linear_wgrad_unsupported_shape_is_loud():
     from lavila_amd import ops
     from lavila_amd._cabi import HipExtensionError
