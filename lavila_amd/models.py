@@ -32,6 +32,15 @@ def _amp_region():
 
 
 _TEXT_STREAM = os.environ.get('LAVILA_TEXT_STREAM', '1') != '0'
+_text_streams = {}
+
+
+def _text_stream(device):
+    """One side stream per device for the text tower (kept out of the module so that the model stays picklable)."""
+    st = _text_streams.get(device)
+    if st is None:
+        st = _text_streams[device] = torch.cuda.Stream(device=device)
+    return st
 
 
 class CLIP(nn.Module):
@@ -109,7 +118,7 @@ class CLIP(nn.Module):
             # its short kernels fill the tails of the video tower's launches. Autograd replays each tower's backward on
             # the stream its forward ran on and joins the streams at the end of backward().
             main = torch.cuda.current_stream()
-            side = self._text_stream = getattr(self, '_text_stream', None) or torch.cuda.Stream(device=image.device)
+            side = _text_stream(image.device)
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 text_embed = self.encode_text(text, use_checkpoint=use_checkpoint)
