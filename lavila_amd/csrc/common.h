@@ -43,6 +43,8 @@ __device__ __forceinline__ uint32_t f32x2_to_bf16x2(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, v);
 }
 
+typedef uint32_t lvl_u32x4 __attribute__((ext_vector_type(4)));
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
   static __device__ __forceinline__ float load(const float* p) { return *p; }
@@ -58,6 +60,8 @@ template <> struct Elem<float> {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
     *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
   }
+  static __device__ __forceinline__ void load8_nt(const float* p, float (&v)[8]) { load8(p, v); }
+  static __device__ __forceinline__ void store8_nt(float* p, const float (&v)[8]) { store8(p, v); }
   static __device__ __forceinline__ void load4(const float* p, float (&v)[4]) {
     const float4 a = *reinterpret_cast<const float4*>(p);
     v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
@@ -84,6 +88,22 @@ template <> struct Elem<bf16_t> {
     a.z = f32x2_to_bf16x2(v[4], v[5]);
     a.w = f32x2_to_bf16x2(v[6], v[7]);
     *reinterpret_cast<uint4*>(p) = a;
+  }
+  // streaming variants (non-temporal: the tensor is far larger than L2 + Infinity Cache and is touched once)
+  static __device__ __forceinline__ void load8_nt(const bf16_t* p, float (&v)[8]) {
+    const lvl_u32x4 a = __builtin_nontemporal_load(reinterpret_cast<const lvl_u32x4*>(p));
+    v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xffff0000u);
+    v[2] = __uint_as_float(a.y << 16); v[3] = __uint_as_float(a.y & 0xffff0000u);
+    v[4] = __uint_as_float(a.z << 16); v[5] = __uint_as_float(a.z & 0xffff0000u);
+    v[6] = __uint_as_float(a.w << 16); v[7] = __uint_as_float(a.w & 0xffff0000u);
+  }
+  static __device__ __forceinline__ void store8_nt(bf16_t* p, const float (&v)[8]) {
+    lvl_u32x4 a;
+    a.x = f32x2_to_bf16x2(v[0], v[1]);
+    a.y = f32x2_to_bf16x2(v[2], v[3]);
+    a.z = f32x2_to_bf16x2(v[4], v[5]);
+    a.w = f32x2_to_bf16x2(v[6], v[7]);
+    __builtin_nontemporal_store(a, reinterpret_cast<lvl_u32x4*>(p));
   }
   static __device__ __forceinline__ void load4(const bf16_t* p, float (&v)[4]) {
     const uint2 a = *reinterpret_cast<const uint2*>(p);

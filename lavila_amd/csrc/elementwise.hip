@@ -28,7 +28,7 @@ __global__ __launch_bounds__(128) void bias_gelu_fwd_kernel(const T* __restrict_
   for (; r + (kGeluUnroll - 1) * stride < rows; r += kGeluUnroll * stride) {
     float x[kGeluUnroll][8];
 #pragma unroll
-    for (int k = 0; k < kGeluUnroll; ++k) Elem<T>::load8(u + (r + k * stride) * cols + vc * 8, x[k]);
+    for (int k = 0; k < kGeluUnroll; ++k) Elem<T>::load8_nt(u + (r + k * stride) * cols + vc * 8, x[k]);
 #pragma unroll
     for (int k = 0; k < kGeluUnroll; ++k) {
       float o[8];
@@ -37,18 +37,18 @@ __global__ __launch_bounds__(128) void bias_gelu_fwd_kernel(const T* __restrict_
         const float y = x[k][j] + b[j];
         o[j] = y * sigmoidf_fast(1.702f * y);
       }
-      Elem<T>::store8(a + (r + k * stride) * cols + vc * 8, o);
+      Elem<T>::store8_nt(a + (r + k * stride) * cols + vc * 8, o);
     }
   }
   for (; r < rows; r += stride) {
     float x[8], o[8];
-    Elem<T>::load8(u + r * cols + vc * 8, x);
+    Elem<T>::load8_nt(u + r * cols + vc * 8, x);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float y = x[j] + b[j];
       o[j] = y * sigmoidf_fast(1.702f * y);
     }
-    Elem<T>::store8(a + r * cols + vc * 8, o);
+    Elem<T>::store8_nt(a + r * cols + vc * 8, o);
   }
 }
 
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(128) void bias_gelu_bwd_kernel(const T* __restrict_
       o[j] = g[j] * (s + 1.702f * y * s * (1.0f - s));
       acc[j] += Elem<T>::round(o[j]);      // dbias sums what the weight-grad GEMM will see
     }
-    Elem<T>::store8(du + r * cols + vc * 8, o);
+    Elem<T>::store8_nt(du + r * cols + vc * 8, o);
   };
   const int64_t stride = gridDim.y;
   int64_t r = blockIdx.y;
@@ -78,16 +78,16 @@ __global__ __launch_bounds__(128) void bias_gelu_bwd_kernel(const T* __restrict_
     float x[kGeluUnroll][8], g[kGeluUnroll][8];
 #pragma unroll
     for (int k = 0; k < kGeluUnroll; ++k) {
-      Elem<T>::load8(u + (r + k * stride) * cols + vc * 8, x[k]);
-      Elem<T>::load8(da + (r + k * stride) * cols + vc * 8, g[k]);
+      Elem<T>::load8_nt(u + (r + k * stride) * cols + vc * 8, x[k]);
+      Elem<T>::load8_nt(da + (r + k * stride) * cols + vc * 8, g[k]);
     }
 #pragma unroll
     for (int k = 0; k < kGeluUnroll; ++k) one_row(x[k], g[k], r + k * stride);
   }
   for (; r < rows; r += stride) {
     float x[8], g[8];
-    Elem<T>::load8(u + r * cols + vc * 8, x);
-    Elem<T>::load8(da + r * cols + vc * 8, g);
+    Elem<T>::load8_nt(u + r * cols + vc * 8, x);
+    Elem<T>::load8_nt(da + r * cols + vc * 8, g);
     one_row(x, g, r);
   }
   if (part) {
