@@ -10,7 +10,6 @@ from collections import OrderedDict
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 import torch.utils.checkpoint as checkpoint
 
 from . import ops
@@ -70,11 +69,11 @@ class ResidualAttentionBlock(nn.Module):
             h = ops.layer_norm(x, l1.weight, l1.bias, l1.eps)
         else:
             x, h = ops.add_layer_norm(res, pend, pend_bias, l1.weight, l1.bias, l1.eps, keep_sum=True)
-        o = ops.causal_attention(F.linear(h, at.in_proj_weight, at.in_proj_bias), at.num_heads)
-        y = F.linear(o, at.out_proj.weight)
+        o = ops.causal_attention(ops.linear(h, at.in_proj_weight, at.in_proj_bias), at.num_heads)
+        y = ops.linear(o, at.out_proj.weight)
         x1, h2 = ops.add_layer_norm(x, y, at.out_proj.bias, l2.weight, l2.bias, l2.eps, keep_sum=True)
-        a = ops.bias_quick_gelu(F.linear(h2, self.mlp.c_fc.weight), self.mlp.c_fc.bias)
-        return x1, F.linear(a, self.mlp.c_proj.weight), self.mlp.c_proj.bias
+        a = ops.bias_quick_gelu(ops.linear(h2, self.mlp.c_fc.weight), self.mlp.c_fc.bias)
+        return x1, ops.linear(a, self.mlp.c_proj.weight), self.mlp.c_proj.bias
 
     def forward(self, x: torch.Tensor, use_checkpoint=False):
         """Reference signature: x is [L, N, D] (openai_model.py:206-216)."""
