@@ -69,7 +69,8 @@ class ResidualAttentionBlock(nn.Module):
             h = ops.layer_norm(x, l1.weight, l1.bias, l1.eps)
         else:
             x, h = ops.add_layer_norm(res, pend, pend_bias, l1.weight, l1.bias, l1.eps, keep_sum=True)
-        o = ops.causal_attention(ops.linear(h, at.in_proj_weight, at.in_proj_bias), at.num_heads)
+        o = ops.causal_attention(ops.linear(h, at.in_proj_weight, at.in_proj_bias.detach()), at.num_heads,
+                                 bias=at.in_proj_bias)
         y = ops.linear(o, at.out_proj.weight)
         x1, h2 = ops.add_layer_norm(x, y, at.out_proj.bias, l2.weight, l2.bias, l2.eps, keep_sum=True)
         a = ops.bias_quick_gelu(ops.linear(h2, self.mlp.c_fc.weight), self.mlp.c_fc.bias)

@@ -298,9 +298,24 @@ def embed_tokens(pe, cls_token, pos_embed, temporal_embed, frames, n_per_frame):
 # --------------------------------------------------------------------------------------------------
 # attention cores
 # --------------------------------------------------------------------------------------------------
+def _qkv_bias_grad(dqkv, dout, dtype):
+    """d(bias) of the qkv Linear that feeds an attention core = column sums of dqkv, without reading the k and v
+    thirds: every softmax row sums to 1, so sum_rows(dv) = sum_rows(dout) exactly, and the scores do not change when a
+    constant vector is added to every key, so sum_rows(dk) = 0. Only the q third is reduced from dqkv itself
+    (2/3 of the bytes of the plain reduction saved on q|k|v, 1/3 read back from dout)."""
+    D = dout.shape[-1]
+    db = torch.zeros(3 * D, dtype=torch.float32, device=dqkv.device)
+    db[:D] = dqkv.reshape(-1, 3 * D)[:, :D].sum(0, dtype=torch.float32)
+    db[2 * D:] = dout.reshape(-1, D).sum(0, dtype=torch.float32)
+    return db.to(dtype)
+
+
 class _DividedAttnFn(torch.autograd.Function):
+    """`bias` (optional): the bias of the qkv Linear that produced `qkv` (already added there; the caller hands the
+    Linear a detached copy). It takes no part in the forward; its gradient comes from _qkv_bias_grad."""
+
     @staticmethod
-    def forward(ctx, qkv, frames, n_per_frame, heads, mode):
+    def forward(ctx, qkv, bias, frames, n_per_frame, heads, mode):
         qkv = qkv.contiguous()
         C.require_device(qkv)
         B, T, D3 = qkv.shape
@@ -310,20 +325,21 @@ class _DividedAttnFn(torch.autograd.Function):
                                       f'(head dim must be 64), frames={frames}, patches/frame={n_per_frame}')
         out, lse = divided_attn_fwd_raw(qkv, frames, n_per_frame, heads, mode)
         ctx.save_for_backward(qkv, out, lse)
-        ctx.cfg = (B, frames, n_per_frame, heads, mode)
+        ctx.cfg = (B, frames, n_per_frame, heads, mode, None if bias is None else bias.dtype)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         qkv, out, lse = ctx.saved_tensors
-        B, Fr, N, H, mode = ctx.cfg
+        B, Fr, N, H, mode, bdt = ctx.cfg
         dout = dout.contiguous()
         dqkv = torch.empty_like(qkv)
         ws = C.workspace('divided_attn_bwd', B * H, 1 + Fr * N, qkv.device)
         C.check(C.lib().lvl_divided_attn_bwd(C.ptr(qkv), C.ptr(out), C.ptr(dout), C.ptr(lse), C.ptr(dqkv), C.ptr(ws),
                                              B, Fr, N, H, mode, C.dtype_code(qkv), C.stream_ptr()),
                 'lvl_divided_attn_bwd')
-        return dqkv, None, None, None, None
+        db = _qkv_bias_grad(dqkv, dout, bdt) if (bdt is not None and ctx.needs_input_grad[1]) else None
+        return dqkv, db, None, None, None, None
 
 
 def divided_attn_fwd_raw(qkv, frames, n_per_frame, heads, mode):
@@ -337,15 +353,16 @@ def divided_attn_fwd_raw(qkv, frames, n_per_frame, heads, mode):
     return out, lse
 
 
-def divided_attention(qkv, frames, n_per_frame, heads, mode):
-    """mode: 'space' | 'time'. qkv [B,T,3D] -> [B,T,D] (timesformer.py:110-140 between the two Linears)."""
+def divided_attention(qkv, frames, n_per_frame, heads, mode, bias=None):
+    """mode: 'space' | 'time'. qkv [B,T,3D] -> [B,T,D] (timesformer.py:110-140 between the two Linears).
+    bias: see _DividedAttnFn."""
     m = {'space': C.ATTN_SPACE, 'time': C.ATTN_TIME}[mode]
-    return _DividedAttnFn.apply(qkv, frames, n_per_frame, heads, m)
+    return _DividedAttnFn.apply(qkv, bias, frames, n_per_frame, heads, m)
 
 
 class _CausalAttnFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, qkv, heads):
+    def forward(ctx, qkv, bias, heads):
         qkv = qkv.contiguous()
         C.require_device(qkv)
         B, L, D3 = qkv.shape
@@ -357,23 +374,25 @@ class _CausalAttnFn(torch.autograd.Function):
         C.check(C.lib().lvl_causal_attn_fwd(C.ptr(qkv), C.ptr(out), C.ptr(lse), B, L, heads, C.dtype_code(qkv),
                                             C.stream_ptr()), 'lvl_causal_attn_fwd')
         ctx.save_for_backward(qkv, out, lse)
-        ctx.cfg = (B, L, heads)
+        ctx.cfg = (B, L, heads, None if bias is None else bias.dtype)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         qkv, out, lse = ctx.saved_tensors
-        B, L, H = ctx.cfg
+        B, L, H, bdt = ctx.cfg
         dout = dout.contiguous()
         dqkv = torch.empty_like(qkv)
         ws = C.workspace('causal_attn_bwd', B * H, L, qkv.device)
         C.check(C.lib().lvl_causal_attn_bwd(C.ptr(qkv), C.ptr(out), C.ptr(dout), C.ptr(lse), C.ptr(dqkv), C.ptr(ws),
                                             B, L, H, C.dtype_code(qkv), C.stream_ptr()), 'lvl_causal_attn_bwd')
-        return dqkv, None
+        db = _qkv_bias_grad(dqkv, dout, bdt) if (bdt is not None and ctx.needs_input_grad[1]) else None
+        return dqkv, db, None
 
 
-def causal_attention(qkv, heads):
-    return _CausalAttnFn.apply(qkv, heads)
+def causal_attention(qkv, heads, bias=None):
+    """bias: the in_proj bias that produced qkv (see _DividedAttnFn)."""
+    return _CausalAttnFn.apply(qkv, bias, heads)
 
 
 # --------------------------------------------------------------------------------------------------

@@ -165,8 +165,11 @@ class VarAttention(nn.Module):
 
     def core(self, x, mode, frames, n_per_frame):
         """qkv Linear + attention core; returns the pre-projection tensor [B,T,D]."""
-        return ops.divided_attention(ops.linear(x, self.qkv.weight, self.qkv.bias), frames, n_per_frame,
-                                     self.num_heads, mode)
+        bias = self.qkv.bias
+        # the GEMM adds the bias; its gradient is produced next to the attention backward (ops._qkv_bias_grad),
+        # hence the detached copy for the Linear
+        qkv = ops.linear(x, self.qkv.weight, None if bias is None else bias.detach())
+        return ops.divided_attention(qkv, frames, n_per_frame, self.num_heads, mode, bias=bias)
 
     def forward(self, x, einops_from, einops_to, einops_dims):
         mode, k = self._mode(einops_to, einops_dims)

@@ -146,6 +146,18 @@ def _attn_case(B, Fr, N, H, seed):
     return torch.randn(B, T, 3 * D, generator=g) * 1.5, torch.randn(B, T, D, generator=g)
 
 
+def _check_qkv_bias_grad(got, dqkv_oracle, dt):
+    """d(bias) of the qkv Linear = column sums of the oracle's dqkv. The product derives the v third from dout
+    (softmax rows sum to 1) and sets the k third to its exact value 0 (softmax is shift-invariant in the keys)."""
+    want = dqkv_oracle.sum((0, 1))
+    D = want.numel() // 3
+    scale = want.abs().max().item() + 1e-6
+    tol = (3e-2 if dt == torch.bfloat16 else 2e-5) * scale
+    assert (got.cpu() - want).abs().max().item() < tol, ((got.cpu() - want).abs().max().item(), tol)
+    assert want[D:2 * D].abs().max().item() < 1e-4 * scale + 1e-5          # the oracle's own k third: rounding noise
+    assert float(got[D:2 * D].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('mode', ['space', 'time'])
 @pytest.mark.parametrize('B,Fr,N,H', [(2, 3, 5, 2), (2, 2, 49, 3), (3, 1, 7, 2), (2, 16, 4, 1), (1, 4, 196, 2), (1, 2, 256, 12), (1, 4, 196, 16), (2, 8, 33, 3),
@@ -158,10 +170,12 @@ def test_divided_attention_core(dt, mode, B, Fr, N, H):
     oo = O.divided_attention_core(qo, H, Fr, N, mode)
     oo.backward(dout)
     qg = qkv.to(DEV, dt).requires_grad_(True)
-    o = ops.divided_attention(qg, Fr, N, H, mode)
+    bias = torch.zeros(qkv.shape[-1], device=DEV, requires_grad=True)     # stands for the qkv Linear's bias
+    o = ops.divided_attention(qg, Fr, N, H, mode, bias=bias)
     o.backward(dout.to(DEV, dt))
     _close(o, oo.detach(), dt, 2, 'out')
     _close(qg.grad, qo.grad, dt, 6, 'dqkv')
+    _check_qkv_bias_grad(bias.grad, qo.grad, dt)
 
 
 @pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
@@ -175,10 +189,12 @@ def test_causal_attention_core(dt, B, L, H):
     oo = O.causal_attention_core(qo, H)
     oo.backward(dout)
     qg = qkv.to(DEV, dt).requires_grad_(True)
-    o = ops.causal_attention(qg, H)
+    bias = torch.zeros(qkv.shape[-1], device=DEV, requires_grad=True)
+    o = ops.causal_attention(qg, H, bias=bias)
     o.backward(dout.to(DEV, dt))
     _close(o, oo.detach(), dt, 2, 'out')
     _close(qg.grad, qo.grad, dt, 6, 'dqkv')
+    _check_qkv_bias_grad(bias.grad, qo.grad, dt)
 
 
 @pytest.mark.parametrize('case', range(4))
