@@ -44,6 +44,14 @@ template <> struct Vec<4> {
   }
 };
 
+template <> struct Vec<2> {
+  using type = uint32_t;
+  static __device__ __forceinline__ void unpack(const uint32_t& a, float (&v)[2]) {
+    v[0] = __uint_as_float(a << 16); v[1] = __uint_as_float(a & 0xffff0000u);
+  }
+  static __device__ __forceinline__ uint32_t pack(const float (&v)[2]) { return f32x2_to_bf16x2(v[0], v[1]); }
+};
+
 template <int DPL>
 __device__ __forceinline__ float dotp(const float (&a)[DPL], const typename Vec<DPL>::type& b) {
   float v[DPL];
@@ -54,20 +62,22 @@ __device__ __forceinline__ float dotp(const float (&a)[DPL], const typename Vec<
   return s;
 }
 
-// sum over the 64/DPL lanes of one problem (an aligned 8- or 16-lane group inside a DPP row): quad xor 1, xor 2,
-// half-mirror, mirror -- plain VALU DPP operands, no LDS crossbar round trips
+// sum over the 64/DPL lanes of one problem (an aligned 8-, 16- or 32-lane group): quad xor 1, xor 2, half-mirror,
+// mirror are plain VALU DPP operands (no LDS crossbar round trips); only the 32-lane groups of DPL = 2 (many
+// frames: 2 channels per lane keep the F key/value rows in registers) need one cross-row exchange
 template <int DPL>
 __device__ __forceinline__ float group_sum(float v) {
   v += dpp_move<0xB1>(v);
   v += dpp_move<0x4E>(v);
   v += dpp_move<0x141>(v);
-  if (DPL == 4) v += dpp_move<0x140>(v);
+  if (DPL <= 4) v += dpp_move<0x140>(v);
+  if (DPL == 2) v += __shfl_xor(v, 16, 64);
   return v;
 }
 
 // block = (64/DPL) * H * NPB threads; thread group = fixed head h, location slot n_sub
 template <int F, int DPL>
-__global__ __launch_bounds__(256, (F <= 4 ? 4 : 2)) void time_fwd_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
+__global__ __launch_bounds__((DPL == 2 ? 512 : 256), (DPL == 2 ? 1 : (F <= 4 ? 4 : 2))) void time_fwd_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
                                                        float* __restrict__ lse, float* __restrict__ cls_ws, int N,
                                                        int H, int NPB, int NCH, int NC) {
   using V = Vec<DPL>;
@@ -195,7 +205,7 @@ __global__ __launch_bounds__(256, (F <= 4 ? 4 : 2)) void time_fwd_kernel(const u
 // registers (no saved statistics needed, and delta = sum_j P dP needs no O rows: `out` is only read for the cls
 // row), dq/dk/dv rows of the patch tokens are written exactly once. HBM: 5 row reads + 3 row writes per token.
 template <int F, int DPL>
-__global__ __launch_bounds__(256, (F <= 2 ? 4 : (F <= 4 ? 3 : 2))) void time_bwd_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out,
+__global__ __launch_bounds__((DPL == 2 ? 512 : 256), (DPL == 2 ? 1 : (F <= 2 ? 4 : (F <= 4 ? 3 : 2)))) void time_bwd_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out,
                                                        const uint16_t* __restrict__ dout, const float* __restrict__ lse,
                                                        uint16_t* __restrict__ dqkv, float* __restrict__ atom_ws, int N,
                                                        int H, int NPB, int NCH, int NC) {
@@ -365,17 +375,19 @@ __global__ __launch_bounds__(256, (F <= 2 ? 4 : (F <= 4 ? 3 : 2))) void time_bwd
 
 int gcd_int(int a, int b) { return b ? gcd_int(b, a % b) : a; }
 
-constexpr int kDPL = 4;
+// channels per lane: 4 (16 lanes per problem) up to 4 frames, 2 (32 lanes per problem) from 8 frames on, where the
+// F key / value / query / dO rows would not fit the register file at 4 channels per lane
+inline int time_dpl(int F) { return F >= 8 ? 2 : 4; }
 
 struct TimeGeom { int NPB, NCH, NC, block; bool ok; };
 
-TimeGeom time_geometry(int N, int H) {
+TimeGeom time_geometry(int N, int H, int dpl) {
   TimeGeom g{};
-  const int per_n = (64 / kDPL) * H;
+  const int per_n = (64 / dpl) * H;
   g.NPB = 64 / gcd_int(per_n, 64);
   if (per_n * g.NPB < 128) g.NPB *= 2;
   g.block = per_n * g.NPB;
-  g.ok = g.block <= 256;
+  g.ok = g.block <= (dpl == 2 ? 512 : 256);
   int nch = g.NPB * 8;                       // >= 8 locations per thread group: amortise the cls/LDS epilogue
   while ((N + nch - 1) / nch > 64) nch *= 2;  // at most 64 partial records per (b,h)
   g.NCH = nch;
@@ -390,24 +402,25 @@ void lvl_launch_cls_grad_finalize(const float* atom_ws, void* dqkv, int B, int T
 
 bool lvl_time_fast_supported(int F, int N, int H) {
   if (!(F == 1 || F == 2 || F == 3 || F == 4 || F == 8 || F == 16)) return false;
-  return time_geometry(N, H).ok;
+  return time_geometry(N, H, time_dpl(F)).ok;
 }
 
 int lvl_time_fast_fwd(const void* qkv, void* out, float* lse, float* ws, int B, int F, int N, int H, hipStream_t st) {
-  const TimeGeom g = time_geometry(N, H);
+  const int dpl = time_dpl(F);
+  const TimeGeom g = time_geometry(N, H, dpl);
   if (!g.ok) return lvl_fail(LVL_ENOSYS, "time_fast_fwd: unsupported head count %d", H);
-  const size_t shmem = (size_t)g.NPB * H * (64 / kDPL) * (2 + kDPL) * sizeof(float);
+  const size_t shmem = (size_t)g.NPB * H * (64 / dpl) * (2 + dpl) * sizeof(float);
   const dim3 grid((unsigned)(B * g.NC)), block(g.block);
-#define TIME_FWD(FF)                                                                                            \
-  hipLaunchKernelGGL((time_fwd_kernel<FF, kDPL>), grid, block, shmem, st, (const uint16_t*)qkv, (uint16_t*)out, lse, \
+#define TIME_FWD(FF, DD)                                                                                        \
+  hipLaunchKernelGGL((time_fwd_kernel<FF, DD>), grid, block, shmem, st, (const uint16_t*)qkv, (uint16_t*)out, lse, \
                      ws, N, H, g.NPB, g.NCH, g.NC)
   switch (F) {
-    case 1: TIME_FWD(1); break;
-    case 2: TIME_FWD(2); break;
-    case 3: TIME_FWD(3); break;
-    case 4: TIME_FWD(4); break;
-    case 8: TIME_FWD(8); break;
-    case 16: TIME_FWD(16); break;
+    case 1: TIME_FWD(1, 4); break;
+    case 2: TIME_FWD(2, 4); break;
+    case 3: TIME_FWD(3, 4); break;
+    case 4: TIME_FWD(4, 4); break;
+    case 8: TIME_FWD(8, 2); break;
+    case 16: TIME_FWD(16, 2); break;
     default: return lvl_fail(LVL_ENOSYS, "time_fast_fwd: unsupported frame count %d", F);
   }
 #undef TIME_FWD
@@ -418,30 +431,32 @@ int lvl_time_fast_fwd(const void* qkv, void* out, float* lse, float* ws, int B, 
 }
 
 bool lvl_time_fast_bwd_supported(int F, int N, int H) {
-  if (!(F == 1 || F == 2 || F == 3 || F == 4 || F == 8)) return false;
-  return time_geometry(N, H).ok;
+  if (!(F == 1 || F == 2 || F == 3 || F == 4 || F == 8 || F == 16)) return false;
+  return time_geometry(N, H, time_dpl(F)).ok;
 }
 
 // ws layout: delta [B*H*T] f32 (unused here), then atomics [B*H*192] f32
 int lvl_time_fast_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* ws,
                       int B, int F, int N, int H, hipStream_t st) {
-  const TimeGeom g = time_geometry(N, H);
+  const int dpl = time_dpl(F);
+  const TimeGeom g = time_geometry(N, H, dpl);
   if (!g.ok) return lvl_fail(LVL_ENOSYS, "time_fast_bwd: unsupported head count %d", H);
   const int T = 1 + F * N;
   float* atom_ws = ws + (size_t)B * H * T;
   hipError_t e = hipMemsetAsync(atom_ws, 0, (size_t)B * H * 192 * sizeof(float), st);
   if (e != hipSuccess) return lvl_fail(LVL_EHIP, "time_bwd memset: %s", hipGetErrorString(e));
-  const size_t shmem = (size_t)g.NPB * H * (64 / kDPL) * 3 * kDPL * sizeof(float);
+  const size_t shmem = (size_t)g.NPB * H * (64 / dpl) * 3 * dpl * sizeof(float);
   const dim3 grid((unsigned)(B * g.NC)), block(g.block);
-#define TIME_BWD(FF)                                                                                              \
-  hipLaunchKernelGGL((time_bwd_kernel<FF, kDPL>), grid, block, shmem, st, (const uint16_t*)qkv, (const uint16_t*)out, \
+#define TIME_BWD(FF, DD)                                                                                          \
+  hipLaunchKernelGGL((time_bwd_kernel<FF, DD>), grid, block, shmem, st, (const uint16_t*)qkv, (const uint16_t*)out, \
                      (const uint16_t*)dout, lse, (uint16_t*)dqkv, atom_ws, N, H, g.NPB, g.NCH, g.NC)
   switch (F) {
-    case 1: TIME_BWD(1); break;
-    case 2: TIME_BWD(2); break;
-    case 3: TIME_BWD(3); break;
-    case 4: TIME_BWD(4); break;
-    case 8: TIME_BWD(8); break;
+    case 1: TIME_BWD(1, 4); break;
+    case 2: TIME_BWD(2, 4); break;
+    case 3: TIME_BWD(3, 4); break;
+    case 4: TIME_BWD(4, 4); break;
+    case 8: TIME_BWD(8, 2); break;
+    case 16: TIME_BWD(16, 2); break;
     default: return lvl_fail(LVL_ENOSYS, "time_fast_bwd: unsupported frame count %d", F);
   }
 #undef TIME_BWD
