@@ -260,7 +260,7 @@ def main():
                         'traffic_note': 'PMC traffic is of the fc1-shaped launch (N=3072, K=768): 1.626 GB vs '
                                         '1.619 GB algorithmic'}
         line = {
-            'metric': 'clip-text pairs/s (whole node), TSF-B/16 4x224^2 + CLIP text tower, fwd+loss+bwd+AdamW',
+            'metric': f'clip-text pairs/s (whole node), TSF-B/16 {Fr}x{img}^2 + CLIP text tower, fwd+loss+bwd+AdamW',
             'value': round(world * B * args.steps / elapsed, 2), 'unit': 'clip-text pairs/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
