@@ -288,29 +288,32 @@ __global__ __launch_bounds__(256, (VPL * W <= 12 ? (sizeof(T) == 2 ? 3 : 2) : 1)
 }
 
 // out_s[k - s*seg] = sum_p part[p][k] for k in segment s of width seg.
-// 64 columns per workgroup, 4 waves each summing a quarter of the partial slabs (coalesced 256-B rows),
-// merged through LDS: width/64 workgroups instead of width/256 keeps the tail of the backward short.
+// 16 columns per workgroup, 16 thread groups each summing one sixteenth of the partial slabs (64-B row segments),
+// merged through LDS: width/16 workgroups (144 for 3 x 768) instead of width/64 spread this latency-bound tail of
+// the backward over more CUs and shorten each thread's dependent load chain 4x.
 __global__ __launch_bounds__(256) void column_reduce_kernel(const float* __restrict__ part, int nparts, int width,
                                                             int seg, float* __restrict__ out0,
                                                             float* __restrict__ out1, float* __restrict__ out2) {
-  __shared__ float red[4][64];
-  const int col = threadIdx.x & 63, pg = threadIdx.x >> 6;
-  const int k = blockIdx.x * 64 + col;
+  __shared__ float red[16][16];
+  const int col = threadIdx.x & 15, pg = threadIdx.x >> 4;
+  const int k = blockIdx.x * 16 + col;
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
   if (k < width) {
     int p = pg;
-    for (; p + 12 < nparts; p += 16) {
+    for (; p + 48 < nparts; p += 64) {
       a0 += part[(size_t)p * width + k];
-      a1 += part[(size_t)(p + 4) * width + k];
-      a2 += part[(size_t)(p + 8) * width + k];
-      a3 += part[(size_t)(p + 12) * width + k];
+      a1 += part[(size_t)(p + 16) * width + k];
+      a2 += part[(size_t)(p + 32) * width + k];
+      a3 += part[(size_t)(p + 48) * width + k];
     }
-    for (; p < nparts; p += 4) a0 += part[(size_t)p * width + k];
+    for (; p < nparts; p += 16) a0 += part[(size_t)p * width + k];
   }
   red[pg][col] = (a0 + a1) + (a2 + a3);
   __syncthreads();
   if (pg == 0 && k < width) {
-    const float acc = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc += red[i][col];
     const int sg = k / seg;
     float* o = sg == 0 ? out0 : (sg == 1 ? out1 : out2);
     if (o) o[k - sg * seg] = acc;
@@ -339,7 +342,7 @@ int lvl_ln_bwd_parts() { return kLnBwdParts; }
 // out0/out1/out2 receive consecutive `seg`-wide segments of the column sums of part[nparts][width]
 int lvl_launch_column_reduce(const float* part, int nparts, int width, int seg, float* out0, float* out1,
                              float* out2, hipStream_t st) {
-  hipLaunchKernelGGL(column_reduce_kernel, dim3((width + 63) / 64), dim3(256), 0, st, part, nparts, width, seg,
+  hipLaunchKernelGGL(column_reduce_kernel, dim3((width + 15) / 16), dim3(256), 0, st, part, nparts, width, seg,
                      out0, out1, out2);
   LVL_CHECK_LAUNCH("column_reduce");
   return LVL_OK;
