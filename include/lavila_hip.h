@@ -156,6 +156,12 @@ int lvl_ssl_clip_loss_bwd(const void* img_all, const void* txt_all, const int32_
 int lvl_linear_wgrad(const void* dy, const void* x, float* dw, float* dbias, float* ws, int64_t M, int N, int K,
                      int dtype, void* stream);
 
+/* ---- weight staging of a Linear layer under bf16 autocast ----------------------------------------------------
+ * dst[n,k] = bf16(src[n,k]), dst_t[k,n] = bf16(src[n,k]): the cast autocast applies to nn.Linear weights
+ * (main_pretrain.py:491 `amp.autocast`) plus the transposed copy the input-gradient GEMM wants, in one pass.
+ * src: [N,K] f32; dst: [N,K] bf16; dst_t: [K,N] bf16. */
+int lvl_cast_transpose(const float* src, void* dst, void* dst_t, int N, int K, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -194,6 +194,32 @@ inline unsigned grid_for(int64_t total, int block) {
   return (unsigned)g;
 }
 
+// ---- weight staging for the Linear layers: f32 master -> bf16 copy and bf16 transposed copy, one pass --------
+// 32 x 32 tiles through LDS (33-word rows): the row-major copy feeds the forward GEMM, the transposed copy the
+// input-gradient GEMM (both contraction-contiguous). One launch instead of a cast plus a strided transpose copy.
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst,
+                                                             uint16_t* __restrict__ dst_t, int N, int K) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+  const int n0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int n = n0 + ty + i * 8, k = k0 + tx;
+    float v = 0.f;
+    if (n < N && k < K) {
+      v = src[(size_t)n * K + k];
+      dst[(size_t)n * K + k] = f32_to_bf16(v);
+    }
+    tile[ty + i * 8][tx] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = k0 + ty + i * 8, n = n0 + tx;
+    if (n < N && k < K) dst_t[(size_t)k * N + n] = f32_to_bf16(tile[tx][ty + i * 8]);
+  }
+}
+
 }  // namespace
 
 extern "C" int lvl_bias_quickgelu_fwd(const void* u, const float* bias, void* a, int64_t rows, int cols, int dtype,
@@ -269,5 +295,14 @@ extern "C" int lvl_embed_tokens_fwd(const void* pe, const float* cls, const floa
                                                (hipStream_t)stream, (const T*)pe, cls, pos, temporal, (T*)x, B, F, N,
                                                D));
   LVL_CHECK_LAUNCH("embed_tokens_fwd");
+  return LVL_OK;
+}
+
+extern "C" int lvl_cast_transpose(const float* src, void* dst, void* dst_t, int N, int K, void* stream) {
+  LVL_REQUIRE(src && dst && dst_t, "cast_transpose: null pointer");
+  LVL_REQUIRE(N > 0 && K > 0, "cast_transpose: bad shape N=%d K=%d", N, K);
+  hipLaunchKernelGGL(cast_transpose_kernel, dim3((K + 31) / 32, (N + 31) / 32), dim3(256), 0, (hipStream_t)stream, src,
+                     (uint16_t*)dst, (uint16_t*)dst_t, N, K);
+  LVL_CHECK_LAUNCH("cast_transpose");
   return LVL_OK;
 }

@@ -24,6 +24,7 @@ def _f32(p: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
 
 _DGRAD_TN = os.environ.get('LAVILA_DGRAD_TN', '1') != '0'
 _WGRAD_MFMA = os.environ.get('LAVILA_WGRAD_MFMA', '1') != '0'
+_CAST_T = os.environ.get('LAVILA_CAST_T', '1') != '0'
 
 
 def _rows_cols(x: torch.Tensor):
@@ -37,24 +38,34 @@ def _rows_cols(x: torch.Tensor):
 class _LinearFn(torch.autograd.Function):
     """y = x W^T (+ b) for token-major activations [rows, in] with rows ~ 2e5.
 
-    Forward and input-gradient are plain library GEMMs (the input gradient against a transposed weight copy). The weight gradient dW[out,in] = dY^T X contracts over
-    the ~2e5 rows and writes a tiny output (9..36 tiles of 256x256): the library's stream-K kernels reach only
-    0.3-0.9 PF/s there. Splitting the rows into S batches (one bmm, S x more output tiles, all 256 CUs busy)
-    and summing the S partial products in f32 measured 1.3-2.3x faster on MI355X (tools/probe_wgrad.py) with the
-    same rounding error as the single GEMM."""
+    Forward and input-gradient are plain library GEMMs, both with contraction-contiguous operands: the input gradient
+    multiplies by a transposed bf16 weight copy that lvl_cast_transpose produces together with the forward's bf16 copy.
+    The weight gradient dW[out,in] = dY^T X contracts over the ~2e5 rows into a tiny output, a shape library GEMMs
+    handle poorly: it goes to the hand-written MFMA kernel (lvl_linear_wgrad); shapes that kernel does not tile fall
+    back to a split-row batched library GEMM + f32 sum (tools/probe_wgrad.py)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
-        w = weight if weight.dtype == x.dtype else weight.to(x.dtype)
+        wt = None
+        rows = x.numel() // x.shape[-1]
+        if (_DGRAD_TN and _CAST_T and rows >= 32768 and x.dtype == torch.bfloat16 and weight.dtype == torch.float32
+                and weight.is_cuda and weight.is_contiguous() and ctx.needs_input_grad[0]):
+            # bf16 copy for this GEMM and the transposed bf16 copy for the input-gradient GEMM in one pass
+            w = torch.empty_like(weight, dtype=torch.bfloat16)
+            wt = torch.empty(weight.shape[1], weight.shape[0], dtype=torch.bfloat16, device=weight.device)
+            C.check(C.lib().lvl_cast_transpose(C.ptr(weight.detach()), C.ptr(w), C.ptr(wt), weight.shape[0],
+                                               weight.shape[1], C.stream_ptr()), 'lvl_cast_transpose')
+        else:
+            w = weight if weight.dtype == x.dtype else weight.to(x.dtype)
         b = None if bias is None else (bias if bias.dtype == x.dtype else bias.to(x.dtype))
-        ctx.save_for_backward(x, w)
+        ctx.save_for_backward(x, w, wt)
         ctx.meta = (weight.dtype, None if bias is None else bias.dtype)
         with torch.autocast('cuda', enabled=False):
             return torch.nn.functional.linear(x, w, b)
 
     @staticmethod
     def backward(ctx, dy):
-        x, w = ctx.saved_tensors
+        x, w, wt = ctx.saved_tensors
         wdt, bdt = ctx.meta
         with torch.autocast('cuda', enabled=False):
             dy2 = dy.reshape(-1, dy.shape[-1])
@@ -64,7 +75,7 @@ class _LinearFn(torch.autograd.Function):
                 if _DGRAD_TN and dy2.shape[0] >= 32768:
                     # both operands contraction-contiguous ("TN", the layout of the forward GEMM): 8-18 % faster than
                     # dy @ W on MI355X (tools/probe_gemm_layouts.py); the transposed weight copy is ~10 us
-                    dx = torch.nn.functional.linear(dy2, w.t().contiguous()).reshape(x.shape)
+                    dx = torch.nn.functional.linear(dy2, wt if wt is not None else w.t().contiguous()).reshape(x.shape)
                 else:
                     dx = (dy2 @ w).reshape(x.shape)
             dw = db = None

@@ -309,7 +309,8 @@ def test_linear_wgrad_mfma(M, N, K):
     assert none is None and torch.equal(dw2, dw)                     # deterministic (no atomics)
 
 
-@pytest.mark.parametrize('rows,n_in,n_out', [(8192, 768, 2304), (6000, 3072, 768), (5000, 512, 1536), (300, 768, 768)])
+@pytest.mark.parametrize('rows,n_in,n_out', [(8192, 768, 2304), (6000, 3072, 768), (5000, 512, 1536), (300, 768, 768),
+                                             (33000, 768, 800), (40000, 100, 72)])
 def test_linear_layer_bf16_training_path(rows, n_in, n_out):
     """ops.linear as the towers call it under bf16 autocast: forward GEMM, input gradient against the transposed
     weight copy, weight gradient through lvl_linear_wgrad (>= 4096 rows) or the library (fewer), bias gradient --
