@@ -156,6 +156,15 @@ int lvl_ssl_clip_loss_bwd(const void* img_all, const void* txt_all, const int32_
 int lvl_linear_wgrad(const void* dy, const void* x, float* dw, float* dbias, float* ws, int64_t M, int N, int K,
                      int dtype, void* stream);
 
+/* ---- bias gradient of the qkv Linear that feeds an attention core ------------------------------------------------
+ * dbias[3D] = column sums over all rows of the dqkv an attention backward produced (what autograd computes for
+ * `qkv.bias`, timesformer.py:96 / `in_proj_bias`, openai_model.py:196-198) without reading the k and v thirds:
+ * every softmax row sums to 1, so sum_rows(dv) = sum_rows(dout); the scores are invariant to a constant added to
+ * every key, so sum_rows(dk) = 0; only the q third of dqkv is reduced. dqkv: [rows, 3D], dout: [rows, D] dtype;
+ * dbias: [3D] f32. Workspace: lvl_workspace_floats("qkv_bias_grad", rows, D). */
+int lvl_qkv_bias_grad(const void* dqkv, const void* dout, float* dbias, float* ws, int64_t rows, int D, int dtype,
+                      void* stream);
+
 /* ---- weight staging of a Linear layer under bf16 autocast ----------------------------------------------------
  * dst[n,k] = bf16(src[n,k]), dst_t[k,n] = bf16(src[n,k]): the cast autocast applies to nn.Linear weights
  * (main_pretrain.py:491 `amp.autocast`) plus the transposed copy the input-gradient GEMM wants, in one pass.

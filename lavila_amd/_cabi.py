@@ -39,6 +39,7 @@ SIGNATURES = {
     'lvl_ssl_clip_loss_bwd': (_I, [_P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _P, _P, _I, _P]),
     'lvl_linear_wgrad': (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _P]),
     'lvl_cast_transpose': (_I, [_P, _P, _P, _I, _I, _P]),
+    'lvl_qkv_bias_grad': (_I, [_P, _P, _P, _P, _L, _I, _I, _P]),
 }
 
 _lib = None

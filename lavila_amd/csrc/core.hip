@@ -15,6 +15,7 @@ int lvl_fail(int code, const char* fmt, ...) {
 
 int lvl_ln_bwd_parts();
 int lvl_gelu_bwd_row_blocks();
+int lvl_qkv_bias_row_blocks();
 int64_t lvl_wgrad_workspace_floats(int64_t N, int64_t K);
 
 extern "C" const char* lvl_version(void) { return "lavila_hip 0.1 (gfx950)"; }
@@ -27,6 +28,7 @@ extern "C" int64_t lvl_workspace_floats(const char* op, int64_t rows, int64_t co
   if (!strcmp(op, "divided_attn_fwd")) return rows * 64 * 66;   // <= 64 CLS-row partial records per (b,h)
   if (!strcmp(op, "divided_attn_bwd")) return rows * cols + rows * 192;   // delta [B*H, T] + cls-grad atomics
   if (!strcmp(op, "causal_attn_bwd")) return rows * cols;    // delta [B*H, L]
+  if (!strcmp(op, "qkv_bias_grad")) return (int64_t)lvl_qkv_bias_row_blocks() * 2 * cols;   // cols = D
   if (!strcmp(op, "linear_wgrad")) return lvl_wgrad_workspace_floats(rows, cols);   // rows = N (out), cols = K (in); -1: no tiling
   return -1;
 }

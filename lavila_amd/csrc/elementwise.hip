@@ -194,6 +194,40 @@ inline unsigned grid_for(int64_t total, int block) {
   return (unsigned)g;
 }
 
+// ---- d(bias) of a qkv Linear from its attention core's dq and dO rows (see lvl_qkv_bias_grad) -----------------
+// blockIdx.z = 0: the q third of dqkv (row stride 3D), 1: dout (row stride D). Thread = one 8-wide column vector,
+// walks rows with stride gridDim.y, 4 rows in flight; partial slab row = [sums of dq | sums of dout].
+constexpr int kBiasGradRowBlocks = 1024;
+template <typename T>
+__global__ __launch_bounds__(128) void qkv_bias_partial_kernel(const T* __restrict__ dqkv, const T* __restrict__ dout,
+                                                               float* __restrict__ part, int64_t rows, int D) {
+  const int vc = blockIdx.x * blockDim.x + threadIdx.x;
+  if (vc * 8 >= D) return;
+  const int src = blockIdx.z;
+  const T* base = (src == 0 ? dqkv : dout) + vc * 8;
+  const int64_t ld = src == 0 ? 3 * (int64_t)D : D;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int64_t stride = gridDim.y;
+  int64_t r = blockIdx.y;
+  for (; r + 3 * stride < rows; r += 4 * stride) {
+    float x[4][8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) Elem<T>::load8_nt(base + (r + k * stride) * ld, x[k]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += x[k][j];
+  }
+  for (; r < rows; r += stride) {
+    float x[8];
+    Elem<T>::load8_nt(base + r * ld, x);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] += x[j];
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) part[(size_t)blockIdx.y * 2 * D + src * D + vc * 8 + j] = acc[j];
+}
+
 // ---- weight staging for the Linear layers: f32 master -> bf16 copy and bf16 transposed copy, one pass --------
 // 32 x 32 tiles through LDS (33-word rows): the row-major copy feeds the forward GEMM, the transposed copy the
 // input-gradient GEMM (both contraction-contiguous). One launch instead of a cast plus a strided transpose copy.
@@ -305,4 +339,23 @@ extern "C" int lvl_cast_transpose(const float* src, void* dst, void* dst_t, int 
                      (uint16_t*)dst, (uint16_t*)dst_t, N, K);
   LVL_CHECK_LAUNCH("cast_transpose");
   return LVL_OK;
+}
+
+int lvl_qkv_bias_row_blocks() { return kBiasGradRowBlocks; }
+
+extern "C" int lvl_qkv_bias_grad(const void* dqkv, const void* dout, float* dbias, float* ws, int64_t rows, int D,
+                                 int dtype, void* stream) {
+  LVL_REQUIRE(dqkv && dout && dbias && ws, "qkv_bias_grad: null pointer");
+  LVL_REQUIRE(rows >= 0 && D > 0 && D % 8 == 0, "qkv_bias_grad: D=%d must be a multiple of 8", D);
+  LVL_REQUIRE(lvl_aligned16(dqkv) && lvl_aligned16(dout), "qkv_bias_grad: pointers must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(dbias, 0, (size_t)3 * D * sizeof(float), st);      // the k third is exactly 0
+  if (e != hipSuccess) return lvl_fail(LVL_EHIP, "qkv_bias_grad memset: %s", hipGetErrorString(e));
+  if (rows == 0) return LVL_OK;
+  int64_t gy = rows < kBiasGradRowBlocks ? rows : kBiasGradRowBlocks;
+  const dim3 grid((unsigned)((D / 8 + 127) / 128), (unsigned)gy, 2);
+  LVL_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((qkv_bias_partial_kernel<T>), grid, dim3(128), 0, st, (const T*)dqkv,
+                                               (const T*)dout, ws, rows, D));
+  LVL_CHECK_LAUNCH("qkv_bias_grad");
+  return lvl_launch_column_reduce(ws, (int)gy, 2 * D, D, dbias, dbias + 2 * (size_t)D, nullptr, st);
 }

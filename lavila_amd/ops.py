@@ -315,9 +315,11 @@ def _qkv_bias_grad(dqkv, dout, dtype):
     constant vector is added to every key, so sum_rows(dk) = 0. Only the q third is reduced from dqkv itself
     (2/3 of the bytes of the plain reduction saved on q|k|v, 1/3 read back from dout)."""
     D = dout.shape[-1]
-    db = torch.zeros(3 * D, dtype=torch.float32, device=dqkv.device)
-    db[:D] = dqkv.reshape(-1, 3 * D)[:, :D].sum(0, dtype=torch.float32)
-    db[2 * D:] = dout.reshape(-1, D).sum(0, dtype=torch.float32)
+    rows = dout.numel() // D
+    db = torch.empty(3 * D, dtype=torch.float32, device=dqkv.device)
+    ws = C.workspace('qkv_bias_grad', rows, D, dqkv.device)
+    C.check(C.lib().lvl_qkv_bias_grad(C.ptr(dqkv), C.ptr(dout), C.ptr(db), C.ptr(ws), rows, D, C.dtype_code(dqkv),
+                                      C.stream_ptr()), 'lvl_qkv_bias_grad')
     return db.to(dtype)
 
 
