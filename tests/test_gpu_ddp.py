@@ -1,0 +1,95 @@
+"""GPU (-m gpu): the N>1 training path on ONE device -- two ranks share cuda:0 and talk over gloo (which carries CUDA
+tensors through the host), so that DistributedDataParallel + the custom autograd Functions + the text tower's side
+stream + the sharded contrastive loss can be checked where only a single MI355X is available.
+
+Checked: both ranks end with the same parameter gradients (DDP average), and that average equals the oracle's
+gradient of the GLOBAL loss on the rank-ordered concatenated batch: with use_vissl=True every rank hands back W x its
+slice of d(global loss), DDP divides by W, the sum over ranks is the full derivative."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+CFG = dict(img=32, patch=16, frames=2, dim=128, depth=2, heads=2, t_width=128, t_heads=2, t_layers=2, vocab=512,
+           embed=64, batch=3, gated=False)
+
+
+def _inputs(world):
+    from oracle import oracle as O
+    video, tokens = O.synthetic_batch(world * CFG['batch'], CFG['frames'], CFG['img'], seed=21)
+    tokens = tokens.clone()
+    tokens[:, 1:31] = tokens[:, 1:31] % 510 + 1
+    tokens[:, 0], tokens[:, 31] = 510, 511
+    return video, tokens
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+    from helpers import build_model
+    from lavila.models.loss import CLIPLoss
+    from oracle import oracle as O
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    model = build_model(CFG)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict(O.procedural_weights(shapes, seed=3))
+    model.cuda().train()
+    ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], gradient_as_bucket_view=True)
+    crit = CLIPLoss(use_vissl=True, cache_labels=True, rank=rank, world_size=world)
+    video, tokens = _inputs(world)
+    sl = slice(rank * CFG['batch'], (rank + 1) * CFG['batch'])
+    losses = []
+    for _ in range(2):                       # two iterations: the second one reuses DDP's bucket views
+        model.zero_grad(set_to_none=True)
+        out = ddp(video[sl].cuda(), tokens[sl].cuda(), norm_embed=True)
+        ld = crit(out)
+        ld['loss'].backward()
+        losses.append(ld['loss'].item())
+    torch.cuda.synchronize()
+    grads = {k: p.grad.detach().cpu().tolist() for k, p in model.named_parameters()
+             if k in ('visual.blocks.0.timeattn.qkv.weight', 'visual.blocks.1.attn.qkv.bias', 'visual.blocks.1.mlp.fc1.weight',
+                      'transformer.resblocks.0.attn.in_proj_bias', 'transformer.resblocks.1.mlp.c_fc.weight', 'logit_scale',
+                      'visual.cls_token', 'text_projection')}
+    q.put((rank, losses, grads))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ddp_two_ranks_on_one_device_match_global_oracle_gradient():
+    from helpers import build_model
+    from oracle import oracle as O
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, 29811, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+    # oracle: global loss on the concatenated batch, f32 on the CPU
+    model = build_model(CFG)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    w = O.procedural_weights(shapes, seed=3)
+    wo = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in w.items()}
+    video, tokens = _inputs(world)
+    oo = O.clip_forward(video, tokens, wo, CFG['heads'], CFG['t_heads'], norm_embed=True)
+    lo = O.clip_loss(oo['image_embed'], oo['text_embed'], oo['logit_scale'])
+    lo['loss'].backward()
+    for rank, losses, grads in got:
+        assert abs(losses[0] - lo['loss'].item()) < 1e-4 and abs(losses[1] - losses[0]) < 1e-6
+        for k, g in grads.items():
+            g = torch.tensor(g)
+            torch.testing.assert_close(g, wo[k].grad.reshape(g.shape), atol=2e-5, rtol=2e-3, msg=lambda m, k=k: f'{k}: {m}')
+    for k in got[0][2]:                       # DDP: identical on both ranks
+        assert got[0][2][k] == got[1][2][k], k
