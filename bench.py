@@ -52,8 +52,14 @@ def _enable_tuned_gemms():
 
 TUNED_GEMMS = _enable_tuned_gemms()
 
+import warnings  # noqa: E402
+
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
+
+# under DDP the text tower's gradients are produced on the side stream while DDP keeps their AccumulateGrad nodes on
+# the main stream: autograd joins the two (correct, see tests/test_gpu_ddp.py) and says so on every backward
+warnings.filterwarnings('ignore', message="The AccumulateGrad node's stream does not match")
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 (the 2:1-sparsity headline figure is never used)
@@ -162,11 +168,16 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run'
     assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs (there is no CPU path)'
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    dev_index = local_rank % torch.cuda.device_count()      # = local_rank on a full node; lets a 1-GPU box rehearse N>1
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=device)     # RCCL over xGMI
+        backend = os.environ.get('LAVILA_DIST_BACKEND', 'nccl')     # 'nccl' = RCCL over xGMI; 'gloo' only for rehearsals
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from lavila_amd import ops
     from lavila.models.loss import CLIPLoss
@@ -182,7 +193,7 @@ def main():
     img = model.visual.patch_embed.img_size[0]
     net = model
     if world > 1:
-        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank], bucket_cap_mb=200,
+        net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev_index], bucket_cap_mb=200,
                                                         gradient_as_bucket_view=True)
     crit = CLIPLoss(use_vissl=True, cache_labels=True, rank=rank, world_size=world)
     decay = [p for n, p in model.named_parameters() if not (p.ndim < 2 or 'bias' in n or 'ln' in n or 'bn' in n)]
