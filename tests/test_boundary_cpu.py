@@ -28,6 +28,22 @@ def test_cabi_exports_every_declared_symbol():
     assert _cabi.lib().lvl_workspace_floats(b'layernorm_bwd', 10, 768) > 0
 
 
+def test_workspace_queries_are_host_only_and_shape_aware():
+    """lvl_workspace_floats is pure host code: every op the header names answers without a GPU, unknown ops and
+    shapes the weight-gradient kernel cannot tile answer -1 (the caller then keeps the library GEMM)."""
+    from lavila_amd import _cabi
+    ws = _cabi.lib().lvl_workspace_floats
+    for op, r, c in ((b'layernorm_bwd', 10, 768), (b'bias_quickgelu_bwd', 10, 3072), (b'divided_attn_fwd', 24, 785),
+                     (b'divided_attn_bwd', 24, 785), (b'causal_attn_bwd', 16, 77), (b'qkv_bias_grad', 1000, 768)):
+        assert ws(op, r, c) > 0, op
+    assert ws(b'no_such_op', 1, 1) == -1
+    # weight-gradient tilings: (N, K) multiples of 192/288/384 (6x6 wave tiles) or 128/256 (8x4 wave tiles)
+    for n, k in ((768, 768), (2304, 768), (3072, 768), (768, 3072), (1024, 1024), (4096, 1024), (1536, 512), (256, 128)):
+        assert ws(b"linear_wgrad", n, k) >= n * k * 4, (n, k)          # S >= 4 f32 partial tiles (S * tiles ~ 256)
+    for n, k in ((200, 200), (384, 128), (100, 768)):
+        assert ws(b'linear_wgrad', n, k) == -1, (n, k)
+
+
 @pytest.mark.parametrize('name', MODELS)
 def test_state_dict_names_and_shapes_match_reference(name):
     fx = load_golden(f'model_{name}.pt')
