@@ -30,6 +30,7 @@ extern "C" {
 enum { LVL_F32 = 0, LVL_BF16 = 1 };
 enum { LVL_OK = 0, LVL_EINVAL = -22, LVL_ENOSYS = -38, LVL_EHIP = -5 };
 enum { LVL_ATTN_SPACE = 0, LVL_ATTN_TIME = 1 };
+enum { LVL_EPI_BIAS = 0, LVL_EPI_BIAS_QUICKGELU = 1, LVL_EPI_QUICKGELU_BWD = 2 };
 
 /* library identification / diagnostics (host pointers) */
 const char* lvl_version(void);
@@ -146,6 +147,23 @@ int lvl_ssl_clip_loss_bwd(const void* img_all, const void* txt_all, const int32_
                           const float* lse_all, const float* scales3, const float* upstream, float coef,
                           int B, int G, int E, int row0, float* dimg, float* dtxt, int dtype,
                           void* stream);
+
+/* ---- Linear layers: forward and input-gradient GEMMs with fused epilogues -------------------------------------
+ * y[M,N] = epilogue(x[M,K] . w[N,K]^T): both operands bf16, row-major, contraction-contiguous; f32 accumulation.
+ * Forward of every nn.Linear on the path (qkv/proj timesformer.py:95-96,110,142; Mlp fc1/fc2 timesformer.py:47-58;
+ * the Conv2d(k=s=P) contraction timesformer.py:77,83; text in_proj/out_proj/c_fc/c_proj openai_model.py:186-192)
+ * with w = the bf16 weight [out,in]; input gradient dx = dy . wt^T with wt = the transposed bf16 copy [in,out]
+ * that lvl_cast_transpose writes (what autograd computes for the Linear input when loss.backward() runs,
+ * main_pretrain.py:520). bias: [N] f32, nullable. Epilogues:
+ *   LVL_EPI_BIAS             y = acc + bias
+ *   LVL_EPI_BIAS_QUICKGELU   aux_out = u = bf16(acc + bias); y = u * sigmoid(1.702 u)     (fc1 + QuickGELU,
+ *                            timesformer.py:52-54, openai_model.py:177-179; u is kept for the backward)
+ *   LVL_EPI_QUICKGELU_BWD    y = acc * d quickgelu(aux_in); colsum[N] f32 = column sums of y (= d fc1.bias);
+ *                            acc = dA = dY . W2 is the input gradient of fc2, y = d(fc1 output)
+ * aux_out / aux_in: [M,N] bf16. N % 256 == 0 and K % 32 == 0, else LVL_ENOSYS. Workspace (QUICKGELU_BWD only):
+ * lvl_workspace_floats("linear_tn", M, N) floats. */
+int lvl_linear_tn(const void* x, const void* w, const float* bias, void* y, void* aux_out, const void* aux_in,
+                  float* colsum, float* ws, int64_t M, int N, int K, int epilogue, int dtype, void* stream);
 
 /* ---- Linear-layer weight gradient ------------------------------------------------------------------------
  * dW[N,K] = dY[M,N]^T X[M,K], dbias[N] (nullable) = column sums of dY: what torch.autograd computes for the weight

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'liblavila_hip.so')
 
 LVL_F32, LVL_BF16 = 0, 1
 ATTN_SPACE, ATTN_TIME = 0, 1
+EPI_BIAS, EPI_BIAS_QUICKGELU, EPI_QUICKGELU_BWD = 0, 1, 2
 
 _c = ctypes
 _P, _I, _L, _F = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float
@@ -37,6 +38,7 @@ SIGNATURES = {
     'lvl_clip_loss_bwd': (_I, [_P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _P, _P, _I, _P]),
     'lvl_ssl_clip_loss_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P]),
     'lvl_ssl_clip_loss_bwd': (_I, [_P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _P, _P, _I, _P]),
+    'lvl_linear_tn': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
     'lvl_linear_wgrad': (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _P]),
     'lvl_cast_transpose': (_I, [_P, _P, _P, _I, _I, _P]),
     'lvl_qkv_bias_grad': (_I, [_P, _P, _P, _P, _L, _I, _I, _P]),
@@ -90,9 +92,18 @@ def dtype_code(t: torch.Tensor) -> int:
 
 
 def require_device(*tensors):
+    """Every kernel is queued on the CURRENT device's current stream (stream_ptr): tensors must live there."""
+    cur = None
     for t in tensors:
         if t is None:
             continue
+        if t.is_cuda:
+            if cur is None:
+                cur = torch.cuda.current_device()
+            if t.device.index != cur:
+                raise HipExtensionError(
+                    f'lavila_amd: tensor on {t.device} but the current device is cuda:{cur}; call '
+                    'torch.cuda.set_device() (one process per GPU) before running the model')
         if not t.is_cuda:
             raise HipExtensionError(
                 'lavila_amd: tensor on %s -- the HIP kernels need a ROCm device tensor; there is no CPU '

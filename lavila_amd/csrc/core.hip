@@ -17,6 +17,7 @@ int lvl_ln_bwd_parts();
 int lvl_gelu_bwd_row_blocks();
 int lvl_qkv_bias_row_blocks();
 int64_t lvl_wgrad_workspace_floats(int64_t N, int64_t K);
+int64_t lvl_linear_tn_workspace_floats(int64_t M, int64_t N);
 
 extern "C" const char* lvl_version(void) { return "lavila_hip 0.1 (gfx950)"; }
 extern "C" const char* lvl_last_error(void) { return lvl_err_buf; }
@@ -30,5 +31,6 @@ extern "C" int64_t lvl_workspace_floats(const char* op, int64_t rows, int64_t co
   if (!strcmp(op, "causal_attn_bwd")) return rows * cols;    // delta [B*H, L]
   if (!strcmp(op, "qkv_bias_grad")) return (int64_t)lvl_qkv_bias_row_blocks() * 2 * cols;   // cols = D
   if (!strcmp(op, "linear_wgrad")) return lvl_wgrad_workspace_floats(rows, cols);   // rows = N (out), cols = K (in); -1: no tiling
+  if (!strcmp(op, "linear_tn")) return lvl_linear_tn_workspace_floats(rows, cols);   // rows = M, cols = N
   return -1;
 }

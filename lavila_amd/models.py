@@ -117,9 +117,10 @@ class CLIP(nn.Module):
             # The two towers are independent until the loss: the (small) text tower runs on a second HIP stream so that
             # its short kernels fill the tails of the video tower's launches. Autograd replays each tower's backward on
             # the stream its forward ran on and joins the streams at the end of backward().
-            main = torch.cuda.current_stream()
+            main = torch.cuda.current_stream(image.device)
             side = _text_stream(image.device)
             side.wait_stream(main)
+            text.record_stream(side)
             with torch.cuda.stream(side):
                 text_embed = self.encode_text(text, use_checkpoint=use_checkpoint)
                 if norm_embed:
@@ -162,6 +163,10 @@ def load_openai_clip(name, device='cpu'):
     caller keeps its (seeded) initialisation."""
     root = os.environ.get('LAVILA_CLIP_WEIGHTS_DIR')
     if not root:
+        import warnings
+        warnings.warn(f'lavila_amd: OpenAI CLIP weights for {name} are NOT loaded (no network; set '
+                      'LAVILA_CLIP_WEIGHTS_DIR to a directory holding the .pt files): the model keeps its seeded '
+                      'random initialisation, unlike the reference constructor', stacklevel=3)
         return None
     path = os.path.join(root, name.replace('/', '-') + '.pt')
     if not os.path.isfile(path):
@@ -199,6 +204,9 @@ def _clip_openai_timesformer(clip_name, vision_kwargs, vision_width, text_width,
         print(f"=> Loading CLIP ({clip_name}) weights")
         vis = {k[len('visual.'):]: v for k, v in clip_sd.items() if k.startswith('visual.')}
         pretrained_names = set(remap_keys(dict(vis), transformer_layers=vision_layers).keys())
+    if timesformer_freeze_space and clip_sd is None:
+        raise RuntimeError('timesformer_freeze_space=True needs the pretrained CLIP weights (nothing would be frozen '
+                           'without them); set LAVILA_CLIP_WEIGHTS_DIR')
     if timesformer_freeze_space:
         print("=> Freeze the space part in TimeSformer")
         freeze_list, unfreeze_list = [], []

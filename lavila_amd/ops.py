@@ -120,6 +120,29 @@ def linear_wgrad_raw(dy, x, want_dbias: bool, ws_floats: int = -1):
     return dw, db
 
 
+def linear_tn_raw(x, w, bias=None, epilogue=C.EPI_BIAS, aux_in=None):
+    """One lvl_linear_tn call on bf16 tensors: y[M,N] = epilogue(x[M,K] . w[N,K]^T).
+    Returns y (EPI_BIAS), (y, u) (EPI_BIAS_QUICKGELU) or (y, colsum) (EPI_QUICKGELU_BWD)."""
+    C.require_device(x, w, bias, aux_in)
+    M, K = x.shape
+    N = w.shape[0]
+    y = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
+    aux_out = colsum = ws = None
+    if epilogue == C.EPI_BIAS_QUICKGELU:
+        aux_out = torch.empty_like(y)
+    elif epilogue == C.EPI_QUICKGELU_BWD:
+        colsum = torch.empty(N, dtype=torch.float32, device=x.device)
+        ws = C.workspace('linear_tn', M, N, x.device)
+    C.check(C.lib().lvl_linear_tn(C.ptr(x), C.ptr(w), C.ptr(bias), C.ptr(y), C.ptr(aux_out), C.ptr(aux_in),
+                                  C.ptr(colsum), C.ptr(ws), M, N, K, epilogue, C.LVL_BF16, C.stream_ptr()),
+            'lvl_linear_tn')
+    if epilogue == C.EPI_BIAS_QUICKGELU:
+        return y, aux_out
+    if epilogue == C.EPI_QUICKGELU_BWD:
+        return y, colsum
+    return y
+
+
 def linear(x, weight, bias=None):
     """F.linear with the split-row weight gradient. Activation dtype = x.dtype (weights are cast to it)."""
     if torch.is_autocast_enabled() and x.dtype == torch.float32:

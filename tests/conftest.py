@@ -14,6 +14,17 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
+def pytest_collection_modifyitems(config, items):
+    """`gpu` tests need a real device: on a host without one they are skipped (never silently passed)."""
+    import torch
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason='no ROCm device visible (run on the GPU box: pytest -m gpu)')
+    for item in items:
+        if 'gpu' in item.keywords:
+            item.add_marker(skip)
+
+
 @pytest.fixture(scope='session')
 def golden_dir():
     return GOLDEN

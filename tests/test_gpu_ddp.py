@@ -6,6 +6,7 @@ Checked: both ranks end with the same parameter gradients (DDP average), and tha
 gradient of the GLOBAL loss on the rank-ordered concatenated batch: with use_vissl=True every rank hands back W x its
 slice of d(global loss), DDP divides by W, the sum over ranks is the full derivative."""
 import os
+import time
 import sys
 
 import pytest
@@ -71,10 +72,23 @@ def test_ddp_two_ranks_on_one_device_match_global_oracle_gradient():
     world = 2
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, 29811, q)) for r in range(world)]
+    import queue
+    import socket
+    with socket.socket() as sk:               # a free rendezvous port (parallel test runs must not collide)
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+    got, deadline = [], time.time() + 600
+    while len(got) < world:                   # poll: a crashed worker fails the test at once instead of blocking
+        try:
+            got.append(q.get(timeout=2))
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            assert not dead, f'DDP worker exited with {dead}'
+            assert time.time() < deadline, 'DDP workers timed out'
+    got.sort(key=lambda t: t[0])
     for p in procs:
         p.join(timeout=120)
     # oracle: global loss on the concatenated batch, f32 on the CPU
