@@ -160,7 +160,7 @@ int lvl_ssl_clip_loss_bwd(const void* img_all, const void* txt_all, const int32_
  *                            timesformer.py:52-54, openai_model.py:177-179; u is kept for the backward)
  *   LVL_EPI_QUICKGELU_BWD    y = acc * d quickgelu(aux_in); colsum[N] f32 = column sums of y (= d fc1.bias);
  *                            acc = dA = dY . W2 is the input gradient of fc2, y = d(fc1 output)
- * aux_out / aux_in: [M,N] bf16. N % 256 == 0 and K % 32 == 0, else LVL_ENOSYS. Workspace (QUICKGELU_BWD only):
+ * aux_out / aux_in: [M,N] bf16. N % 256 == 0 and K % 64 == 0 (operands < 4 GiB), else LVL_ENOSYS. Workspace (QUICKGELU_BWD only):
  * lvl_workspace_floats("linear_tn", M, N) floats. */
 int lvl_linear_tn(const void* x, const void* w, const float* bias, void* y, void* aux_out, const void* aux_in,
                   float* colsum, float* ws, int64_t M, int N, int K, int epilogue, int dtype, void* stream);

@@ -12,23 +12,37 @@
 //   2  y = acc * quickgelu'(aux_in) ; column sums of y -> partial slab     backward of the same: fc2's input gradient
 //                                                                          becomes d(fc1 output); sums = d(fc1 bias)
 //
-// Shape of the problem on this path: M = B*T ~ 2e5 rows, N,K in {768, 2304, 3072}: the K = 768 products are close to
-// the HBM ridge (384-614 flop/B), so the design is about streaming X once and never stalling the matrix pipe:
-//   * 256x256 output tile per workgroup of 8 waves (2 along M x 4 along N), a wave owns 128x64 as 4x2 tiles of
-//     v_mfma_f32_32x32x16_bf16 with SWAPPED operands (A = weight rows, B = activation rows): the accumulator then
+// Shape of the problem on this path: M = B*T ~ 2e5 rows, N,K in {768, 2304, 3072}. Measured facts that shaped it
+// (profiles/r02_pmc_gemm_tn_v1_qkv.txt, tools/probe_gemm_trace.py): (1) what the L2 can serve is a number of
+// REQUESTS, so every request must be a full 128-byte line (a K step of 32 = 64-byte rows doubled the requests and
+// ran at 650-930 TF/s); (2) a workgroup that ends after one tile pays ~17 us of launch + first-fetch + store drain
+// per 20-us tile; (3) under this load the chip clocks at 1.3-1.7 GHz (power), so instruction and LDS economy matter
+// as much as stalls. Design:
+//   * PERSISTENT workgroups (one per CU) of 8 waves (2 along M x 4 along N) walk 256x256 output tiles; the K loop
+//     never drains at a tile boundary: the first blocks of the next tile are in flight, and its first operands
+//     already in registers, while the finished tile is stored;
+//   * v_mfma_f32_32x32x16_bf16 with SWAPPED operands (A = weight rows, B = activation rows): the accumulator then
 //     holds, per lane, 4 consecutive output columns of one row, so bias / activation / aux tensors are read and
 //     written as 8- and 16-byte vectors without an LDS transpose of the tile;
-//   * K is walked 32 at a time through a 4-deep ring of LDS stages (X image 256 rows x 64 B | W image 256 rows x
-//     64 B = 32 KiB per stage) filled by LDS-DMA (global_load_lds_dwordx4, no VGPR round trip) running 2-3 steps
-//     ahead; one bare s_barrier per step, placed between the two K=16 halves of a step, so neither fill latency nor
-//     LDS latency separates two steps' MFMAs (the schedule of wgrad_mfma.hip);
-//   * the 16-byte chunks of a row are XOR-permuted inside the image (chunk ^ (-(row/4) & 3), applied to the per-lane
-//     SOURCE address of the DMA and to the fragment reads) so that every ds_read_b128 lane group touches 16 distinct
-//     16-byte slots of the 256-byte bank row: conflict-free for the 32-row fragments;
+//   * K is walked in blocks of 64 (one 128-byte line per operand row). The 128 KiB of LDS are a ring of 8 SLOTS of
+//     128 rows x 128 B: a K block is four slots (X rows 0-127 | X rows 128-255 | W half 0 | W half 1), two blocks are
+//     resident. LDS is only a transit buffer: a wave's share of a slot is read ONCE into registers (X: 64 rows = 8
+//     fragments, W: 32 rows = 4 fragments) and the slot is refilled by LDS-DMA (global_load_lds_dwordx4, no VGPR round
+//     trip) as soon as every wave has consumed it -- 5-6 phases before it is read again;
+//   * a K block is four PHASES, one output quadrant (64 x 32 per wave, 8 MFMAs) each, ordered so that every phase
+//     needs exactly one new operand: P0 X0.W0, P1 X0.W1, P2 X1.W1, P3 X1.W0. All waves run in step with ONE bare
+//     s_barrier per phase; the reads of the NEXT phase's operand and the refill DMAs ride between the MFMAs (one
+//     per MFMA), so no LDS or DMA latency separates two phases and the two waves of a SIMD cover each other;
+//   * the eight 16-byte chunks of a row are XOR-permuted inside a slot (chunk ^ ((row>>1) & 7), applied to the per-lane
+//     SOURCE address of the DMA and to the fragment reads): every ds_read_b128 lane group touches 16 distinct 16-byte
+//     slots of the 256-byte bank row (SQ_LDS_BANK_CONFLICT = 0), and the 8 lanes of a row still fetch one whole line;
+//   * the tile's bias values travel by LDS-DMA too, so the epilogue issues no vector-memory load; its stores stay in
+//     flight across the next tile's first blocks (the vmcnt allowances account for them);
 //   * blockIdx -> tile is XCD-aware (workgroup i runs on XCD i % 8): each XCD owns a contiguous range of the
 //     N-fastest tile order, so the N/256 tiles that read the same 256 rows of X sit behind one L2 and X comes from
 //     HBM once; W (<= 4.7 MB) lives in L2 / Infinity Cache.
 #include <atomic>
+#include <type_traits>
 
 #include "common.h"
 
@@ -40,12 +54,13 @@ typedef __attribute__((ext_vector_type(16))) float gm_f32x16;
 
 namespace {
 
-constexpr int BK = 32;                 // contraction elements per step (two 32x32x16 MFMAs deep)
+constexpr int BK = 64;                 // contraction elements per K block (one 128-byte line per row)
 constexpr int TM = 256, TN = 256;      // workgroup tile
-constexpr int IMG = 256 * BK * 2;      // bytes of one operand image (256 rows x 64 B)
-constexpr int STAGE_B = 2 * IMG;       // X image | W image
-constexpr int NSTAGE = 4;
-constexpr int NI = 4;                  // LDS-DMA fills per wave per step (32 fills of 1 KiB / 8 waves)
+constexpr int SLOT = 128 * 128;        // bytes of one slot: 128 rows x 128 B
+constexpr int NSLOT = 8;               // two K blocks x {X0, X1, W0, W1}
+constexpr int BIAS_OFF = NSLOT * SLOT; // four 1-KiB images of bias[n0 .. n0+255] behind the ring (tile index & 3)
+constexpr int SMEM_B = BIAS_OFF + 4 * 1024;
+enum { S_X0 = 0, S_X1 = 1, S_W0 = 2, S_W1 = 3 };
 
 __device__ __forceinline__ gm_f32x16 mfma32(uint4 a, uint4 b, gm_f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gm_bf16x8, a), __builtin_bit_cast(gm_bf16x8, b),
@@ -74,211 +89,349 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
                                                       const uint16_t* __restrict__ aux_in,
                                                       float* __restrict__ colpart, int64_t M, int N, int K,
                                                       int tiles_n, int ntiles) {
-  extern __shared__ __attribute__((aligned(1024))) uint8_t smem[];      // [NSTAGE][X image | W image]
+  extern __shared__ __attribute__((aligned(1024))) uint8_t smem[];      // [NSLOT][128 rows][128 B]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
-  // XCD-aware tile decode (bijective for any tile count): XCD x = bid % 8 owns a contiguous range of tiles
-  const int bid = blockIdx.x, xcd = bid & 7;
-  const int tq = ntiles >> 3, tr = ntiles & 7;
-  const int pair = (xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq) + (bid >> 3);
-  const int tm = pair / tiles_n, tn = pair - tm * tiles_n;
-  const int64_t m0 = (int64_t)tm * TM;
-  const int n0 = tn * TN;
-  const int nsteps = K / BK;
+  const int nb = K / BK;
+  // PERSISTENT workgroups, one per CU: workgroup b sits on XCD b % 8 and walks the tiles first, first + wpx, ... of
+  // that XCD's contiguous range of the N-fastest tile order (bijective for any tile count): at any time the
+  // workgroups of an XCD work on neighbouring tiles, so the N/256 tiles that read the same rows of X share one L2.
+  const int nx = gridDim.x >= 8 ? 8 : 1;
+  const int bid = blockIdx.x, xcd = bid % nx, wpx = gridDim.x / nx;
+  const int tq = ntiles / nx, tr = ntiles % nx;
+  const int cnt = tq + (xcd < tr ? 1 : 0);
+  if (bid / nx >= cnt) return;
+  const int first = (xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq) + bid / nx;
+  const int my_tiles = (cnt - bid / nx + wpx - 1) / wpx;
 
-  // ---- staging plan ---------------------------------------------------------------------------------------------
-  // Fill f (0..31) of a step covers image rows 16*(f%16) .. +15 of X (f < 16) or W; lane l lands at stage byte
-  // f*1024 + l*16 = row (l>>2), physical chunk (l&3), and therefore fetches the LOGICAL chunk (l&3) ^ g(row).
-  const uint16_t* src[NI];
-  uint32_t dst_off[NI];
+  // ---- LDS-DMA plan -----------------------------------------------------------------------------------------------
+  // A slot is 16 fills of 1 KiB (8 rows x 128 B); wave w issues fills w and w+8 of every slot. Lane l of fill f
+  // lands at slot byte f*1024 + l*16 = slot row 8f + (l>>3), physical chunk l&7, and therefore fetches the LOGICAL
+  // chunk (l&7) ^ ((row>>1)&7) of its row. Slot rows: X slot q = tile rows q*128 + r; W slot q = tile columns
+  // (r>>5)*64 + q*32 + (r&31) (the two 32-column groups of every wave's 64 output columns go to different halves).
+  // Per-lane sources are 32-bit byte offsets relative to the tile; the tile and the K block ride in scalars.
+  uint32_t xrel[4], wrel[2], xclamp;
   {
-    const int r16 = lane >> 2;
-    const int chunk = (lane & 3) ^ ((4 - (lane >> 4)) & 3);
+    const int sub = lane >> 3;
+    const int chunk = (lane & 7) ^ ((4 * wave + (sub >> 1)) & 7);
 #pragma unroll
-    for (int q = 0; q < NI; ++q) {
-      const int f = wave + 8 * (q & 1);
-      const int row = 16 * f + r16;
-      if (q < 2) {
-        int64_t gm = m0 + row;
-        if (gm > M - 1) gm = M - 1;          // tail tile: re-read the last row, its products are never stored
-        src[q] = X + gm * (int64_t)K + chunk * 8;
-        dst_off[q] = (uint32_t)(f * 1024);
+    for (int h = 0; h < 2; ++h) {
+      const int lr = 8 * (wave + 8 * h) + sub;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) xrel[q * 2 + h] = (uint32_t)(q * 128 + lr) * (uint32_t)(K * 2) + chunk * 16;
+      wrel[h] = (uint32_t)((lr >> 5) * 64 + (lr & 31)) * (uint32_t)(K * 2) + chunk * 16;
+    }
+    xclamp = (uint32_t)((M - 1) * K * 2) + chunk * 16;       // tail tile: re-read the last row (never stored)
+  }
+  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+  // fetch cursor: the K block the next refills bring in (two blocks ahead of the one being multiplied)
+  int f_i = 0, f_j = 0;
+  uint32_t f_xrow;                 // byte offset of the fetch tile's first X row
+  const char* f_wbase;             // first W row of the fetch tile
+  auto fetch_tile = [&](int i) {
+    const int pair = first + i * wpx;
+    const int tm = pair / tiles_n, tn = pair - tm * tiles_n;
+    f_xrow = (uint32_t)tm * (uint32_t)(TM * K * 2);
+    f_wbase = reinterpret_cast<const char*>(W) + (int64_t)tn * TN * K * 2;
+    if (EPI != 2 && bias != nullptr && wave == 0) {
+      // the tile's 256 bias values travel the same way (one 1-KiB LDS-DMA by wave 0, >= 8 phases before the
+      // epilogue that reads them): the epilogue then issues no vector-memory LOAD, so nothing in it has to wait
+      // for the run-ahead fills or for its own stores
+      const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds0 + BIAS_OFF + (uint32_t)(i & 3) * 1024);
+      const uint32_t off = (uint32_t)lane * 16;
+      const char* base = reinterpret_cast<const char*>(bias + tn * TN);
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(off), "s"(base)
+                   : "memory", "m0");
+    }
+  };
+  auto fetch_advance = [&]() {
+    if (++f_j == nb) {
+      if (f_i + 1 < my_tiles) {
+        f_j = 0;
+        fetch_tile(++f_i);
       } else {
-        src[q] = W + (int64_t)(n0 + row) * K + chunk * 8;
-        dst_off[q] = (uint32_t)(IMG + f * 1024);
+        f_j = nb - 1;              // past the end: keep re-reading the last block (never consumed)
       }
     }
-  }
+  };
   // Fills go through inline asm: the compiler's LDS-DMA alias tracking would otherwise put s_waitcnt vmcnt(0) in
-  // front of every LDS read and drain the run-ahead. Steps issued beyond the last one re-read the last K block.
-  const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
-  int issued = 0;
-  auto issue_loads = [&](int stage) {
-#pragma unroll
-    for (int q = 0; q < NI; ++q) {
-      const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)stage * STAGE_B + dst_off[q]);
-      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(src[q])
-                   : "memory", "m0");
-      if (issued < nsteps - 1) src[q] += BK;
+  // front of every LDS read and drain the run-ahead.
+  auto issue_fill = [&](int type, int par, int h) {
+    const char* base = type < S_W0 ? reinterpret_cast<const char*>(X) + (int64_t)f_j * (BK * 2)
+                                   : f_wbase + (int64_t)f_j * (BK * 2) + (type == S_W1 ? (int64_t)32 * K * 2 : 0);
+    uint32_t off;
+    if (type < S_W0) {
+      off = xrel[type * 2 + h] + f_xrow;
+      off = off < xclamp ? off : xclamp;
+    } else {
+      off = wrel[h];
     }
-    ++issued;
+    const uint32_t m0v =
+        __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)(par + type) * SLOT + (uint32_t)wave * 1024 + h * 8192);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(off), "s"(base)
+                 : "memory", "m0");
+  };
+  auto issue_group = [&](int type, int par) {
+    issue_fill(type, par, 0);
+    issue_fill(type, par, 1);
   };
 
   // ---- fragment addresses -----------------------------------------------------------------------------------------
   // 32x32x16 operand: lane l carries row (l & 31), contraction elements 8*(l>>5) .. +7 of the K=16 slice kk, i.e.
-  // logical chunk 2*kk + (l>>5) of the row's four 16-byte chunks.
+  // logical chunk 2*kk + (l>>5) of the row's eight 16-byte chunks.
   const int r5 = lane & 31, hi = lane >> 5;
-  const int g = (4 - ((r5 >> 2) & 3)) & 3;
-  uint32_t offX[2], offW[2];
+  uint32_t xa[4], wa[4];
 #pragma unroll
-  for (int kk = 0; kk < 2; ++kk) {
-    const int p = (2 * kk + hi) ^ g;
-    offX[kk] = (uint32_t)((wm * 128 + r5) * 64 + p * 16);
-    offW[kk] = (uint32_t)(IMG + (wn * 64 + r5) * 64 + p * 16);
+  for (int kk = 0; kk < 4; ++kk) {
+    const int offk = ((2 * kk + hi) ^ ((r5 >> 1) & 7)) * 16;
+    xa[kk] = (uint32_t)((wm * 64 + r5) * 128 + offk);
+    wa[kk] = (uint32_t)((wn * 32 + r5) * 128 + offk);
   }
-
-  gm_f32x16 acc[2][4];
+  auto read_x = [&](int slot, uint4 (&xf)[8]) {
+    const uint8_t* b = smem + slot * SLOT;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  auto read_frags = [&](const uint8_t* st, int kk, uint4 (&xf)[4], uint4 (&wf)[2]) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) wf[i] = *reinterpret_cast<const uint4*>(st + offW[kk] + i * 2048);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) xf[j] = *reinterpret_cast<const uint4*>(st + offX[kk] + j * 2048);
+      for (int kk = 0; kk < 4; ++kk) xf[mt * 4 + kk] = *reinterpret_cast<const uint4*>(b + xa[kk] + mt * 4096);
   };
-  auto multiply = [&](const uint4 (&xf)[4], const uint4 (&wf)[2]) {
+  auto read_w = [&](int slot, uint4 (&wf)[4]) {
+    const uint8_t* b = smem + slot * SLOT;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int i = 0; i < 2; ++i) acc[i][j] = mfma32(wf[i], xf[j], acc[i][j]);
+    for (int kk = 0; kk < 4; ++kk) wf[kk] = *reinterpret_cast<const uint4*>(b + wa[kk]);
   };
 
-  // Ring schedule, barrier in the MIDDLE of a step. Step s multiplies stage s%4 in two K=16 halves. The first
-  // half's fragments were read during the previous step; while it runs, the second half's fragments are read.
-  // Between the halves: wait until this wave's fills of step s+1 have landed (vmcnt counts them in order; the
-  // fills of step s+2 stay in flight), s_barrier (=> step s+1 is complete for every wave and every wave is done
-  // with stage s-1), issue the fills of step s+3 into the stage step s-1 used, read the first-half fragments of
-  // step s+1, run the second half. The barrier is the bare s_barrier: a fence would drain the run-ahead.
-  uint4 xp[4], wp[2], xq[4], wq[2];
-  issue_loads(0);
-  issue_loads(1);
-  issue_loads(2);
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI) : "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  read_frags(smem, 0, xp, wp);
-  __builtin_amdgcn_sched_barrier(0);
-  int stage = 0;
-  for (int s = 0; s < nsteps; ++s) {
-    const uint8_t* st = smem + stage * STAGE_B;
-    const int nstage = (stage + 1) & (NSTAGE - 1);
-    // sched_barrier(0): the machine scheduler would otherwise sink every fragment read down to its first use
-    // (fewer live registers) and expose the LDS latency four times per step
-    read_frags(st, 1, xq, wq);
-    __builtin_amdgcn_sched_barrier(0);
-    multiply(xp, wp);
-    __builtin_amdgcn_sched_barrier(0);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    issue_loads((stage + NSTAGE - 1) & (NSTAGE - 1));
-    read_frags(smem + nstage * STAGE_B, 0, xp, wp);
-    __builtin_amdgcn_sched_barrier(0);
-    multiply(xq, wq);
-    __builtin_amdgcn_sched_barrier(0);
-    stage = nstage;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the run-ahead fills before this workgroup's LDS is freed
-
-  // ---- epilogue -----------------------------------------------------------------------------------------------------
-  // acc[i][j][4*rq + e] = output row m0 + wm*128 + j*32 + r5, column n0 + wn*64 + i*32 + 8*rq + 4*hi + e
-  const int ncol0 = n0 + wn * 64 + 4 * hi;
-  float csum[32];
-  if (EPI == 2) {
+  gm_f32x16 acc[2][2][2];           // [qm][qn][mt]
+  auto zero_acc = [&]() {
 #pragma unroll
-    for (int c = 0; c < 32; ++c) csum[c] = 0.f;
-  }
+    for (int a = 0; a < 8; ++a)
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int64_t m = m0 + wm * 128 + j * 32 + r5;
-    const bool valid = m < M;
-    const int64_t mrow = valid ? m : M - 1;
-    uint16_t* yrow = Y + mrow * (int64_t)N;
+      for (int r = 0; r < 16; ++r) acc[a >> 2][(a >> 1) & 1][a & 1][r] = 0.f;
+  };
+  auto epilogue = [&](int tm, int tn, int ti) {
+    const uint8_t* bias_img = smem + BIAS_OFF + (ti & 3) * 1024;
+    const int64_t m0 = (int64_t)tm * TM;
+    const int n0 = tn * TN;
+    float csum[32];
+    if (EPI == 2) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      uint2 ypk[4], upk[4];
+      for (int c = 0; c < 32; ++c) csum[c] = 0.f;
+    }
 #pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        const int n = ncol0 + i * 32 + 8 * rq;
-        float v[4];
+    for (int j = 0; j < 4; ++j) {          // row group (qm, mt): 32 rows
+      const int64_t mg = m0 + (j >> 1) * 128 + wm * 64 + (j & 1) * 32;
+      uint4 yv[2][2], uv[2][2];           // [qn][jj]: 16 bytes = columns qn*32 + 16*jj + 8*hi .. +7 of row r5
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * rq + e];
-        if (EPI != 2 && bias != nullptr) {
-          const float4 b = *reinterpret_cast<const float4*>(bias + n);
-          v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+      for (int i = 0; i < 2; ++i) {        // column group qn
+        const gm_f32x16& a16 = acc[j >> 1][i][j & 1];
+        uint2 ypk[4], upk[4];
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+          const int nl = wn * 64 + i * 32 + 8 * rq + 4 * hi;       // column inside the tile
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = a16[4 * rq + e];
+          if (EPI != 2 && bias != nullptr) {
+            const float4 b = *reinterpret_cast<const float4*>(bias_img + nl * 4);
+            v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+          }
+          if (EPI == 1) {
+            upk[rq] = make_uint2(f32x2_to_bf16x2(v[0], v[1]), f32x2_to_bf16x2(v[2], v[3]));
+            // the activation sees the ROUNDED pre-activation (what the reference's bf16 Linear output holds and
+            // what the backward reads back)
+            v[0] = quick_gelu(__uint_as_float(upk[rq].x << 16));
+            v[1] = quick_gelu(__uint_as_float(upk[rq].x & 0xffff0000u));
+            v[2] = quick_gelu(__uint_as_float(upk[rq].y << 16));
+            v[3] = quick_gelu(__uint_as_float(upk[rq].y & 0xffff0000u));
+          }
+          if (EPI == 2) {
+            const int64_t m = mg + r5;
+            const bool valid = m < M;
+            const uint2 ub = *reinterpret_cast<const uint2*>(aux_in + (valid ? m : M - 1) * (int64_t)N + n0 + nl);
+            v[0] *= quick_gelu_grad(__uint_as_float(ub.x << 16));
+            v[1] *= quick_gelu_grad(__uint_as_float(ub.x & 0xffff0000u));
+            v[2] *= quick_gelu_grad(__uint_as_float(ub.y << 16));
+            v[3] *= quick_gelu_grad(__uint_as_float(ub.y & 0xffff0000u));
+            if (valid) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) csum[i * 16 + rq * 4 + e] += v[e];
+            }
+          }
+          ypk[rq] = make_uint2(f32x2_to_bf16x2(v[0], v[1]), f32x2_to_bf16x2(v[2], v[3]));
         }
-        if (EPI == 1) {
-          upk[rq] = make_uint2(f32x2_to_bf16x2(v[0], v[1]), f32x2_to_bf16x2(v[2], v[3]));
-          // the activation sees the ROUNDED pre-activation (what the reference's bf16 Linear output holds and what
-          // the backward reads back)
-          v[0] = quick_gelu(__uint_as_float(upk[rq].x << 16));
-          v[1] = quick_gelu(__uint_as_float(upk[rq].x & 0xffff0000u));
-          v[2] = quick_gelu(__uint_as_float(upk[rq].y << 16));
-          v[3] = quick_gelu(__uint_as_float(upk[rq].y & 0xffff0000u));
-        }
-        if (EPI == 2) {
-          const uint2 ub = *reinterpret_cast<const uint2*>(aux_in + mrow * (int64_t)N + n);
-          v[0] *= quick_gelu_grad(__uint_as_float(ub.x << 16));
-          v[1] *= quick_gelu_grad(__uint_as_float(ub.x & 0xffff0000u));
-          v[2] *= quick_gelu_grad(__uint_as_float(ub.y << 16));
-          v[3] *= quick_gelu_grad(__uint_as_float(ub.y & 0xffff0000u));
-          if (valid) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) csum[i * 16 + rq * 4 + e] += v[e];
+        for (int jj = 0; jj < 2; ++jj) {
+          yv[i][jj] = widen_pair(ypk[2 * jj], ypk[2 * jj + 1]);
+          if (EPI == 1) uv[i][jj] = widen_pair(upk[2 * jj], upk[2 * jj + 1]);
+        }
+      }
+      // 16-byte stores: lower lanes take columns 16*jj .. +7, upper lanes 16*jj + 8 .. +15 of a column group
+      // (an LDS-staged variant that leaves as full 128-byte lines measured no faster: the tail is not line-bound)
+      const int64_t m = mg + r5;
+      if (m < M) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            const int64_t o = m * (int64_t)N + n0 + wn * 64 + i * 32 + 16 * jj + 8 * hi;
+            *reinterpret_cast<uint4*>(Y + o) = yv[i][jj];
+            if (EPI == 1) *reinterpret_cast<uint4*>(aux_out + o) = uv[i][jj];
+          }
+      }
+    }
+    if (EPI == 2) {
+      // column sums over the wave's 128 rows: 32 values per lane, summed over the 32 lanes of each half-wave by a
+      // halving butterfly (31 exchanges): lane r5 ends up with the total of value index c = r5
+      int cnt2 = 16;
+#pragma unroll
+      for (int mask = 16; mask >= 1; mask >>= 1) {
+        const bool up = (lane & mask) != 0;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          if (c < cnt2) {
+            const float lo = csum[c], hv = csum[c + cnt2];
+            const float send = up ? lo : hv, keep = up ? hv : lo;
+            csum[c] = keep + __shfl_xor(send, mask, 64);
           }
         }
-        ypk[rq] = make_uint2(f32x2_to_bf16x2(v[0], v[1]), f32x2_to_bf16x2(v[2], v[3]));
+        cnt2 >>= 1;
       }
-      // 16-byte stores: lower lanes take columns 16*jj .. +7, upper lanes 16*jj + 8 .. +15 of this 32-column group
-      const int nst = n0 + wn * 64 + i * 32 + 8 * hi;
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        const uint4 yv = widen_pair(ypk[2 * jj], ypk[2 * jj + 1]);
-        if (valid) *reinterpret_cast<uint4*>(yrow + nst + 16 * jj) = yv;
-        if (EPI == 1) {
-          const uint4 uv = widen_pair(upk[2 * jj], upk[2 * jj + 1]);
-          if (valid) *reinterpret_cast<uint4*>(aux_out + mrow * (int64_t)N + nst + 16 * jj) = uv;
-        }
-      }
+      const int c = r5;
+      const int col = (c >> 4) * 32 + ((c >> 2) & 3) * 8 + 4 * hi + (c & 3);
+      colpart[(size_t)(tm * 2 + wm) * N + n0 + wn * 64 + col] = csum[0];
     }
+  };
+
+#ifdef GM_TRACE
+  // debug build only (tools/probe_gemm_trace.py): wall-clock stamps (100 MHz) of wave 0 and wave 4 of every workgroup
+  unsigned long long* trace = reinterpret_cast<unsigned long long*>(colpart) + ((size_t)bid * 2 + wm) * 128;
+  int tpos = 0;
+#define GM_STAMP()                                                          \
+  do {                                                                      \
+    if (wn == 0 && lane == 0 && tpos < 64) {                                \
+      trace[64 + tpos] = __builtin_readcyclecounter();                      \
+      trace[tpos++] = wall_clock64();                                       \
+    }                                                                       \
+  } while (0)
+#else
+#define GM_STAMP() do { } while (0)
+#endif
+  GM_STAMP();
+  uint4 xA[8], xB[8], wA[4], wB[4];
+  fetch_tile(0);
+#pragma unroll
+  for (int b0 = 0; b0 < 2; ++b0) {         // blocks 0 and 1, groups in the order the phases will read them
+    issue_group(S_X0, b0 * 4);
+    issue_group(S_W0, b0 * 4);
+    issue_group(S_W1, b0 * 4);
+    issue_group(S_X1, b0 * 4);
+    fetch_advance();
   }
-  if (EPI == 2) {
-    // column sums over the wave's 128 rows: 32 values per lane, summed over the 32 lanes of each half-wave by a
-    // halving butterfly (31 exchanges): lane r5 ends up with the total of value index c = r5
-    int cnt = 16;
-#pragma unroll
-    for (int mask = 16; mask >= 1; mask >>= 1) {
-      const bool up = (lane & mask) != 0;
-#pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        if (c < cnt) {
-          const float lo = csum[c], hv = csum[c + cnt];
-          const float send = up ? lo : hv, keep = up ? hv : lo;
-          csum[c] = keep + __shfl_xor(send, mask, 64);
-        }
-      }
-      cnt >>= 1;
+  // LOCKSTEP schedule. All 8 waves run the same phase; ONE barrier per phase. A phase = 8 MFMAs per wave with, riding
+  // between them, the fragment reads of the operand the NEXT phase needs and this phase's refill DMAs; the two waves
+  // of a SIMD interleave freely inside a phase, so one wave's LDS / DMA issue hides under the other's MFMAs:
+  //   P0 = X0.W0  reads W1(j)            no refill
+  //   P1 = X0.W1  reads X1(j)            refills X0(j), W0(j) <- block j+2   (both consumed in P0)
+  //   P2 = X1.W1  reads X0(j+1)          refills W1(j)        <- block j+2   (consumed in P1)
+  //   P3 = X1.W0  reads W0(j+1)          refills X1(j)        <- block j+2   (consumed in P2)
+  // (W0 fragment k is re-read right after its last use in P3.) A slot is refilled only after a barrier that follows
+  // the phase in which every wave CONSUMED its fragments (the compiler's lgkmcnt wait in front of the consuming MFMA
+  // is the completion of the read), and is read again 5-6 phases after the refill. Before each barrier a wave waits
+  // until the fills of the slot the next phase reads have landed: fills return in order, so "all but the N newest
+  // vector-memory operations" with N = the operations issued after that slot's fills (10 / 8 / 10 / 10 for P0..P3;
+  // the bias image and the epilogue's stores only make the wait stricter). The barrier is the bare s_barrier: a
+  // fence would drain the run-ahead fills.
+#define GM_BAR(N)                                                     \
+  do {                                                                \
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");          \
+    __builtin_amdgcn_s_barrier();                                     \
+    asm volatile("" ::: "memory");                                    \
+    __builtin_amdgcn_sched_barrier(0);                                \
+  } while (0)
+  // 8 MFMAs; after MFMA k: rd(k) (one fragment read) and dm(k) (one refill DMA or nothing)
+#define GM_PHASE(xf, wf, c, rd, dm)                                                                       \
+  do {                                                                                                    \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                    \
+      _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) {                                                  \
+        c[mt] = mfma32(wf[kk], xf[mt * 4 + kk], c[mt]);                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+        rd(kk * 2 + mt);                                                                                  \
+        dm(kk * 2 + mt);                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                \
+      }                                                                                                   \
+    }                                                                                                     \
+  } while (0)
+  GM_BAR(12);                            // X0 and W0 of block 0 have landed
+  read_x(S_X0, xA);
+  read_w(S_W0, wA);
+  __builtin_amdgcn_sched_barrier(0);
+  GM_STAMP();
+  zero_acc();
+  int par = 0;
+  // One K block = four phases. A0 / A1 are added to the vmcnt allowance of the barriers in front of P0,P1 / P2,P3:
+  // vector-memory operations retire in issue order, so in the first block(s) after an epilogue -- while the slot a
+  // barrier waits for was still filled BEFORE that epilogue -- the epilogue's NS result stores sit between the
+  // awaited fills and the newer ones and may stay in flight (waiting for them to be acknowledged would cost every
+  // tile ~2 us of idle matrix pipe).
+  constexpr int NS = EPI == 1 ? 32 : 16;
+  auto k_block = [&](auto a0_, auto a1_) {
+    constexpr int A0 = decltype(a0_)::value, A1 = decltype(a1_)::value;
+    const uint8_t* sb = smem + par * SLOT;
+    const uint8_t* sbn = smem + (par ^ 4) * SLOT;
+    auto rd_w1 = [&](int k) { if (k < 4) wB[k] = *reinterpret_cast<const uint4*>(sb + S_W1 * SLOT + wa[k]); };
+    auto rd_x1 = [&](int k) { xB[k] = *reinterpret_cast<const uint4*>(sb + S_X1 * SLOT + xa[k & 3] + (k >> 2) * 4096); };
+    auto rd_x0 = [&](int k) { xA[k] = *reinterpret_cast<const uint4*>(sbn + S_X0 * SLOT + xa[k & 3] + (k >> 2) * 4096); };
+    // W0 of the next block: fragment kk is free once both MFMAs of step kk have been issued (k = 2*kk + 1)
+    auto rd_w0 = [&](int k) { if (k & 1) wA[k >> 1] = *reinterpret_cast<const uint4*>(sbn + S_W0 * SLOT + wa[k >> 1]); };
+    auto dm_none = [&](int) {};
+    auto dm_x0w0 = [&](int k) {
+      if (k == 0) issue_fill(S_X0, par, 0);
+      if (k == 2) issue_fill(S_X0, par, 1);
+      if (k == 4) issue_fill(S_W0, par, 0);
+      if (k == 6) issue_fill(S_W0, par, 1);
+    };
+    auto dm_w1 = [&](int k) {
+      if (k == 1) issue_fill(S_W1, par, 0);
+      if (k == 5) issue_fill(S_W1, par, 1);
+    };
+    auto dm_x1 = [&](int k) {
+      if (k == 0) issue_fill(S_X1, par, 0);
+      if (k == 4) issue_fill(S_X1, par, 1);
+    };
+    GM_BAR(10 + A0);
+    GM_PHASE(xA, wA, acc[0][0], rd_w1, dm_none);
+    GM_BAR(8 + A0);
+    GM_PHASE(xA, wB, acc[0][1], rd_x1, dm_x0w0);
+    GM_BAR(10 + A1);
+    GM_PHASE(xB, wB, acc[1][1], rd_x0, dm_w1);
+    GM_BAR(10 + A1);
+    GM_PHASE(xB, wA, acc[1][0], rd_w0, dm_x1);
+    fetch_advance();
+    par ^= 4;
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using IS = std::integral_constant<int, NS>;
+  for (int i = 0; i < my_tiles; ++i) {
+    int j = 0;
+    if (i > 0) {                     // the slots read here were filled before the previous tile's epilogue
+      k_block(IS{}, IS{});
+      if (nb > 1) k_block(IS{}, I0{});
+      j = 2;
     }
-    const int c = r5;
-    const int col = (c >> 4) * 32 + ((c >> 2) & 3) * 8 + 4 * hi + (c & 3);
-    colpart[(size_t)(tm * 2 + wm) * N + n0 + wn * 64 + col] = csum[0];
+    for (; j < nb; ++j) k_block(I0{}, I0{});
+    // the fills of the next tile's first blocks are in flight and its first X0 / W0 fragments already in registers
+    // while this tile's results leave
+    GM_STAMP();
+    const int pair = first + i * wpx;
+    const int tm = pair / tiles_n;
+    epilogue(tm, pair - tm * tiles_n, i);
+    GM_STAMP();
+    zero_acc();
+    __builtin_amdgcn_sched_barrier(0);
   }
+#undef GM_BAR
+#undef GM_PHASE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the run-ahead fills before this workgroup's LDS is freed
 }
 
 // out[n] = sum_p part[p][n]   (deterministic, no atomics): 64 columns x 16 row lanes per workgroup
@@ -315,17 +468,31 @@ int allow_lds(int bytes) {
   return LVL_OK;
 }
 
+int num_cus() {                    // compute units of the current device (one persistent workgroup each)
+  static std::atomic<int> cached[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  int v = cached[dev & 63].load(std::memory_order_relaxed);
+  if (v == 0) {
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    cached[dev & 63].store(v, std::memory_order_relaxed);
+  }
+  return v;
+}
+
 template <int EPI>
 int launch_tn(const void* x, const void* w, const float* bias, void* y, void* aux_out, const void* aux_in,
               float* colpart, int64_t M, int N, int K, hipStream_t st) {
-  constexpr int shmem = NSTAGE * STAGE_B;
+  constexpr int shmem = SMEM_B;
   const int rc = allow_lds<gemm_tn_kernel<EPI>>(shmem);
   if (rc != LVL_OK) return rc;
   const int tiles_n = N / TN;
   const int64_t tiles_m = (M + TM - 1) / TM;
   const int64_t ntiles = tiles_m * tiles_n;
   if (ntiles > 0x7fffffff) return lvl_fail(LVL_EINVAL, "linear_tn: too many tiles");
-  hipLaunchKernelGGL((gemm_tn_kernel<EPI>), dim3((unsigned)ntiles), dim3(512), shmem, st, (const uint16_t*)x,
+  int grid = (int)(ntiles < num_cus() ? ntiles : num_cus());
+  if (grid >= 8) grid -= grid % 8;          // whole XCD rounds (the kernel maps workgroup b to XCD b % 8)
+  hipLaunchKernelGGL((gemm_tn_kernel<EPI>), dim3((unsigned)grid), dim3(512), shmem, st, (const uint16_t*)x,
                      (const uint16_t*)w, bias, (uint16_t*)y, (uint16_t*)aux_out, (const uint16_t*)aux_in, colpart, M,
                      N, K, tiles_n, (int)ntiles);
   LVL_CHECK_LAUNCH("linear_tn");
@@ -336,6 +503,13 @@ int launch_tn(const void* x, const void* w, const float* bias, void* y, void* au
 
 int64_t lvl_linear_tn_workspace_floats(int64_t M, int64_t N) { return 2 * ((M + TM - 1) / TM) * N; }
 
+#ifdef GM_TRACE
+extern "C" int lvl_linear_tn_trace(const void* x, const void* w, const float* bias, void* y, void* trace, int64_t M,
+                                   int N, int K, void* stream) {
+  return launch_tn<0>(x, w, bias, y, nullptr, nullptr, (float*)trace, M, N, K, (hipStream_t)stream);
+}
+#endif
+
 extern "C" int lvl_linear_tn(const void* x, const void* w, const float* bias, void* y, void* aux_out,
                              const void* aux_in, float* colsum, float* ws, int64_t M, int N, int K, int epilogue,
                              int dtype, void* stream) {
@@ -343,7 +517,9 @@ extern "C" int lvl_linear_tn(const void* x, const void* w, const float* bias, vo
   LVL_REQUIRE(dtype == LVL_BF16, "linear_tn: bf16 operands only (dtype=%d)", dtype);
   LVL_REQUIRE(M > 0 && N > 0 && K > 0, "linear_tn: empty problem");
   if (N % TN != 0 || K % BK != 0)
-    return lvl_fail(LVL_ENOSYS, "linear_tn: no tiling for N=%d K=%d (N %% 256 == 0 and K %% 32 == 0 needed)", N, K);
+    return lvl_fail(LVL_ENOSYS, "linear_tn: no tiling for N=%d K=%d (N %% 256 == 0 and K %% 64 == 0 needed)", N, K);
+  if ((uint64_t)M * K * 2 >= (1ull << 32) || (uint64_t)N * K * 2 >= (1ull << 32))
+    return lvl_fail(LVL_ENOSYS, "linear_tn: operand larger than 4 GiB (32-bit DMA offsets)");
   LVL_REQUIRE(lvl_aligned16(x) && lvl_aligned16(w) && lvl_aligned16(y) && lvl_aligned16(bias) &&
                   lvl_aligned16(aux_out) && lvl_aligned16(aux_in),
               "linear_tn: pointers must be 16-byte aligned");

@@ -73,8 +73,8 @@ class ResidualAttentionBlock(nn.Module):
                                  bias=at.in_proj_bias)
         y = ops.linear(o, at.out_proj.weight)
         x1, h2 = ops.add_layer_norm(x, y, at.out_proj.bias, l2.weight, l2.bias, l2.eps, keep_sum=True)
-        a = ops.bias_quick_gelu(ops.linear(h2, self.mlp.c_fc.weight), self.mlp.c_fc.bias)
-        return x1, ops.linear(a, self.mlp.c_proj.weight), self.mlp.c_proj.bias
+        return x1, ops.mlp_quickgelu(h2, self.mlp.c_fc.weight, self.mlp.c_fc.bias, self.mlp.c_proj.weight), \
+            self.mlp.c_proj.bias
 
     def forward(self, x: torch.Tensor, use_checkpoint=False):
         """Reference signature: x is [L, N, D] (openai_model.py:206-216)."""

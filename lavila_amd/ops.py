@@ -22,9 +22,6 @@ def _f32(p: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     return p.contiguous()
 
 
-_DGRAD_TN = os.environ.get('LAVILA_DGRAD_TN', '1') != '0'
-_WGRAD_MFMA = os.environ.get('LAVILA_WGRAD_MFMA', '1') != '0'
-_CAST_T = os.environ.get('LAVILA_CAST_T', '1') != '0'
 
 
 def _rows_cols(x: torch.Tensor):
@@ -33,74 +30,157 @@ def _rows_cols(x: torch.Tensor):
 
 
 # --------------------------------------------------------------------------------------------------
-# Linear layers: library GEMMs (hipBLASLt through torch), with an MI355X-shaped weight-gradient
+# Linear layers: hand-written MFMA GEMMs (forward / input gradient: lvl_linear_tn, weight gradient: lvl_linear_wgrad)
 # --------------------------------------------------------------------------------------------------
-class _LinearFn(torch.autograd.Function):
-    """y = x W^T (+ b) for token-major activations [rows, in] with rows ~ 2e5.
+_warned = set()
 
-    Forward and input-gradient are plain library GEMMs, both with contraction-contiguous operands: the input gradient
-    multiplies by a transposed bf16 weight copy that lvl_cast_transpose produces together with the forward's bf16 copy.
-    The weight gradient dW[out,in] = dY^T X contracts over the ~2e5 rows into a tiny output, a shape library GEMMs
-    handle poorly: it goes to the hand-written MFMA kernel (lvl_linear_wgrad); shapes that kernel does not tile fall
-    back to a split-row batched library GEMM + f32 sum (tools/probe_wgrad.py)."""
+
+def warn_once(key, msg):
+    """One line per process when a bf16 call leaves the fast kernels (shape not tiled, generic attention, ...)."""
+    if key not in _warned:
+        _warned.add(key)
+        import warnings
+        warnings.warn('lavila_amd: ' + msg, stacklevel=3)
+
+
+def weight_copies(weight: torch.Tensor):
+    """(w, wt): the bf16 copy [out,in] the forward GEMM reads and the transposed bf16 copy [in,out] the input-gradient
+    GEMM reads (both operands of lvl_linear_tn are contraction-contiguous). One lvl_cast_transpose pass per optimizer
+    step: the pair is cached on the parameter and keyed by its version counter, so activation checkpointing's second
+    forward and every backward reuse it."""
+    # a 2-D view of a parameter (the Conv2d weight of the patch embedding) caches on the parameter itself
+    holder = weight._base if weight._base is not None else weight
+    ver, key = weight._version, tuple(weight.shape)
+    cache = getattr(holder, '_lvl_copies', None)
+    if cache is None:
+        cache = holder._lvl_copies = {}
+    c = cache.get(key)
+    if c is not None and c[0] == ver and c[1].device == weight.device:
+        return c[1], c[2]
+    src = weight.detach()
+    if src.dtype == torch.float32 and src.is_contiguous():
+        w = torch.empty_like(src, dtype=torch.bfloat16)
+        wt = torch.empty(src.shape[1], src.shape[0], dtype=torch.bfloat16, device=src.device)
+        C.check(C.lib().lvl_cast_transpose(C.ptr(src), C.ptr(w), C.ptr(wt), src.shape[0], src.shape[1], C.stream_ptr()),
+                'lvl_cast_transpose')
+    else:
+        w = src.to(torch.bfloat16).contiguous()
+        wt = w.t().contiguous()
+    cache[key] = (ver, w, wt)
+    return w, wt
+
+
+def _tn_ok(rows: int, n_out: int, n_in: int) -> bool:
+    """lvl_linear_tn tiles N in 256s and K in 64s (every width of the CLIP_OPENAI_TIMESFORMER_* towers)."""
+    return rows > 0 and n_out % 256 == 0 and n_in % 64 == 0 and rows * max(n_in, n_out) * 2 < (1 << 32)
+
+
+def _wgrad(dy2, x2, wdt):
+    """dW = dy^T x: the MFMA weight-gradient kernel; shapes it does not tile fall back to a library GEMM (logged)."""
+    rows, n_out, n_in = dy2.shape[0], dy2.shape[1], x2.shape[1]
+    ws_floats = -1
+    if (rows >= 32 and dy2.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16 and dy2.is_contiguous()
+            and x2.is_contiguous() and dy2.is_cuda):
+        ws_floats = C.lib().lvl_workspace_floats(b'linear_wgrad', n_out, n_in)
+    if ws_floats >= 0:
+        return linear_wgrad_raw(dy2, x2, False, int(ws_floats))[0].to(wdt)
+    if dy2.dtype == torch.bfloat16 and rows >= 4096:
+        warn_once(('wgrad', n_out, n_in), f'weight gradient [{n_out},{n_in}] falls back to a library GEMM '
+                                          '(lvl_linear_wgrad tiles multiples of 192/288/384 or 128/256)')
+    return (dy2.t() @ x2).to(wdt)
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = x W^T (+ b) for token-major activations [rows, in].
+
+    bf16: forward and input gradient are lvl_linear_tn calls (the input gradient multiplies by the cached transposed
+    weight copy, so both GEMMs read contraction-contiguous operands), the weight gradient is lvl_linear_wgrad. f32
+    (the parity configuration) and widths the kernels do not tile use the library GEMM."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
-        wt = None
-        rows = x.numel() // x.shape[-1]
-        if (_DGRAD_TN and _CAST_T and rows >= 32768 and x.dtype == torch.bfloat16 and weight.dtype == torch.float32
-                and weight.is_cuda and weight.is_contiguous() and ctx.needs_input_grad[0]):
-            # bf16 copy for this GEMM and the transposed bf16 copy for the input-gradient GEMM in one pass
-            w = torch.empty_like(weight, dtype=torch.bfloat16)
-            wt = torch.empty(weight.shape[1], weight.shape[0], dtype=torch.bfloat16, device=weight.device)
-            C.check(C.lib().lvl_cast_transpose(C.ptr(weight.detach()), C.ptr(w), C.ptr(wt), weight.shape[0],
-                                               weight.shape[1], C.stream_ptr()), 'lvl_cast_transpose')
-        else:
-            w = weight if weight.dtype == x.dtype else weight.to(x.dtype)
+        x2 = x.reshape(-1, x.shape[-1])
+        rows, n_in, n_out = x2.shape[0], x2.shape[1], weight.shape[0]
+        own = (x.dtype == torch.bfloat16 and x.is_cuda and _tn_ok(rows, n_out, n_in)
+               and (not ctx.needs_input_grad[0] or _tn_ok(rows, n_in, n_out)))     # the input gradient swaps N and K
+        ctx.own = own
+        ctx.meta = (weight.dtype, None if bias is None else bias.dtype, x.shape)
+        if own:
+            w, wt = weight_copies(weight)
+            ctx.save_for_backward(x2 if x2.is_contiguous() else x2.contiguous(), wt)
+            y = linear_tn_raw(x2 if x2.is_contiguous() else x2.contiguous(), w, _f32(bias), C.EPI_BIAS)
+            return y.reshape(*x.shape[:-1], n_out)
+        if x.dtype == torch.bfloat16 and rows >= 4096:
+            warn_once(('linear', n_out, n_in), f'Linear [{n_out},{n_in}] runs on the library GEMM (lvl_linear_tn needs '
+                                               'out % 256 == 0 and in % 64 == 0)')
+        w = weight if weight.dtype == x.dtype else weight.to(x.dtype)
         b = None if bias is None else (bias if bias.dtype == x.dtype else bias.to(x.dtype))
-        ctx.save_for_backward(x, w, wt)
-        ctx.meta = (weight.dtype, None if bias is None else bias.dtype)
+        ctx.save_for_backward(x2, w)
         with torch.autocast('cuda', enabled=False):
             return torch.nn.functional.linear(x, w, b)
 
     @staticmethod
     def backward(ctx, dy):
-        x, w, wt = ctx.saved_tensors
-        wdt, bdt = ctx.meta
+        x2, w = ctx.saved_tensors                 # own path: w is the TRANSPOSED copy [in, out]
+        wdt, bdt, xshape = ctx.meta
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        dx = dw = db = None
         with torch.autocast('cuda', enabled=False):
-            dy2 = dy.reshape(-1, dy.shape[-1])
-            x2 = x.reshape(-1, x.shape[-1])
-            dx = None
             if ctx.needs_input_grad[0]:
-                if _DGRAD_TN and dy2.shape[0] >= 32768:
-                    # both operands contraction-contiguous ("TN", the layout of the forward GEMM): 8-18 % faster than
-                    # dy @ W on MI355X (tools/probe_gemm_layouts.py); the transposed weight copy is ~10 us
-                    dx = torch.nn.functional.linear(dy2, wt if wt is not None else w.t().contiguous()).reshape(x.shape)
-                else:
-                    dx = (dy2 @ w).reshape(x.shape)
-            dw = db = None
-            want_db = bdt is not None and ctx.needs_input_grad[2]
+                dx = (linear_tn_raw(dy2, w, None, C.EPI_BIAS) if ctx.own else dy2 @ w).reshape(xshape)
             if ctx.needs_input_grad[1]:
-                rows, n_out, n_in = dy2.shape[0], dy2.shape[1], x2.shape[1]
-                ws_floats = -1
-                if (_WGRAD_MFMA and rows >= 4096 and dy2.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16
-                        and dy2.is_contiguous() and x2.is_contiguous() and dy2.is_cuda):
-                    ws_floats = C.lib().lvl_workspace_floats(b'linear_wgrad', n_out, n_in)
-                if ws_floats >= 0:
-                    # dbias stays a separate column reduction: fused (v_dot2 beside the MFMAs) it costs the tiled
-                    # kernel 0.11-0.19 ms, the stand-alone reduction 0.13 ms (tools/probe_wgrad_mfma.py)
-                    dw = linear_wgrad_raw(dy2, x2, False, int(ws_floats))[0].to(wdt)
-                else:
-                    split = 32 if n_out >= 3 * n_in else 16
-                    if rows >= 32768 and rows % split == 0 and dy2.is_contiguous() and x2.is_contiguous():
-                        part = torch.bmm(dy2.view(split, rows // split, n_out).transpose(1, 2),
-                                         x2.view(split, rows // split, n_in))
-                        dw = part.sum(0, dtype=torch.float32).to(wdt)
-                    else:
-                        dw = (dy2.t() @ x2).to(wdt)
-            if want_db:
+                dw = _wgrad(dy2, x2, wdt)
+            if bdt is not None and ctx.needs_input_grad[2]:
                 db = dy2.sum(0, dtype=torch.float32).to(bdt)      # f32 accumulation AND f32 result
         return dx, dw, db
+
+
+class _MlpFn(torch.autograd.Function):
+    """y = fc2(QuickGELU(fc1(x) + b1)) without fc2's bias (the caller leaves it pending for the next fused
+    residual + LayerNorm): timesformer.py:52-58 / openai_model.py:189-192. Two lvl_linear_tn calls forward (the
+    first one adds the bias, applies the activation and keeps the pre-activation u), and in backward the QuickGELU
+    derivative and the fc1 bias gradient are the epilogue of fc2's input-gradient GEMM: the [rows, 4D] tensors are
+    touched by GEMM epilogues only."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2):
+        x2 = x.reshape(-1, x.shape[-1])
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        w1b, w1t = weight_copies(w1)
+        w2b, w2t = weight_copies(w2)
+        a, u = linear_tn_raw(x2, w1b, _f32(b1), C.EPI_BIAS_QUICKGELU)
+        y = linear_tn_raw(a, w2b, None, C.EPI_BIAS)
+        ctx.save_for_backward(x2, u, a, w1t, w2t)
+        ctx.meta = (w1.dtype, None if b1 is None else b1.dtype, w2.dtype, x.shape)
+        return y.reshape(*x.shape[:-1], w2.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, u, a, w1t, w2t = ctx.saved_tensors
+        w1dt, b1dt, w2dt, xshape = ctx.meta
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        du, db1 = linear_tn_raw(dy2, w2t, None, C.EPI_QUICKGELU_BWD, aux_in=u)
+        dw2 = _wgrad(dy2, a, w2dt) if ctx.needs_input_grad[3] else None
+        dx = linear_tn_raw(du, w1t, None, C.EPI_BIAS).reshape(xshape) if ctx.needs_input_grad[0] else None
+        dw1 = _wgrad(du, x2, w1dt) if ctx.needs_input_grad[1] else None
+        return dx, dw1, (db1.to(b1dt) if (b1dt is not None and ctx.needs_input_grad[2]) else None), dw2
+
+
+def mlp_quickgelu(x, w1, b1, w2):
+    """fc2(QuickGELU(fc1(x))) minus fc2's bias; fused GEMM epilogues in bf16, composed kernels otherwise."""
+    if torch.is_autocast_enabled() and x.dtype == torch.float32:
+        x = x.to(torch.get_autocast_dtype('cuda'))
+    rows = x.numel() // x.shape[-1]
+    if (x.dtype == torch.bfloat16 and x.is_cuda and b1 is not None and _tn_ok(rows, w1.shape[0], w1.shape[1])
+            and _tn_ok(rows, w1.shape[1], w1.shape[0]) and _tn_ok(rows, w2.shape[0], w2.shape[1])
+            and _tn_ok(rows, w2.shape[1], w2.shape[0])):
+        return _MlpFn.apply(x, w1, b1, w2)
+    return linear(bias_quick_gelu(linear(x, w1), b1), w2)
 
 
 def linear_wgrad_raw(dy, x, want_dbias: bool, ws_floats: int = -1):
@@ -144,7 +224,8 @@ def linear_tn_raw(x, w, bias=None, epilogue=C.EPI_BIAS, aux_in=None):
 
 
 def linear(x, weight, bias=None):
-    """F.linear with the split-row weight gradient. Activation dtype = x.dtype (weights are cast to it)."""
+    """nn.Linear forward with hand-written forward / input-gradient / weight-gradient GEMMs behind it.
+    Activation dtype = x.dtype (the autocast dtype when autocast is on); parameters stay f32 masters."""
     if torch.is_autocast_enabled() and x.dtype == torch.float32:
         x = x.to(torch.get_autocast_dtype('cuda'))
     return _LinearFn.apply(x, weight, bias)

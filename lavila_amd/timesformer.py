@@ -231,10 +231,11 @@ class SpaceTimeBlock(nn.Module):
         else:
             y_s, b_s = ops.linear(o_s, sa.proj.weight), sa.proj.bias
         x1, h2 = ops.add_layer_norm(x, y_s, b_s, n2.weight, n2.bias, n2.eps, keep_sum=True)
-        a = self.mlp.hidden(h2)
         if self._dropping():
-            return x1, self.drop_path(self.mlp.drop(self.mlp.fc2(a))), None
-        return x1, ops.linear(a, self.mlp.fc2.weight), self.mlp.fc2.bias
+            return x1, self.drop_path(self.mlp.drop(self.mlp.fc2(self.mlp.hidden(h2)))), None
+        if self.mlp._fused_act:
+            return x1, ops.mlp_quickgelu(h2, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight), self.mlp.fc2.bias
+        return x1, ops.linear(self.mlp.hidden(h2), self.mlp.fc2.weight), self.mlp.fc2.bias
 
     def forward(self, x, einops_from_space, einops_to_space, einops_from_time, einops_to_time,
                 time_n, space_f, use_checkpoint=False):

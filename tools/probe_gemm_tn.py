@@ -65,7 +65,7 @@ def check(M, N, K, seed=0):
 
 
 ok = True
-for (M, N, K) in [(256, 256, 96), (1000, 512, 64), (777, 256, 32), (4096, 768, 768), (2049, 2304, 768), (513, 768, 3072)]:
+for (M, N, K) in [(256, 256, 64), (1000, 512, 128), (777, 256, 192), (4096, 768, 768), (2049, 2304, 768), (513, 768, 3072), (70001, 768, 768), (33000, 256, 128), (1800, 256, 64)]:
     ok &= check(M, N, K)
 print('CORRECTNESS', 'OK' if ok else 'FAILED', flush=True)
 

@@ -1,0 +1,12 @@
+// minimal host-side status plumbing for the GM_TRACE debug build of gemm_tn_mfma.hip (tools/probe_gemm_trace.py)
+#include <stdarg.h>
+#include <stdio.h>
+thread_local char lvl_err_buf[512] = "";
+int lvl_fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(lvl_err_buf, sizeof(lvl_err_buf), fmt, ap);
+  va_end(ap);
+  fprintf(stderr, "lvl_fail: %s\n", lvl_err_buf);
+  return code;
+}
