@@ -434,23 +434,20 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the run-ahead fills before this workgroup's LDS is freed
 }
 
-// out[n] = sum_p part[p][n]   (deterministic, no atomics): 64 columns x 16 row lanes per workgroup
-__global__ __launch_bounds__(1024) void colpart_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
-                                                              int P, int N) {
-  __shared__ float red[16][64];
+// out[g][n] = sum over the rows p = g, g + G, g + 2G, ... of part[p][n] (deterministic, no atomics). Launched twice:
+// P rows -> 32 rows, 32 rows -> 1. 64 columns x 4 row lanes per workgroup, grid (N/64, G).
+__global__ __launch_bounds__(256) void colpart_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                             int P, int N) {
+  __shared__ float red[4][64];
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const int n = blockIdx.x * 64 + cx;
+  const int G = gridDim.y, g = blockIdx.y;
   float a = 0.f;
   if (n < N)
-    for (int p = ry; p < P; p += 16) a += part[(size_t)p * N + n];
+    for (int p = g + ry * G; p < P; p += 4 * G) a += part[(size_t)p * N + n];
   red[ry][cx] = a;
   __syncthreads();
-  if (ry == 0 && n < N) {
-    float t = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) t += red[r][cx];
-    out[n] = t;
-  }
+  if (ry == 0 && n < N) out[(size_t)g * N + n] = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
 }
 
 // hipFuncSetAttribute once per (kernel instantiation, device), thread-safe
@@ -501,7 +498,7 @@ int launch_tn(const void* x, const void* w, const float* bias, void* y, void* au
 
 }  // namespace
 
-int64_t lvl_linear_tn_workspace_floats(int64_t M, int64_t N) { return 2 * ((M + TM - 1) / TM) * N; }
+int64_t lvl_linear_tn_workspace_floats(int64_t M, int64_t N) { return (2 * ((M + TM - 1) / TM) + 32) * N; }
 
 #ifdef GM_TRACE
 extern "C" int lvl_linear_tn_trace(const void* x, const void* w, const float* bias, void* y, void* trace, int64_t M,
@@ -536,7 +533,10 @@ extern "C" int lvl_linear_tn(const void* x, const void* w, const float* bias, vo
       const int rc = launch_tn<2>(x, w, nullptr, y, nullptr, aux_in, ws, M, N, K, st);
       if (rc != LVL_OK) return rc;
       const int P = (int)(2 * ((M + TM - 1) / TM));
-      hipLaunchKernelGGL(colpart_reduce_kernel, dim3((unsigned)((N + 63) / 64)), dim3(1024), 0, st, ws, colsum, P, N);
+      float* mid = ws + (size_t)P * N;          // [32][N]
+      hipLaunchKernelGGL(colpart_reduce_kernel, dim3((unsigned)((N + 63) / 64), 32), dim3(256), 0, st, ws, mid, P, N);
+      hipLaunchKernelGGL(colpart_reduce_kernel, dim3((unsigned)((N + 63) / 64), 1), dim3(256), 0, st, mid, colsum, 32,
+                         N);
       LVL_CHECK_LAUNCH("linear_tn_colsum");
       return LVL_OK;
     }

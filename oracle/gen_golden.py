@@ -30,6 +30,9 @@ CONFIGS = {
                      t_layers=2, vocab=512, embed=64, batch=3, gated=False),
     'tiny_p14_gated': dict(img=42, patch=14, frames=3, dim=128, depth=2, heads=2, t_width=64, t_heads=1,
                            t_layers=1, vocab=512, embed=32, batch=2, gated=True),
+    # 16-frame clips (the frame count of BASELINE.json configs[2]): F=16 time attention, T = 1 + 16*4
+    'tiny_f16': dict(img=32, patch=16, frames=16, dim=128, depth=2, heads=2, t_width=128, t_heads=2,
+                     t_layers=2, vocab=512, embed=64, batch=2, gated=False),
     # BASELINE.json configs[0]: CLIP_OPENAI_TIMESFORMER_BASE shape, 2 frames 112^2, batch 4
     'config1_tsfb_112': dict(img=112, patch=16, frames=2, dim=768, depth=12, heads=12, t_width=512,
                              t_heads=8, t_layers=12, vocab=49408, embed=256, batch=4, gated=False),
@@ -105,6 +108,9 @@ def run_model_golden(ref, name, c):
     if c['dim'] <= 128:
         fixture['acts'] = acts
         fixture['grads'] = grads
+        with torch.no_grad():       # narrator-style call: all tokens, not only the cls row (timesformer.py:377-381)
+            fixture['features_all_tokens'] = model.visual.forward_features(
+                video.permute(0, 2, 1, 3, 4).contiguous(), use_checkpoint=False, cls_at_last=False).detach().clone()
     else:      # full-size model: keep per-parameter grad norms + a few full small grads
         fixture['grad_norms'] = {k: g.norm().item() for k, g in grads.items()}
         keep = ['logit_scale', 'visual.cls_token', 'visual.temporal_embed', 'visual.norm.weight',
@@ -167,6 +173,50 @@ def _rank_worker(rank, world, port, use_vissl, q):
            scale.grad.item()))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _gather_rank_worker(rank, world, port, with_grad, q):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    ref = load_reference()
+    g = torch.Generator().manual_seed(55)
+    E, Bl = 8, 3
+    img = torch.randn(world * Bl, E, generator=g)
+    txt = torch.randn(world * Bl, E, generator=g)
+    wa = torch.randn(world, world * Bl, E, generator=g)       # a different downstream weighting on every rank
+    wb = torch.randn(world, world * Bl, E, generator=g)
+    li = img[rank * Bl:(rank + 1) * Bl].clone().requires_grad_(True)
+    lt = txt[rank * Bl:(rank + 1) * Bl].clone().requires_grad_(True)
+    ai, at = ref.loss.gather_features(li, lt, local_loss=False, gather_with_grad=with_grad, rank=rank, world_size=world)
+    ((ai * wa[rank]).sum() + (at * wb[rank]).sum()).backward()
+    q.put((rank, ai.detach().tolist(), at.detach().tolist(), li.grad.tolist(), lt.grad.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def run_gather_features_golden():
+    """gather_features (loss.py:18-43) on 2 gloo ranks, with and without gather_with_grad."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    results = {}
+    port = 29671
+    world = 2
+    for with_grad in (False, True):
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_gather_rank_worker, args=(r, world, port, with_grad, q)) for r in range(world)]
+        port += 1
+        for p in procs:
+            p.start()
+        got = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+        for p in procs:
+            p.join()
+        results[with_grad] = {'all_img': [torch.tensor(g[1]) for g in got], 'all_txt': [torch.tensor(g[2]) for g in got],
+                              'dimg': [torch.tensor(g[3]) for g in got], 'dtxt': [torch.tensor(g[4]) for g in got]}
+        print(f'[golden] gather_features with_grad={with_grad}')
+    torch.save({'E': 8, 'B_local': 3, 'seed': 55, 'world': world, 'results': results},
+               os.path.join(GOLDEN, 'gather_features.pt'))
 
 
 def run_multirank_loss_golden():
@@ -253,9 +303,11 @@ def main():
     ref = load_reference()
     if not only or 'attn' in only:
         run_var_attention_golden(ref)
-    if not only or 'model' in only:
-        for name, c in CONFIGS.items():
+    for name, c in CONFIGS.items():
+        if not only or 'model' in only or f'model:{name}' in only:
             run_model_golden(ref, name, c)
+    if not only or 'gather' in only:
+        run_gather_features_golden()
     if not only or 'multirank' in only:
         run_multirank_loss_golden()
     if not only or 'ssl' in only:

@@ -75,6 +75,37 @@ def test_named_constructor_swallows_driver_kwargs_and_matches_survey_counts():
         models.get_loss('VCLM_OPENAI_TIMESFORMER_BASE_GPT2', args)
 
 
+@pytest.mark.skipif(not reference_available(), reason='reference only exists in the build container')
+@pytest.mark.parametrize('ctor,frames', [('CLIP_OPENAI_TIMESFORMER_LARGE', 4), ('CLIP_OPENAI_TIMESFORMER_LARGE_336PX', 16)])
+def test_large_constructors_match_reference_state_dict(ctor, frames):
+    """models.py:374-491: TSF-L/14 at 224 (N=256) and 336 (N=576): parameter names, shapes, order, and the freeze-space
+    error behaviour when no CLIP weights are present."""
+    import contextlib
+    import io
+    from lavila.models import models
+    from oracle.ref_import import load_reference
+    import torch.nn as nn
+    ref = load_reference()
+    with contextlib.redirect_stdout(io.StringIO()):
+        ours = getattr(models, ctor)(num_frames=frames, pretrained=False, project_embed_dim=256)
+        size = 336 if '336' in ctor else 224
+        rv = ref.timesformer.SpaceTimeTransformer(
+            img_size=size, patch_size=14, embed_dim=1024, depth=24, num_heads=16, num_frames=frames, time_init='zeros',
+            attention_style='frozen-in-time', ln_pre=True, act_layer=ref.openai_model.QuickGELU, is_tanh_gating=False)
+        rv.head = nn.Identity()
+        rv.pre_logits = nn.Identity()
+        rv.fc = nn.Identity()
+        theirs = ref.models.CLIP(embed_dim=256, vision_width=1024, vision_model=rv, context_length=77, vocab_size=49408,
+                                 transformer_width=768, transformer_heads=12, transformer_layers=12, tempearture_init=0.07)
+    a = {k: tuple(v.shape) for k, v in ours.state_dict().items()}
+    b = {k: tuple(v.shape) for k, v in theirs.state_dict().items()}
+    assert list(a) == list(b) and a == b
+    assert ours.visual.patches_per_frame == (size // 14) ** 2
+    with pytest.raises(RuntimeError):      # nothing would be frozen without the pretrained weights: say so
+        with contextlib.redirect_stdout(io.StringIO()):
+            getattr(models, ctor)(num_frames=frames, timesformer_freeze_space=True)
+
+
 def test_no_cpu_fallback():
     from lavila_amd._cabi import HipExtensionError
     fx = load_golden('model_tiny_p16.pt')

@@ -148,3 +148,47 @@ def test_ssl_loss_multirank_requires_vissl():
     with pytest.raises(NotImplementedError):           # loss.py:167-168
         crit({'image_embed': torch.zeros(2, 4), 'text_embed': torch.zeros(2, 4), 'logit_scale': torch.ones(())},
              torch.ones(2, dtype=torch.long))
+
+
+def _gather_worker(rank, world, port, with_grad, fx, q):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from lavila.models.loss import gather_features
+    g = torch.Generator().manual_seed(fx['seed'])
+    E, Bl = fx['E'], fx['B_local']
+    img = torch.randn(world * Bl, E, generator=g)
+    txt = torch.randn(world * Bl, E, generator=g)
+    wa = torch.randn(world, world * Bl, E, generator=g)
+    wb = torch.randn(world, world * Bl, E, generator=g)
+    li = img[rank * Bl:(rank + 1) * Bl].clone().requires_grad_(True)
+    lt = txt[rank * Bl:(rank + 1) * Bl].clone().requires_grad_(True)
+    ai, at = gather_features(li, lt, local_loss=False, gather_with_grad=with_grad, rank=rank, world_size=world)
+    ((ai * wa[rank]).sum() + (at * wb[rank]).sum()).backward()
+    q.put((rank, ai.detach().tolist(), at.detach().tolist(), li.grad.tolist(), lt.grad.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('with_grad', [False, True])
+def test_gather_features_matches_reference(with_grad):
+    """loss.py:18-43 on 2 gloo ranks: rank-ordered concatenation; without gather_with_grad only the own slice carries
+    a gradient, with it every rank's use of the slice flows back (summed over ranks)."""
+    fx = load_golden('gather_features.pt')
+    want = fx['results'][with_grad]
+    world = fx['world']
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29731 + int(with_grad)
+    procs = [ctx.Process(target=_gather_worker, args=(r, world, port, with_grad, fx, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join()
+    for r, ai, at, di, dt in got:
+        torch.testing.assert_close(torch.tensor(ai), want['all_img'][r])
+        torch.testing.assert_close(torch.tensor(at), want['all_txt'][r])
+        torch.testing.assert_close(torch.tensor(di), want['dimg'][r])
+        torch.testing.assert_close(torch.tensor(dt), want['dtxt'][r])

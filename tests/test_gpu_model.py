@@ -28,7 +28,7 @@ def _run(name, norm_embed=True):
     return fx, model, out, ld, crit
 
 
-@pytest.mark.parametrize('name', ['tiny_p16', 'tiny_p14_gated', 'config1_tsfb_112'])
+@pytest.mark.parametrize('name', ['tiny_p16', 'tiny_p14_gated', 'tiny_f16', 'config1_tsfb_112'])
 def test_model_matches_reference_fp32(name):
     fx, model, out, ld, crit = _run(name)
     assert set(out) == {'image_embed', 'text_embed', 'logit_scale'}
@@ -123,3 +123,108 @@ def test_bf16_autocast_training_step_tracks_fp32():
         ref = fx['grads']['visual.blocks.1.mlp.fc1.weight']
         cos = torch.nn.functional.cosine_similarity(g.float().cpu().flatten(), ref.flatten(), dim=0)
         assert cos > 0.98, cos
+
+
+@pytest.mark.parametrize('name', ['tiny_p16', 'tiny_f16'])
+@pytest.mark.parametrize('amp', [False, True])
+def test_all_token_features_cls_at_last_false(name, amp):
+    """forward_features(x, cls_at_last=False) -- the narrator's call (narrator.py:74, timesformer.py:377-381): the final
+    LayerNorm on EVERY token row (the default path normalises the B cls rows only), float32 and bf16 (F=16: the
+    register-tiled 16-frame time kernels)."""
+    fx = load_golden(f'model_{name}.pt')
+    c = fx['config']
+    model = build_model(c)
+    model.load_state_dict(O.procedural_weights(fx['shapes'], seed=fx['weight_seed']), strict=True)
+    model.to(DEV).eval()
+    video, _ = synthetic_inputs(c, seed=fx['input_seed'])
+    x = video.to(DEV).permute(0, 2, 1, 3, 4).contiguous()              # reference signature: [B, F, C, H, W]
+    with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16, enabled=amp):
+        feats = model.visual.forward_features(x, use_checkpoint=False, cls_at_last=False)
+    want = fx['features_all_tokens']
+    assert feats.shape == want.shape
+    if amp:
+        # 2 blocks of bf16 roundings on O(1) LayerNorm outputs: eps*sqrt(10*2) ~ 5e-3 relative, bound 3e-2 absolute
+        torch.testing.assert_close(feats.float().cpu(), want, atol=3e-2, rtol=3e-2)
+    else:
+        torch.testing.assert_close(feats.cpu(), want, atol=2e-4, rtol=1e-3)
+
+
+def test_grad_scaler_step_is_harmless():
+    """main_pretrain.py:490-521 wraps the step in fp16 autocast + GradScaler (initial scale 65536). fp16 autocast is
+    re-entered as bf16; the scaled loss must flow through every hand-written backward (the contrastive backward takes
+    the upstream gradient as a DEVICE scalar) and scaler.step() must apply the same update as an unscaled step."""
+    from lavila.models.loss import CLIPLoss
+    fx = load_golden('model_tiny_p16.pt')
+    c = fx['config']
+    video, tokens = synthetic_inputs(c, seed=fx['input_seed'])
+    results = []
+    for scaled in (False, True):
+        model = build_model(c)
+        model.load_state_dict(O.procedural_weights(fx['shapes'], seed=fx['weight_seed']), strict=True)
+        model.to(DEV).train()
+        opt = torch.optim.SGD(model.parameters(), lr=0.1)
+        scaler = torch.amp.GradScaler('cuda', enabled=scaled)
+        with torch.autocast('cuda', dtype=torch.float16):
+            out = model(video.to(DEV), tokens.to(DEV), norm_embed=True)
+            loss = CLIPLoss()(out)['loss']
+        scaler.scale(loss).backward()
+        if scaled:
+            assert scaler.get_scale() == 65536.0
+            g = model.visual.blocks[0].attn.qkv.weight.grad
+            assert torch.isfinite(g).all() and g.abs().max() > 1.0      # gradients really carry the 2^16 factor
+        scaler.step(opt)
+        scaler.update()
+        assert not scaled or scaler.get_scale() == 65536.0            # no inf/nan was found: the scale is kept
+        results.append({k: p.detach().clone() for k, p in model.named_parameters()})
+    for k in results[0]:
+        torch.testing.assert_close(results[1][k], results[0][k], atol=2e-4, rtol=2e-2, msg=lambda m, k=k: f'{k}: {m}')
+
+
+def test_block_forward_backward_is_hip_graph_capturable():
+    """include/lavila_hip.h promises that every entry point is stream-ordered, allocation-free and capturable: one
+    SpaceTimeBlock (LayerNorm / GEMM / attention / fused MLP kernels, forward AND backward) is captured into a
+    hipGraph and replayed on new data; the replay must equal eager execution bit for bit."""
+    from lavila.models.openai_model import QuickGELU
+    from lavila.models.timesformer import SpaceTimeBlock
+    torch.manual_seed(0)
+    Fr, N, D, H, B = 4, 196, 768, 12, 2
+    blk = SpaceTimeBlock(D, H, qkv_bias=True, act_layer=QuickGELU, time_init='rand').to(DEV)
+    with torch.no_grad():
+        for p in blk.parameters():
+            if p.ndim > 1:
+                p.normal_(0, 0.02)
+    x_static = torch.randn(B, 1 + Fr * N, D, device=DEV, dtype=torch.bfloat16, requires_grad=True)
+    g_static = torch.randn(B, 1 + Fr * N, D, device=DEV, dtype=torch.bfloat16)
+
+    def step():
+        for p in blk.parameters():
+            p.grad = None
+        x_static.grad = None
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            x1, y, b = blk.chain(x_static, None, None, Fr, N)
+            out = x1 + y + b.to(y.dtype)
+        out.backward(g_static)
+        return out
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):             # warm-up outside capture (lazy attribute setting, weight copies)
+        for _ in range(2):
+            step()
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out_static = step()
+    gx_static = x_static.grad
+    gw_static = blk.mlp.fc1.weight.grad
+    # new data into the static buffers, replay, compare with eager on the same data
+    with torch.no_grad():
+        x_static.copy_(torch.randn_like(x_static))
+        g_static.copy_(torch.randn_like(g_static))
+    graph.replay()
+    torch.cuda.synchronize()
+    got = (out_static.clone(), gx_static.clone(), gw_static.clone())
+    out_e = step()
+    torch.cuda.synchronize()
+    assert torch.equal(got[0], out_e) and torch.equal(got[1], x_static.grad)
+    assert torch.equal(got[2], blk.mlp.fc1.weight.grad)

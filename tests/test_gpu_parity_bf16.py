@@ -1,0 +1,238 @@
+"""GPU (-m gpu): parity evidence for the BENCHMARKED configuration -- bf16 activations on the MFMA kernels
+(attention, forward / input-gradient / weight-gradient GEMMs) at TSF-B width and depth -- which the float32 goldens
+of test_gpu_model.py do not exercise (float32 dispatches to the shape-generic kernels).
+
+Two kinds of evidence:
+  * EXACT structural tests: inputs built so that every intermediate value is exactly representable (one-hot
+    attention, small-integer operands). The expected output is then known bit for bit, so an indexing error (a key
+    dropped from one frame, a CLS row attached to the wrong group, a transposed tile) cannot hide under a bf16
+    tolerance;
+  * a whole training step of CLIP_OPENAI_TIMESFORMER_BASE on 4x224^2 clips under bf16 autocast against the float32
+    CPU oracle, every parameter gradient compared by relative L2, with the bound derived from the bf16 unit roundoff
+    (see test_tsfb_bf16_training_step_vs_oracle_f32).
+"""
+import math
+
+import pytest
+import torch
+
+from helpers import oracle_slab_forward
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# exact structural tests of the attention kernels
+# --------------------------------------------------------------------------------------------------------------------
+def _pair_codes(T):
+    """T distinct unordered pairs (a, b), a < b < 64: token j's key is 64*(e_a + e_b)."""
+    pairs = [(a, b) for a in range(64) for b in range(a + 1, 64)]
+    g = torch.Generator().manual_seed(5)
+    perm = torch.randperm(len(pairs), generator=g)[:T]
+    return torch.tensor(pairs)[perm]          # [T, 2]
+
+
+def _one_hot_problem(B, H, T, allowed, seed):
+    """qkv [B,T,3*H*64] bf16 such that query t of head h attends to exactly ONE key target[b,h,t] drawn from
+    allowed(t): q_t = k_target, keys are 64*(e_a+e_b) with distinct pairs, so the scaled score is 1024 on the target,
+    <= 512 elsewhere: exp(-512) underflows to 0 in float32 and the softmax is exactly one-hot. v and dout hold small
+    integers: every dot product and every sum is exact in float32 whatever the summation order."""
+    g = torch.Generator().manual_seed(seed)
+    codes = _pair_codes(T)
+    keys = torch.zeros(T, 64)
+    keys[torch.arange(T), codes[:, 0]] = 64.0
+    keys[torch.arange(T), codes[:, 1]] = 64.0
+    target = torch.empty(B, H, T, dtype=torch.long)
+    for t in range(T):
+        cand = torch.tensor(allowed(t))
+        target[:, :, t] = cand[torch.randint(len(cand), (B, H), generator=g)]
+    q = keys[target]                                                    # [B,H,T,64]
+    k = keys[None, None].expand(B, H, T, 64)
+    v = torch.randint(-4, 5, (B, H, T, 64), generator=g).float()
+    dout = torch.randint(-3, 4, (B, H, T, 64), generator=g).float()
+    pack = lambda x: x.permute(0, 2, 1, 3).reshape(B, T, H * 64)        # noqa: E731  head-major inside a third
+    qkv = torch.cat([pack(q), pack(k), pack(v)], -1).to(torch.bfloat16)
+    out = torch.gather(v, 2, target[..., None].expand(B, H, T, 64))    # out[t] = v[target(t)]
+    dv = torch.zeros(B, H, T, 64).scatter_add_(2, target[..., None].expand(B, H, T, 64), dout)
+    return qkv, pack(dout).to(torch.bfloat16), pack(out), pack(dv), target
+
+
+def _check_exact(qkv, dout, out_want, dv_want, run):
+    D = out_want.shape[-1]
+    x = qkv.to(DEV).requires_grad_(True)
+    out = run(x)
+    out.backward(dout.to(DEV))
+    assert torch.equal(out.float().cpu(), out_want), 'forward: out[t] != v[target(t)] bit for bit'
+    g = x.grad.float().cpu()
+    assert torch.equal(g[..., 2 * D:], dv_want), 'backward: dv != scatter-add of dout over the targets'
+    assert torch.count_nonzero(g[..., :2 * D]) == 0, 'backward: dq / dk must be exactly zero for a one-hot softmax'
+
+
+@pytest.mark.parametrize('mode,B,Fr,N,H', [('space', 2, 4, 196, 12), ('time', 2, 4, 196, 12), ('space', 1, 2, 49, 3),
+                                           ('time', 1, 16, 4, 2), ('time', 1, 8, 9, 2), ('space', 1, 1, 256, 16)])
+def test_divided_attention_one_hot_exact(mode, B, Fr, N, H):
+    """Every query picks one key of its group (cls | same frame | same location; cls query: any token): the bf16 MFMA /
+    register-tiled kernels must reproduce v[target] and the scatter-added dv exactly (timesformer.py:110-140)."""
+    from lavila_amd import ops
+    T = 1 + Fr * N
+
+    def allowed(t):
+        if t == 0:
+            return list(range(T))
+        f, n = divmod(t - 1, N)
+        if mode == 'space':
+            return [0] + [1 + f * N + m for m in range(N)]
+        return [0] + [1 + ff * N + n for ff in range(Fr)]
+    qkv, dout, out_want, dv_want, _ = _one_hot_problem(B, H, T, allowed, seed=11)
+    _check_exact(qkv, dout, out_want, dv_want, lambda x: ops.divided_attention(x, Fr, N, H, mode))
+
+
+@pytest.mark.parametrize('B,L,H', [(3, 77, 8), (2, 32, 8), (2, 130, 12)])
+def test_causal_attention_one_hot_exact(B, L, H):
+    """Causal text attention (openai_model.py:196-198): query t may only pick a key j <= t."""
+    from lavila_amd import ops
+    qkv, dout, out_want, dv_want, _ = _one_hot_problem(B, H, L, lambda t: list(range(t + 1)), seed=13)
+    _check_exact(qkv, dout, out_want, dv_want, lambda x: ops.causal_attention(x, H))
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# exact tests of the MFMA GEMMs (small-integer operands: float32 accumulation is exact, so is the bf16 result)
+# --------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('M,N,K', [(1000, 768, 768), (70001, 256, 192), (513, 2304, 768)])
+def test_linear_tn_exact_on_integer_operands(M, N, K):
+    from lavila_amd import _cabi as C
+    from lavila_amd import ops
+    g = torch.Generator().manual_seed(M)
+    x = torch.randint(-2, 3, (M, K), generator=g).float()
+    w = torch.randint(-1, 2, (N, K), generator=g).float() * (torch.rand(N, K, generator=g) < 0.08)    # sparse +-1
+    b = torch.randint(-8, 9, (N,), generator=g).float()
+    want = x @ w.t() + b                      # |values| <= 2*0.08*K + 8 stays far below 256: exact in bf16
+    assert want.abs().max() < 256
+    y = ops.linear_tn_raw(x.to(DEV).bfloat16(), w.to(DEV).bfloat16(), b.to(DEV), C.EPI_BIAS)
+    assert torch.equal(y.float().cpu(), want)
+
+
+@pytest.mark.parametrize('M,N,K', [(4096, 768, 768), (20000, 384, 192), (33, 2304, 768)])
+def test_linear_wgrad_exact_on_integer_operands(M, N, K):
+    from lavila_amd import ops
+    g = torch.Generator().manual_seed(M + 1)
+    dy = torch.randint(-2, 3, (M, N), generator=g).float() * (torch.rand(M, N, generator=g) < 0.05)
+    x = torch.randint(-2, 3, (M, K), generator=g).float()
+    want = dy.t() @ x                         # integers < 2^24: exact in float32 in any summation order
+    dw, _ = ops.linear_wgrad_raw(dy.to(DEV).bfloat16(), x.to(DEV).bfloat16(), False)
+    assert torch.equal(dw.cpu(), want)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# contrastive slabs at the global batch of BASELINE.json configs[2] (G = 2048 = 8 ranks x 256)
+# --------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_clip_loss_slabs_at_global_batch_2048(dtype):
+    """The last rank's slabs (rows 1792..2047) of a G=2048, E=256 problem: statistics within 1e-3 of the oracle on the
+    same (rounded) embeddings, argmax indices bit-exact, and the loss of the full ring of 8 slabs equals the oracle's."""
+    from lavila_amd import ops
+    G, B, E, row0 = 2048, 256, 256, 1792
+    g = torch.Generator().manual_seed(21)
+    img = O.l2_normalize(torch.randn(G, E, generator=g)).to(dtype)
+    txt = O.l2_normalize(torch.randn(G, E, generator=g)).to(dtype)
+    # make the task learnable-looking: pairs correlate, so the diagonal competes with 2047 negatives
+    txt = O.l2_normalize((0.6 * img.float() + 0.8 * txt.float())).to(dtype)
+    scale = torch.tensor([14.285714])
+    stats, argmax, _ = ops.clip_loss_fwd_raw(img.to(DEV), txt.to(DEV), scale.to(DEV), B, row0)
+    want_stats, want_argmax = oracle_slab_forward(img, txt, scale, B, row0)
+    torch.testing.assert_close(stats.cpu(), want_stats, atol=1e-3, rtol=1e-4)
+    assert torch.equal(argmax.cpu(), want_argmax)                      # int32 indices: bit-exact
+    total = 0.0
+    for r in range(G // B):
+        st, _, _ = ops.clip_loss_fwd_raw(img.to(DEV), txt.to(DEV), scale.to(DEV), B, r * B)
+        total += (st[..., 0] - st[..., 1]).sum().item()                # sum of (lse - diagonal logit) = CE sums
+    loss = total / (2 * G)
+    ref = O.clip_loss(img.float(), txt.float(), scale.reshape(()))['loss'].item()
+    assert abs(loss - ref) < 1e-3, (loss, ref)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# the benchmarked model, bf16 autocast, one training step vs the float32 oracle
+# --------------------------------------------------------------------------------------------------------------------
+def test_tsfb_bf16_training_step_vs_oracle_f32():
+    """CLIP_OPENAI_TIMESFORMER_BASE (12 x 768 video blocks, 12 x 512 text blocks), 4 frames of 224^2, batch 4,
+    bf16 autocast, forward + CLIPLoss + backward on the MFMA kernels, against oracle.clip_forward / clip_loss in
+    float32 on the same float32 master weights.
+
+    Error model. bf16 keeps 8 significand bits: rounding to nearest has relative error <= u = 2^-9, RMS eps = u/sqrt(3)
+    = 1.1e-3. Per video block the token stream is rounded about r = 10 times on its way through (three LayerNorm
+    outputs, qkv x2, attention outputs x2, projection outputs x2, the stored residual sums, the MLP hidden pair), each
+    an independent relative perturbation of a branch that is O(1) of the stream. Over L = 12 blocks they add as a
+    random walk: relative error of the final features ~ eps * sqrt(r * L) = 1.1e-3 * 11 = 1.2e-2; LayerNorm / softmax
+    Lipschitz factors are O(1-2) here, so the unit-norm embeddings are expected within ~1.2-2.5e-2 (relative L2).
+    Bound used: 2.5e-2 (measured 0.9e-2). A logit is 14.3 * <img, txt> with |<img, txt>| <= c: its error is at most
+    14.3 * (e_img + e_txt) * max(c, e) -- here c ~ 0.1 (random towers), i.e. <= 0.07 (bound 0.1, measured 0.015); the
+    loss averages 2B of them (bound 2e-2, measured 5e-6). Gradients cross every block a second time in backward with
+    the same number of roundings, relative error ~ eps * sqrt(2 r L) * (1-2) = 1.7-3.4e-2 per parameter; bound used
+    for EVERY parameter gradient: relative L2 <= 1e-1, with the aggregate (all parameters concatenated) <= 5e-2
+    (measured: aggregate 3.0e-2, median 3.0e-2, worst tensor 4.9e-2 -- the predicted range).
+    Parameters whose true gradient is ~0 (key biases: softmax is invariant to them; masked-out positional rows) are
+    compared absolutely against the gradient scale of their tensor family.
+    Index outputs (labels, argmax of the logits) are compared exactly whenever the oracle's own top-2 logit margin
+    exceeds the logit bound."""
+    import contextlib
+    import io
+    from lavila.models import models
+    from lavila.models.loss import CLIPLoss
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = models.CLIP_OPENAI_TIMESFORMER_BASE(num_frames=4, project_embed_dim=256)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    w = O.procedural_weights(shapes, seed=17)
+    model.load_state_dict(w)
+    model.to(DEV).train()
+    B = 4
+    video, tokens = O.synthetic_batch(B, 4, 224, seed=31)
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        out = model(video.to(DEV), tokens.to(DEV), norm_embed=True)
+        crit = CLIPLoss()
+        ld = crit(out)
+    ld['loss'].backward()
+    dbg = crit.debug_slabs(out)
+    torch.cuda.synchronize()
+
+    torch.set_num_threads(min(32, torch.get_num_threads() or 1))
+    wo = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in w.items()}
+    oo = O.clip_forward(video, tokens, wo, 12, 8, norm_embed=True)
+    lo = O.clip_loss(oo['image_embed'], oo['text_embed'], oo['logit_scale'])
+    lo['loss'].backward()
+
+    def rel(a, b):
+        return ((a.float().cpu() - b).norm() / b.norm().clamp_min(1e-30)).item()
+    e_img, e_txt = rel(out['image_embed'], oo['image_embed'].detach()), rel(out['text_embed'], oo['text_embed'].detach())
+    dlogit = (dbg['logits'][0].cpu() - lo['logits_per_image'].detach()).abs().max().item()
+    dloss = abs(ld['loss'].item() - lo['loss'].item())
+    assert e_img < 2.5e-2 and e_txt < 2.5e-2, (e_img, e_txt)
+    assert dlogit < 0.1 and dloss < 2e-2, (dlogit, dloss)
+    assert torch.equal(dbg['labels'].cpu(), lo['labels'])
+    top2 = lo['logits_per_image'].detach().topk(2, -1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 2 * 0.1
+    assert torch.equal(dbg['pred'][0].cpu()[safe], lo['pred'][safe])
+
+    worst, num, den = [], 0.0, 0.0
+    grads = dict(model.named_parameters())
+    for k, p in wo.items():
+        if not p.requires_grad:
+            continue
+        got, want = grads[k].grad, p.grad
+        assert got is not None and torch.isfinite(got).all(), k
+        d = (got.float().cpu() - want).norm().item()
+        num += d * d
+        den += want.norm().item() ** 2
+        worst.append((d / max(want.norm().item(), 1e-30), d, want.norm().item(), k))
+    agg = math.sqrt(num / den)
+    scale = math.sqrt(den / len(worst))            # RMS gradient norm of a parameter tensor
+    bad = [(r, d, n, k) for r, d, n, k in worst if r > 1e-1 and d > 1e-3 * scale]
+    worst.sort(reverse=True)
+    print(f'[bf16 TSF-B step] rel L2: image_embed {e_img:.2e} text_embed {e_txt:.2e}; max |d logit| {dlogit:.3f}; '
+          f'|d loss| {dloss:.2e}; gradients: aggregate {agg:.2e}, worst {worst[0][0]:.2e} ({worst[0][3]}), '
+          f'median {worst[len(worst) // 2][0]:.2e} over {len(worst)} tensors')
+    assert agg < 5e-2, agg
+    assert not bad, bad[:5]

@@ -7,7 +7,7 @@ from oracle import oracle as O
 from oracle.gen_golden import synthetic_inputs
 from conftest import load_golden
 
-MODELS = ['tiny_p16', 'tiny_p14_gated', 'config1_tsfb_112']
+MODELS = ['tiny_p16', 'tiny_p14_gated', 'tiny_f16', 'config1_tsfb_112']
 
 
 @pytest.mark.parametrize('case', range(4))
@@ -47,6 +47,19 @@ def test_full_model_matches_reference(name):
     if 'grad_norms' in fx:
         for k, n in fx['grad_norms'].items():
             assert abs(w[k].grad.norm().item() - n) <= 2e-3 * n + 1e-7, k
+
+
+@pytest.mark.parametrize('name', ['tiny_p16', 'tiny_f16'])
+def test_all_token_features_match_reference(name):
+    """forward_features(cls_at_last=False) (the narrator's call, timesformer.py:377-381): every token row of the
+    final LayerNorm, not only the cls row."""
+    fx = load_golden(f'model_{name}.pt')
+    c = fx['config']
+    w = O.procedural_weights(fx['shapes'], seed=fx['weight_seed'])
+    video, _ = synthetic_inputs(c, seed=fx['input_seed'])
+    feats = O.vision_tower(video, w, c['heads'], cls_at_last=False)
+    assert feats.shape == (c['batch'], 1 + c['frames'] * (c['img'] // c['patch']) ** 2, c['dim'])
+    torch.testing.assert_close(feats, fx['features_all_tokens'], atol=2e-5, rtol=1e-4)
 
 
 def test_multirank_loss_equals_single_process_on_concatenation():
