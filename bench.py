@@ -11,10 +11,13 @@ One step = forward (TimeSformer-B/16 video tower on 4x224^2 clips + CLIP text to
 weights with the temporal attention randomised so it is live. Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
-  roofline     -- the dominant hand-written kernel: the MFMA weight-gradient GEMM of the Linear layers
-                  (lvl_linear_wgrad, ~19 % of the step), aggregated over all its video-tower launches: algorithmic flops
+  roofline     -- the dominant hand-written kernel: the MFMA forward / input-gradient GEMM of the Linear layers
+                  (lvl_linear_tn, ~55 % of the step), aggregated over all its video-tower launches: algorithmic flops
                   (2*M*N*K per launch) / duration, measured with HIP events on the launch stream inside the timed
-                  region, against the 2.5 PFLOP/s dense bf16 MFMA peak.
+                  region, against the 2.5 PFLOP/s dense bf16 MFMA peak. `traffic` = HBM bytes per launch from rocprofv3
+                  PMC passes of the same command (profiles/r02_traffic_gemm_tn.json: FETCH_SIZE x 2 + WRITE_SIZE averaged
+                  over the step's launches), next to the algorithmic M*(K+N)*2 + N*K*2.
+  roofline_wgrad -- the same for the MFMA weight-gradient GEMM (lvl_linear_wgrad, ~20 % of the step).
   roofline_hbm -- the dominant HBM-bound hand-written kernel (space-mode divided attention forward,
                   lvl_divided_attn_fwd): algorithmic bytes per launch / average duration against 8 TB/s.
   cpu_baseline -- the CPU oracle (oracle/oracle.py, kind "port") timed on this box's host cores on a bounded
@@ -31,26 +34,6 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-
-def _enable_tuned_gemms():
-    """hipBLASLt/rocBLAS solution table for the Linear-layer GEMM shapes of this config, produced once on an
-    MI355X with PyTorch TunableOp (PYTORCH_TUNABLEOP_TUNING=1) and committed under lavila_amd/tuning/. Replay only
-    (no tuning inside the bench); unknown shapes fall back to the library default."""
-    src = os.path.join(ROOT, 'lavila_amd', 'tuning', 'tunableop_gfx950_tsfb_b256.csv')
-    if os.environ.get('LAVILA_NO_TUNED_GEMMS') or not os.path.isfile(src) or 'PYTORCH_TUNABLEOP_ENABLED' in os.environ:
-        return False
-    import shutil
-    import tempfile
-    dev = int(os.environ.get('LOCAL_RANK', '0'))
-    base = os.path.join(tempfile.gettempdir(), f'lavila_tunableop_{os.getpid()}_')
-    shutil.copy(src, f'{base}{dev}.csv')          # TunableOp appends the device ordinal to the file name
-    os.environ['PYTORCH_TUNABLEOP_ENABLED'] = '1'
-    os.environ['PYTORCH_TUNABLEOP_TUNING'] = '0'
-    os.environ['PYTORCH_TUNABLEOP_FILENAME'] = base + '.csv'
-    return True
-
-
-TUNED_GEMMS = _enable_tuned_gemms()
 
 import warnings  # noqa: E402
 
@@ -75,7 +58,7 @@ def parse():
     p.add_argument('--model', default='CLIP_OPENAI_TIMESFORMER_BASE')
     p.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     p.add_argument('--no-cpu-baseline', action='store_true')
-    p.add_argument('--cpu-batch', type=int, default=4)
+    p.add_argument('--cpu-batch', type=int, default=8)
     p.add_argument('--no-events', action='store_true', help='skip per-launch HIP events (A/B their overhead)')
     return p.parse_args()
 
@@ -133,8 +116,19 @@ def synthetic(args, rank, device, img):
     return video.to(device), tokens.to(device)
 
 
+def _cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
 def cpu_baseline(args, model, img):
-    """Times the CPU oracle (port of the reference path) on one small batch: fwd + loss + bwd, f32."""
+    """Times the CPU oracle (port of the reference path, float32) on a bounded sample: fwd + loss + bwd of one batch
+    of `--cpu-batch` clips of the same shapes, 1 warm-up + 3 timed iterations."""
     from oracle import oracle as O
     cores = min(32, os.cpu_count() or 1)     # torch intra-op threads actually used (more oversubscribes)
     torch.set_num_threads(cores)
@@ -143,22 +137,25 @@ def cpu_baseline(args, model, img):
     video, tokens = O.synthetic_batch(args.cpu_batch, args.frames, img, seed=99)
     vis_heads = model.visual.blocks[0].attn.num_heads
     txt_heads = model.transformer.resblocks[0].attn.num_heads
-    best = None
-    t_total = 0.0
-    for _ in range(2):
+    times = []
+    budget = time.perf_counter() + 45.0
+    for it in range(4):
         t0 = time.perf_counter()
         out = O.clip_forward(video, tokens, w, vis_heads, txt_heads, norm_embed=True)
         O.clip_loss(out['image_embed'], out['text_embed'], out['logit_scale'])['loss'].backward()
         dt = time.perf_counter() - t0
-        t_total += dt
-        best = dt if best is None else min(best, dt)
+        if it > 0:
+            times.append(dt)
         for v in w.values():
             v.grad = None
-        if t_total > 12:
+        if time.perf_counter() > budget and times:
             break
-    return {'value': round(args.cpu_batch / best, 4), 'unit': 'clip-text pairs/s', 'cores': cores, 'kind': 'port',
+    mean = sum(times) / len(times)
+    return {'value': round(args.cpu_batch / mean, 4), 'unit': 'clip-text pairs/s', 'cores': cores, 'kind': 'port',
+            'cpu': f'{_cpu_model()} ({os.cpu_count()} logical cores on the box)',
             'sample': f'oracle/oracle.py fwd+loss+bwd (no optimizer), f32, batch {args.cpu_batch}, '
-                      f'{args.frames}x{img}^2 clips + 77-token captions, best of {1 if t_total > 12 else 2}'}
+                      f'{args.frames}x{img}^2 clips + 77-token captions, 1 warm-up + {len(times)} timed iterations '
+                      f'(mean {mean:.2f} s, best {min(times):.2f} s)'}
 
 
 def main():
@@ -183,8 +180,11 @@ def main():
     from lavila.models.loss import CLIPLoss
     timer = KernelTimer()
     ops.divided_attn_fwd_raw = timer.wrap(ops.divided_attn_fwd_raw, lambda qkv, f, n, h, mode: mode == 0)   # space
-    # every video-tower launch of the MFMA weight-gradient kernel (qkv, proj, fc1, fc2, patch embed: M = B*T rows,
-    # instantiation wgrad_kernel<4,2,6,6,false>); the text tower's small launches overlap on the second stream
+    # every video-tower launch (M = B*T rows) of the two hand-written MFMA GEMM families; the text tower's small
+    # launches overlap on the second stream
+    gtimer = KernelTimer()
+    ops.linear_tn_raw = gtimer.wrap(ops.linear_tn_raw, lambda x, w, *a, **k: x.shape[0] >= 65536,
+                                    work=lambda x, w, *a, **k: 2.0 * x.shape[0] * w.shape[0] * w.shape[1])
     wtimer = KernelTimer()
     ops.linear_wgrad_raw = wtimer.wrap(ops.linear_wgrad_raw, lambda dy, x, *a, **k: dy.shape[0] >= 65536,
                                        work=lambda dy, x, *a, **k: 2.0 * dy.shape[0] * dy.shape[1] * x.shape[1])
@@ -221,13 +221,13 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    timer.enabled = wtimer.enabled = not args.no_events
+    timer.enabled = wtimer.enabled = gtimer.enabled = not args.no_events
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     fence()
     elapsed = time.perf_counter() - t0
-    timer.enabled = wtimer.enabled = False
+    timer.enabled = wtimer.enabled = gtimer.enabled = False
     t = torch.tensor([elapsed], device=device, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -244,7 +244,7 @@ def main():
         kms = timer.mean_ms()
         roofline_hbm = None
         traffic = None
-        tfile = os.path.join(ROOT, 'profiles', 'r01_traffic_space_fwd.json')   # PMC pass of the same kernel/shape
+        tfile = os.path.join(ROOT, 'profiles', 'r02_traffic_space_fwd.json')   # PMC pass of the same kernel/shape
         if os.path.isfile(tfile) and (B, Fr, N, D) == (256, 4, 196, 768) and amp is not None:
             traffic = json.load(open(tfile))['traffic_bytes_per_launch']
         if kms:
@@ -253,23 +253,26 @@ def main():
                             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
                             'traffic': traffic, 'avg_ms': round(kms, 4), 'launches': len(timer.pairs),
                             'alg_bytes_per_launch': alg_bytes}
-        # dominant kernel: the MFMA weight gradient, aggregated over all its launches in the timed region
-        # (algorithmic flops of a launch = 2*M*N*K; the event pair also brackets its 13-us partial-tile reduction)
-        roofline = roofline_hbm
-        if wtimer.pairs:
-            wtraffic = None
-            wfile = os.path.join(ROOT, 'profiles', 'r01_traffic_wgrad.json')    # PMC pass, fc1 shape
-            if os.path.isfile(wfile) and (B, Fr, N, D) == (256, 4, 196, 768):
-                wtraffic = json.load(open(wfile))['traffic_bytes_per_launch']
-            tot_ms, tot_fl = wtimer.total_ms(), sum(wtimer.work)
+        def mfma_roofline(tm, kernel, tfile):
+            if not tm.pairs:
+                return None
+            traffic = note = None
+            path = os.path.join(ROOT, 'profiles', tfile)
+            if os.path.isfile(path) and (B, Fr, N, D) == (256, 4, 196, 768):
+                tj = json.load(open(path))
+                traffic, note = tj['traffic_bytes_per_launch'], tj.get('note')
+            tot_ms, tot_fl = tm.total_ms(), sum(tm.work)
             ach = tot_fl / (tot_ms * 1e-3) / 1e12
-            roofline = {'bound': 'mfma', 'kernel': 'lvl_linear_wgrad (wgrad_kernel<4,2,6,6,false>, all video-tower weight gradients)',
-                        'achieved': round(ach, 1), 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                        'frac': round(ach / MFMA_PEAK_TFLOPS, 4), 'traffic': wtraffic,
-                        'avg_ms': round(tot_ms / len(wtimer.pairs), 4), 'launches': len(wtimer.pairs),
-                        'alg_flops_per_launch': round(tot_fl / len(wtimer.pairs)),
-                        'traffic_note': 'PMC traffic is of the fc1-shaped launch (N=3072, K=768): 1.626 GB vs '
-                                        '1.619 GB algorithmic'}
+            return {'bound': 'mfma', 'kernel': kernel, 'achieved': round(ach, 1), 'peak': MFMA_PEAK_TFLOPS,
+                    'unit': 'TFLOP/s', 'frac': round(ach / MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
+                    'avg_ms': round(tot_ms / len(tm.pairs), 4), 'launches': len(tm.pairs),
+                    'alg_flops_per_launch': round(tot_fl / len(tm.pairs)), 'traffic_note': note}
+        # dominant kernel: the forward / input-gradient GEMM, aggregated over all its launches in the timed region
+        roofline = mfma_roofline(gtimer, 'lvl_linear_tn (gemm_tn_kernel<0|1|2>, all video-tower forward and '
+                                 'input-gradient GEMMs incl. their fused epilogues)', 'r02_traffic_gemm_tn.json') \
+            or roofline_hbm
+        roofline_wgrad = mfma_roofline(wtimer, 'lvl_linear_wgrad (wgrad_kernel<4,2,6,6,false> + its partial-tile '
+                                       'reduction, all video-tower weight gradients)', 'r02_traffic_wgrad.json')
         line = {
             'metric': f'clip-text pairs/s (whole node), TSF-B/16 {Fr}x{img}^2 + CLIP text tower, fwd+loss+bwd+AdamW',
             'value': round(world * B * args.steps / elapsed, 2), 'unit': 'clip-text pairs/s', 'n_gpus': world,
@@ -279,8 +282,9 @@ def main():
             'config': {'workload': f'{args.model}: TSF-B/16 {Fr}x{img}^2 clips + 32-token captions (77 ctx), '
                                    f'local batch {B}, global batch {world * B}, contrastive all-gather over RCCL',
                        'global_batch': world * B, 'parallelism': f'dp{world}', 'final_loss': round(final_loss, 4),
-                       'tuned_gemm_table': TUNED_GEMMS},
+                       'linear_gemms': 'lvl_linear_tn / lvl_linear_wgrad (hand-written MFMA; no library GEMM on the path)'},
             'roofline': roofline,
+            'roofline_wgrad': roofline_wgrad,
             'roofline_hbm': roofline_hbm,
         }
         if world == 1 and not args.no_cpu_baseline:
