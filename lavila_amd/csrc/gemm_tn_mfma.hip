@@ -105,6 +105,13 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
   const int first = (xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq) + bid / nx;
   const int my_tiles = (cnt - bid / nx + wpx - 1) / wpx;
 
+  // Tile order: all N/256 column tiles of a row block are neighbours (N-fastest). (Panels of 3-6 column tiles, to keep
+  // a weight panel L2-resident, measured no faster: the weight re-reads are served by the Infinity Cache.)
+  auto decode_tile = [&](int pair, int& tm, int& tn) {
+    tm = pair / tiles_n;
+    tn = pair - tm * tiles_n;
+  };
+
   // ---- LDS-DMA plan -----------------------------------------------------------------------------------------------
   // A slot is 16 fills of 1 KiB (8 rows x 128 B); wave w issues fills w and w+8 of every slot. Lane l of fill f
   // lands at slot byte f*1024 + l*16 = slot row 8f + (l>>3), physical chunk l&7, and therefore fetches the LOGICAL
@@ -131,7 +138,8 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
   const char* f_wbase;             // first W row of the fetch tile
   auto fetch_tile = [&](int i) {
     const int pair = first + i * wpx;
-    const int tm = pair / tiles_n, tn = pair - tm * tiles_n;
+    int tm, tn;
+    decode_tile(pair, tm, tn);
     f_xrow = (uint32_t)tm * (uint32_t)(TM * K * 2);
     f_wbase = reinterpret_cast<const char*>(W) + (int64_t)tn * TN * K * 2;
     if (EPI != 2 && bias != nullptr && wave == 0) {
@@ -202,14 +210,33 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
   };
 
   gm_f32x16 acc[2][2][2];           // [qm][qn][mt]
-  auto zero_acc = [&]() {
+  // The accumulators of tile ti START as the tile's bias (read straight from its LDS image into the accumulator
+  // registers: no VALU work), so the epilogue has no bias add; without a bias they start at zero.
+  auto init_acc = [&](int ti) {
+    if (EPI != 2 && bias != nullptr) {
+      const uint8_t* bias_img = smem + BIAS_OFF + (ti & 3) * 1024;
 #pragma unroll
-    for (int a = 0; a < 8; ++a)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a >> 2][(a >> 1) & 1][a & 1][r] = 0.f;
+        for (int rq = 0; rq < 4; ++rq) {
+          const float4 b = *reinterpret_cast<const float4*>(bias_img + (wn * 64 + i * 32 + 8 * rq + 4 * hi) * 4);
+#pragma unroll
+          for (int a = 0; a < 4; ++a) {
+            acc[a >> 1][i][a & 1][4 * rq + 0] = b.x;
+            acc[a >> 1][i][a & 1][4 * rq + 1] = b.y;
+            acc[a >> 1][i][a & 1][4 * rq + 2] = b.z;
+            acc[a >> 1][i][a & 1][4 * rq + 3] = b.w;
+          }
+        }
+    } else {
+#pragma unroll
+      for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a >> 2][(a >> 1) & 1][a & 1][r] = 0.f;
+    }
   };
+
   auto epilogue = [&](int tm, int tn, int ti) {
-    const uint8_t* bias_img = smem + BIAS_OFF + (ti & 3) * 1024;
     const int64_t m0 = (int64_t)tm * TM;
     const int n0 = tn * TN;
     float csum[32];
@@ -231,10 +258,6 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
           float v[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = a16[4 * rq + e];
-          if (EPI != 2 && bias != nullptr) {
-            const float4 b = *reinterpret_cast<const float4*>(bias_img + nl * 4);
-            v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-          }
           if (EPI == 1) {
             upk[rq] = make_uint2(f32x2_to_bf16x2(v[0], v[1]), f32x2_to_bf16x2(v[2], v[3]));
             // the activation sees the ROUNDED pre-activation (what the reference's bf16 Linear output holds and
@@ -366,7 +389,7 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
   read_w(S_W0, wA);
   __builtin_amdgcn_sched_barrier(0);
   GM_STAMP();
-  zero_acc();
+  init_acc(0);
   int par = 0;
   // One K block = four phases. A0 / A1 are added to the vmcnt allowance of the barriers in front of P0,P1 / P2,P3:
   // vector-memory operations retire in issue order, so in the first block(s) after an epilogue -- while the slot a
@@ -423,10 +446,11 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
     // while this tile's results leave
     GM_STAMP();
     const int pair = first + i * wpx;
-    const int tm = pair / tiles_n;
-    epilogue(tm, pair - tm * tiles_n, i);
+    int tm, tn;
+    decode_tile(pair, tm, tn);
+    epilogue(tm, tn, i);
     GM_STAMP();
-    zero_acc();
+    init_acc(i + 1);
     __builtin_amdgcn_sched_barrier(0);
   }
 #undef GM_BAR
