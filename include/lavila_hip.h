@@ -29,7 +29,7 @@ extern "C" {
 
 enum { LVL_F32 = 0, LVL_BF16 = 1 };
 enum { LVL_OK = 0, LVL_EINVAL = -22, LVL_ENOSYS = -38, LVL_EHIP = -5 };
-enum { LVL_ATTN_SPACE = 0, LVL_ATTN_TIME = 1 };
+enum { LVL_ATTN_SPACE = 0, LVL_ATTN_TIME = 1, LVL_ATTN_CAUSAL = 2 /* lvl_attention_fast_path only */ };
 enum { LVL_EPI_BIAS = 0, LVL_EPI_BIAS_QUICKGELU = 1, LVL_EPI_QUICKGELU_BWD = 2 };
 
 /* library identification / diagnostics (host pointers) */
@@ -103,6 +103,11 @@ int lvl_divided_attn_fwd(const void* qkv, void* out, float* lse, float* ws, int 
 int lvl_divided_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse,
                          void* dqkv, float* ws, int B, int F, int N, int H, int mode, int dtype,
                          void* stream);
+
+/* host-side query: 1 if a bf16 call of this shape runs on the MFMA / register-tiled attention kernels (forward and
+ * backward), 0 if it falls to the shape-generic kernels (any shape, correct, much slower). mode: LVL_ATTN_SPACE /
+ * LVL_ATTN_TIME with (F, N, H), or LVL_ATTN_CAUSAL with N = L. The Python layer logs one warning per slow shape. */
+int lvl_attention_fast_path(int mode, int F, int N, int H);
 
 /* ---- causal self-attention core of the text tower -------------------------------------------------------
  * nn.MultiheadAttention core with the additive causal mask (openai_model.py:196-198,

@@ -32,6 +32,7 @@ SIGNATURES = {
     'lvl_embed_tokens_fwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     'lvl_divided_attn_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'lvl_divided_attn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    'lvl_attention_fast_path': (_I, [_I, _I, _I, _I]),
     'lvl_causal_attn_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     'lvl_causal_attn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'lvl_clip_loss_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P]),

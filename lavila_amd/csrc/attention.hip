@@ -81,3 +81,12 @@ extern "C" int lvl_causal_attn_bwd(const void* qkv, const void* out, const void*
     return lvl_text_mfma_bwd(qkv, out, dout, lse, dqkv, ws, B, L, H, (hipStream_t)stream);
   return lvl_generic_causal_bwd(qkv, out, dout, lse, dqkv, ws, B, L, H, dtype, (hipStream_t)stream);
 }
+
+// 1 if a bf16 call of this shape runs on the MFMA / register-tiled kernels (forward AND backward), 0 if it lands on
+// the shape-generic kernels of attn_generic.hip (correct, latency-bound). Host-side query, no device work.
+extern "C" int lvl_attention_fast_path(int mode, int F, int N, int H) {
+  if (mode == LVL_ATTN_SPACE) return lvl_space_mfma_supported(F, N) && lvl_space_mfma_bwd_supported(F, N);
+  if (mode == LVL_ATTN_TIME) return lvl_time_fast_supported(F, N, H) && lvl_time_fast_bwd_supported(F, N, H);
+  if (mode == LVL_ATTN_CAUSAL) return lvl_text_mfma_supported(N) && lvl_text_mfma_bwd_supported(N);
+  return 0;
+}

@@ -440,6 +440,9 @@ class _DividedAttnFn(torch.autograd.Function):
         if D != heads * 64 or T != 1 + frames * n_per_frame:
             raise C.HipExtensionError(f'divided attention: qkv {tuple(qkv.shape)} inconsistent with heads={heads} '
                                       f'(head dim must be 64), frames={frames}, patches/frame={n_per_frame}')
+        if qkv.dtype == torch.bfloat16 and not C.lib().lvl_attention_fast_path(mode, frames, n_per_frame, heads):
+            warn_once(('attn', mode, frames, n_per_frame), f'divided attention ({"time" if mode else "space"}, {frames} '
+                      f'frames x {n_per_frame} patches) has no MFMA kernel yet and runs on the generic (slow) kernels')
         out, lse = divided_attn_fwd_raw(qkv, frames, n_per_frame, heads, mode)
         ctx.save_for_backward(qkv, out, lse)
         ctx.cfg = (B, frames, n_per_frame, heads, mode, None if bias is None else bias.dtype)
@@ -486,6 +489,8 @@ class _CausalAttnFn(torch.autograd.Function):
         D = D3 // 3
         if D != heads * 64:
             raise C.HipExtensionError(f'causal attention: width {D} != heads*64 ({heads} heads)')
+        if qkv.dtype == torch.bfloat16 and not C.lib().lvl_attention_fast_path(2, 1, L, heads):
+            warn_once(('attn', 2, L), f'causal attention over {L} tokens runs on the generic (slow) kernels')
         out = torch.empty(B, L, D, dtype=qkv.dtype, device=qkv.device)
         lse = torch.empty(B, heads, L, dtype=torch.float32, device=qkv.device)
         C.check(C.lib().lvl_causal_attn_fwd(C.ptr(qkv), C.ptr(out), C.ptr(lse), B, L, heads, C.dtype_code(qkv),
