@@ -380,12 +380,8 @@ int launch_dq(const void* qkv, const void* out, const void* dout, const float* l
               int F, int N, int H, hipStream_t st) {
   using L = DqLds<NKT>;
   static_assert(L::total <= 160 * 1024, "LDS per CU");
-  static bool attr_set = false;
-  if (L::total > 64 * 1024 && !attr_set) {
-    (void)hipFuncSetAttribute((const void*)space_bwd_dq_kernel<NKT, TEXT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              L::total);
-    attr_set = true;
-  }
+  if (L::total > 64 * 1024)
+    if (int rc = lvl_allow_lds<space_bwd_dq_kernel<NKT, TEXT>>()) return rc;
   hipLaunchKernelGGL((space_bwd_dq_kernel<NKT, TEXT>), dim3((unsigned)(B * F * H)), dim3(512), L::total, st,
                      (const uint16_t*)qkv, (const uint16_t*)out, (const uint16_t*)dout, lse, (uint16_t*)dqkv, delta, F,
                      N, H);
@@ -397,12 +393,8 @@ template <bool TEXT>
 int launch_dkv(const void* qkv, const void* out, const void* dout, const float* lse, const float* delta, void* dqkv,
                float* atom_ws, int B, int F, int N, int H, hipStream_t st) {
   const DkvGeom G = dkv_geometry(N);
-  static int attr_bytes = 0;
-  if (G.total > 64 * 1024 && G.total > attr_bytes) {
-    (void)hipFuncSetAttribute((const void*)space_bwd_dkv_kernel<TEXT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              G.total);
-    attr_bytes = G.total;
-  }
+  if (G.total > 64 * 1024)
+    if (int rc = lvl_allow_lds<space_bwd_dkv_kernel<TEXT>>()) return rc;
   hipLaunchKernelGGL(space_bwd_dkv_kernel<TEXT>, dim3((unsigned)(B * F * H)), dim3(512), G.total, st,
                      (const uint16_t*)qkv, (const uint16_t*)out, (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv,
                      atom_ws, F, N, H, G);

@@ -206,12 +206,8 @@ template <int NKT, bool TEXT = false>
 int launch_space_fwd(const void* qkv, void* out, float* lse, float* ws, int B, int F, int N, int H, hipStream_t st) {
   using L = SpaceLds<NKT>;
   static_assert(L::total <= 160 * 1024, "LDS per CU");   // <= 80 KB (NKT <= 13) keeps 2 workgroups per CU
-  static bool attr_set = false;
-  if (L::total > 64 * 1024 && !attr_set) {
-    (void)hipFuncSetAttribute((const void*)space_fwd_kernel<NKT, TEXT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              L::total);
-    attr_set = true;
-  }
+  if (L::total > 64 * 1024)
+    if (int rc = lvl_allow_lds<space_fwd_kernel<NKT, TEXT>>()) return rc;
   hipLaunchKernelGGL((space_fwd_kernel<NKT, TEXT>), dim3((unsigned)(B * F * H)), dim3(NT), L::total, st,
                      (const uint16_t*)qkv, (uint16_t*)out, lse, ws, F, N, H);
   LVL_CHECK_LAUNCH("space_fwd_mfma");

@@ -155,7 +155,7 @@ extern "C" int lvl_clip_loss_bwd(const void* img_all, const void* txt_all, const
   const size_t shmem = (size_t)(E + G) * sizeof(float);
   LVL_DISPATCH_DTYPE(dtype, {
     if (shmem > 64 * 1024)
-      (void)hipFuncSetAttribute((const void*)clip_bwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+      if (int rc = lvl_allow_lds<clip_bwd_kernel<T>>()) return rc;
     hipLaunchKernelGGL((clip_bwd_kernel<T>), dim3(B, 2), dim3(256), shmem, (hipStream_t)stream, (const T*)img_all,
                        (const T*)txt_all, lse_all, scale, upstream, coef, B, G, E, row0, dimg, dtxt);
   });
@@ -310,7 +310,7 @@ extern "C" int lvl_ssl_clip_loss_bwd(const void* img_all, const void* txt_all, c
   const size_t shmem = (size_t)(E + G) * sizeof(float);
   LVL_DISPATCH_DTYPE(dtype, {
     if (shmem > 64 * 1024)
-      (void)hipFuncSetAttribute((const void*)ssl_bwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+      if (int rc = lvl_allow_lds<ssl_bwd_kernel<T>>()) return rc;
     hipLaunchKernelGGL((ssl_bwd_kernel<T>), dim3(B, 2), dim3(256), shmem, (hipStream_t)stream, (const T*)img_all,
                        (const T*)txt_all, ind_all, lse_all, scales3, upstream, coef, B, G, E, row0, dimg, dtxt);
   });

@@ -1,6 +1,8 @@
 // Shared device/host helpers for the gfx950 kernels. CDNA4 only: wave = 64 lanes.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <atomic>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -27,6 +29,24 @@ int lvl_fail(int code, const char* fmt, ...);
   } while (0)
 
 static inline bool lvl_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+// Kernels that use more than 64 KiB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised once.
+// One call per (kernel instantiation, device), thread-safe, never inside the hot launch path afterwards (and
+// therefore harmless under stream capture once warmed up); the limit is set to the whole 160 KiB of a gfx950 CU.
+template <auto Kernel>
+inline int lvl_allow_lds() {
+  static std::atomic<uint64_t> done{0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return lvl_fail(LVL_EHIP, "hipGetDevice failed");
+  const uint64_t bit = 1ull << (dev & 63);
+  if (!(done.load(std::memory_order_acquire) & bit)) {
+    const hipError_t e =
+        hipFuncSetAttribute((const void*)Kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return lvl_fail(LVL_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    done.fetch_or(bit, std::memory_order_release);
+  }
+  return LVL_OK;
+}
 
 // ---------------------------------------------------------------------------------------------
 // element types. bf16 is carried as raw uint16 bits; arithmetic is always f32.

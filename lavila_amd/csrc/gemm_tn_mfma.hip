@@ -41,7 +41,6 @@
 //   * blockIdx -> tile is XCD-aware (workgroup i runs on XCD i % 8): each XCD owns a contiguous range of the
 //     N-fastest tile order, so the N/256 tiles that read the same 256 rows of X sit behind one L2 and X comes from
 //     HBM once; W (<= 4.7 MB) lives in L2 / Infinity Cache.
-#include <atomic>
 #include <type_traits>
 
 #include "common.h"
@@ -474,21 +473,6 @@ __global__ __launch_bounds__(256) void colpart_reduce_kernel(const float* __rest
   if (ry == 0 && n < N) out[(size_t)g * N + n] = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
 }
 
-// hipFuncSetAttribute once per (kernel instantiation, device), thread-safe
-template <auto Kernel>
-int allow_lds(int bytes) {
-  static std::atomic<uint64_t> done{0};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return lvl_fail(LVL_EHIP, "hipGetDevice failed");
-  const uint64_t bit = 1ull << (dev & 63);
-  if (!(done.load(std::memory_order_acquire) & bit)) {
-    const hipError_t e = hipFuncSetAttribute((const void*)Kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e != hipSuccess) return lvl_fail(LVL_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-    done.fetch_or(bit, std::memory_order_release);
-  }
-  return LVL_OK;
-}
-
 int num_cus() {                    // compute units of the current device (one persistent workgroup each)
   static std::atomic<int> cached[64];
   int dev = 0;
@@ -505,7 +489,7 @@ template <int EPI>
 int launch_tn(const void* x, const void* w, const float* bias, void* y, void* aux_out, const void* aux_in,
               float* colpart, int64_t M, int N, int K, hipStream_t st) {
   constexpr int shmem = SMEM_B;
-  const int rc = allow_lds<gemm_tn_kernel<EPI>>(shmem);
+  const int rc = lvl_allow_lds<gemm_tn_kernel<EPI>>();
   if (rc != LVL_OK) return rc;
   const int tiles_n = N / TN;
   const int64_t tiles_m = (M + TM - 1) / TM;

@@ -389,8 +389,7 @@ extern "C" int lvl_layernorm_bwd(const void* dy, const void* x, const void* x2, 
 #define LN_BWD_T(TT, VPL, W)                                                                                    \
   do {                                                                                                          \
     if (shmem > 64 * 1024)                                                                                      \
-      (void)hipFuncSetAttribute((const void*)ln_bwd_kernel<TT, VPL, W>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                (int)shmem);                                                                    \
+      if (int rc = lvl_allow_lds<ln_bwd_kernel<TT, VPL, W>>()) return rc;                                       \
     hipLaunchKernelGGL((ln_bwd_kernel<TT, VPL, W>), dim3((unsigned)blocks), dim3(256), shmem, st, (const TT*)dy, \
                        (const TT*)x, (const TT*)x2, xbias, gamma, mean, rstd, (const TT*)dadd, (TT*)dx, ws, rows, \
                        cols);                                                                                   \

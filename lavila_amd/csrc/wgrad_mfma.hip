@@ -319,13 +319,11 @@ int launch(const Plan& p, const void* dy, const void* x, float* part, float* bpa
   const size_t shmem = (size_t)G::NSTAGE * G::STAGE * sizeof(uint16_t);
   const dim3 grid((unsigned)(p.ntiles * p.S)), block(G::NT);
   if (bpart != nullptr) {
-    (void)hipFuncSetAttribute((const void*)wgrad_kernel<WN, WK, TA, TB, true>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (int rc = lvl_allow_lds<wgrad_kernel<WN, WK, TA, TB, true>>()) return rc;
     hipLaunchKernelGGL((wgrad_kernel<WN, WK, TA, TB, true>), grid, block, shmem, st, (const uint16_t*)dy,
                        (const uint16_t*)x, part, bpart, M, N, K, p.tiles_k, p.ntiles, p.S);
   } else {
-    (void)hipFuncSetAttribute((const void*)wgrad_kernel<WN, WK, TA, TB, false>,
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (int rc = lvl_allow_lds<wgrad_kernel<WN, WK, TA, TB, false>>()) return rc;
     hipLaunchKernelGGL((wgrad_kernel<WN, WK, TA, TB, false>), grid, block, shmem, st, (const uint16_t*)dy,
                        (const uint16_t*)x, part, bpart, M, N, K, p.tiles_k, p.ntiles, p.S);
   }

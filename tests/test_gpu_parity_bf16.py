@@ -236,3 +236,35 @@ def test_tsfb_bf16_training_step_vs_oracle_f32():
           f'median {worst[len(worst) // 2][0]:.2e} over {len(worst)} tensors')
     assert agg < 5e-2, agg
     assert not bad, bad[:5]
+
+
+@pytest.mark.parametrize('ctor,frames', [('CLIP_OPENAI_TIMESFORMER_LARGE', 4), ('CLIP_OPENAI_TIMESFORMER_LARGE_336PX', 2)])
+def test_large_models_forward_bf16_vs_oracle(ctor, frames):
+    """TSF-L/14 (D=1024, 24 blocks, 16 heads; models.py:374-491) at 224 (257 keys per frame: MFMA space kernels) and at
+    336 (577 keys: no MFMA kernel yet -- the generic kernels run, and say so once). Forward under bf16 autocast against
+    the float32 oracle; bound: eps*sqrt(10*24) = 1.7e-2 relative on the unit-norm embeddings, 4e-2 used."""
+    import contextlib
+    import io
+    import warnings
+    from lavila.models import models
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        model = getattr(models, ctor)(num_frames=frames, project_embed_dim=256)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    w = O.procedural_weights(shapes, seed=23)
+    model.load_state_dict(w)
+    model.to(DEV).eval()
+    img = model.visual.patch_embed.img_size[0]
+    video, tokens = O.synthetic_batch(2, frames, img, seed=41)
+    with warnings.catch_warnings(record=True) as rec, torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):
+        warnings.simplefilter('always')
+        out = model(video.to(DEV), tokens.to(DEV), norm_embed=True)
+    slow = [str(r.message) for r in rec if 'generic (slow) kernels' in str(r.message)]
+    assert bool(slow) == ('336' in ctor), slow          # a fallback is never silent, and only the 577-key shape falls back
+    torch.set_num_threads(min(32, torch.get_num_threads() or 1))
+    with torch.no_grad():
+        oo = O.clip_forward(video, tokens, w, 16, 12, norm_embed=True)
+    for k in ('image_embed', 'text_embed'):
+        err = ((out[k].float().cpu() - oo[k]).norm() / oo[k].norm()).item()
+        assert err < 4e-2, (k, err)
