@@ -26,19 +26,23 @@ constexpr float kExp2 = 0.125f * kLog2e;          // exp(s * scale) = exp2(s * k
 // ------------------------------------------------------------------------------------------------------------
 // dQ kernel
 // ------------------------------------------------------------------------------------------------------------
-template <int NKT> struct DqLds {
+template <int NKT, int NW> struct DqLds {
   static constexpr int KROWS = NKT * 16;
   static constexpr int ks_off = 0;
   static constexpr int vs_off = ks_off + KROWS * RS * 2;
   static constexpr int ot_off = vs_off + KROWS * RS * 2;
-  static constexpr int total = ot_off + 8 * 16 * OS * 2;
+  static constexpr int total = ot_off + NW * 16 * OS * 2;
 };
 
-template <int NKT, bool TEXT>
-__global__ __launch_bounds__(512, (NKT <= 13 ? 4 : 2)) void space_bwd_dq_kernel(
+// NW = 8 waves (two workgroups per CU) up to 272 keys; NW = 4 (one workgroup per CU, one wave per SIMD) for the
+// large groups whose K and V images fill the LDS (TSF-L/14 at 336: 577 keys). MASKALL: NKT is an upper bound of the
+// tile count, every tile is masked against nkeys.
+template <int NKT, bool TEXT, int NW, bool MASKALL>
+__global__ __launch_bounds__(NW * 64, (NW == 4 ? 1 : (NKT <= 13 ? 4 : 2))) void space_bwd_dq_kernel(
     const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out, const uint16_t* __restrict__ dout,
     const float* __restrict__ lse, uint16_t* __restrict__ dqkv, float* __restrict__ delta, int F, int N, int H) {
-  using L = DqLds<NKT>;
+  constexpr int NT = NW * 64;
+  using L = DqLds<NKT, NW>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint16_t* Ks = reinterpret_cast<uint16_t*>(smem + L::ks_off);
   uint16_t* Vs = reinterpret_cast<uint16_t*>(smem + L::vs_off);
@@ -69,15 +73,22 @@ __global__ __launch_bounds__(512, (NKT <= 13 ? 4 : 2)) void space_bwd_dq_kernel(
 
   {   // key row r = token tok0 + r - 1 (r >= 1) or the cls token (r = 0); text: token r
     const uint16_t* krow0 = base + (size_t)(TEXT ? 0 : tok0 - 1) * ts + D;
-    stage_rows2<512, (L::KROWS + 63) / 64>(Ks, krow0, ts, TEXT ? nullptr : base + D, Vs, krow0 + D, ts,
-                                          TEXT ? nullptr : base + 2 * D, L::KROWS, nkeys, tid);
+    constexpr int RPP = NT / 8, GROUP = 8 * RPP;        // at most 8 passes (16 loads per thread) in flight
+    constexpr int MAXP = (L::KROWS < GROUP ? L::KROWS + RPP - 1 : GROUP) / RPP;
+#pragma unroll 1
+    for (int r0 = 0; r0 < L::KROWS; r0 += GROUP) {
+      const int pad = L::KROWS - r0 < GROUP ? L::KROWS - r0 : GROUP;
+      stage_rows2<NT, MAXP>(Ks + r0 * RS, krow0 + (size_t)r0 * ts, ts, (TEXT || r0 != 0) ? nullptr : base + D,
+                            Vs + r0 * RS, krow0 + D + (size_t)r0 * ts, ts, (TEXT || r0 != 0) ? nullptr : base + 2 * D,
+                            pad, nkeys - r0, tid);
+    }
   }
   __syncthreads();
 
   uint16_t* ot = Ot + wave * 16 * OS;
   const FragOff fo = frag_offsets(lane);
 #pragma unroll 1
-  for (int qt = wave; qt * 16 < N; qt += 8) {
+  for (int qt = wave; qt * 16 < N; qt += NW) {
     const int qrow = qt * 16 + c;
     const int tok = tok_of(qt);
     const uint4 q0 = nq0, q1 = nq1, g0 = ng0, g1 = ng1;
@@ -96,7 +107,7 @@ __global__ __launch_bounds__(512, (NKT <= 13 ? 4 : 2)) void space_bwd_dq_kernel(
       dl += __shfl_xor(dl, 16, 64);
       dl += __shfl_xor(dl, 32, 64);
     }
-    if ((qt + 8) * 16 < N) load_frags(qt + 8);
+    if ((qt + NW) * 16 < N) load_frags(qt + NW);
     const size_t srow = ((size_t)b * H + h) * T + tok;
     const float Lk = lse[srow] * kLog2e;
     if (g == 0 && qrow < N) delta[srow] = dl;
@@ -128,11 +139,11 @@ __global__ __launch_bounds__(512, (NKT <= 13 ? 4 : 2)) void space_bwd_dq_kernel(
         float e0 = __builtin_amdgcn_exp2f(fmaf(s0[r], kExp2, -Lk));
         float e1 = __builtin_amdgcn_exp2f(fmaf(s1[r], kExp2, -Lk));
         // space groups: NKT = ceil(nkeys/16) exactly -> only the last tile holds padded keys; text: causal
-        if (TEXT || k0 == last) {
+        if (TEXT || MASKALL || k0 == last) {
           const int key = k0 * 16 + g * 4 + r;
           e0 = (key < nkeys && (!TEXT || key <= qrow)) ? e0 : 0.f;
         }
-        if (TEXT || k1 == last) {
+        if (TEXT || MASKALL || k1 == last) {
           const int key = k1 * 16 + g * 4 + r;
           e1 = (key < nkeys && (!TEXT || key <= qrow)) ? e1 : 0.f;
         }
@@ -171,7 +182,7 @@ struct DkvGeom {
   int qs_off, dos_off, lse_off, del_off, vec_off, ot_off, total;  // bytes
 };
 
-inline DkvGeom dkv_geometry(int N) {
+inline DkvGeom dkv_geometry(int N, int nw = 8) {
   DkvGeom g{};
   g.QROWS = (N + 31) / 32 * 32;
   g.qs_off = 0;
@@ -180,12 +191,12 @@ inline DkvGeom dkv_geometry(int N) {
   g.del_off = g.lse_off + g.QROWS * 4;
   g.vec_off = g.del_off + g.QROWS * 4;          // f32: qc[64], doc[64], dqc[64], scalars[8]
   g.ot_off = g.vec_off + (3 * 64 + 8) * 4;
-  g.total = g.ot_off + 8 * 16 * OS * 2;
+  g.total = g.ot_off + nw * 16 * OS * 2;
   return g;
 }
 
-template <bool TEXT>
-__global__ __launch_bounds__(512, 4) void space_bwd_dkv_kernel(
+template <bool TEXT, int NW>
+__global__ __launch_bounds__(NW * 64, (NW == 4 ? 1 : 4)) void space_bwd_dkv_kernel(
     const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out, const uint16_t* __restrict__ dout,
     const float* __restrict__ lse, const float* __restrict__ delta, uint16_t* __restrict__ dqkv,
     float* __restrict__ atom_ws, int F, int N, int H, DkvGeom G) {
@@ -200,6 +211,7 @@ __global__ __launch_bounds__(512, 4) void space_bwd_dkv_kernel(
   float* scal = dqc + 64;                                         // [0] lse_c (log2 units), [1] delta_c
   uint16_t* Ot = reinterpret_cast<uint16_t*>(smem + G.ot_off);
 
+  constexpr int NT = NW * 64;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = blockIdx.x % H, f = (blockIdx.x / H) % F, b = blockIdx.x / (H * F);
   const int D = H * 64, T = TEXT ? N : 1 + F * N, nkeys = TEXT ? N : N + 1, tok0 = TEXT ? 0 : 1 + f * N;
@@ -227,9 +239,16 @@ __global__ __launch_bounds__(512, 4) void space_bwd_dkv_kernel(
   };
   load_kv(wave < nkt ? wave : 0);
 
-  stage_rows2<512, 4>(Qs, base + (size_t)tok0 * ts, ts, nullptr, dOs, dobase + (size_t)tok0 * D, (size_t)D, nullptr,
-                      QROWS, N, tid);
-  for (int q = tid; q < QROWS; q += 512) {
+  {
+    constexpr int GROUP = 4 * (NT / 8);          // 4 passes (8 loads per thread) in flight at a time
+#pragma unroll 1
+    for (int r0 = 0; r0 < QROWS; r0 += GROUP) {
+      const int pad = QROWS - r0 < GROUP ? QROWS - r0 : GROUP;
+      stage_rows2<NT, 4>(Qs + r0 * RS, base + (size_t)(tok0 + r0) * ts, ts, nullptr, dOs + r0 * RS,
+                         dobase + (size_t)(tok0 + r0) * D, (size_t)D, nullptr, pad, N - r0, tid);
+    }
+  }
+  for (int q = tid; q < QROWS; q += NT) {
     lse_s[q] = q < N ? lrow[tok0 + q] * kLog2e : INFINITY;      // log2 units; padded queries: exp2(-inf) = 0
     del_s[q] = q < N ? drow[tok0 + q] : 0.f;
   }
@@ -248,7 +267,7 @@ __global__ __launch_bounds__(512, 4) void space_bwd_dkv_kernel(
   const FragOff fo = frag_offsets(lane);
 
 #pragma unroll 1
-  for (int kt = wave; kt < nkt; kt += 8) {
+  for (int kt = wave; kt < nkt; kt += NW) {
     const int krow = kt * 16 + c;
     if (kt != wave) load_kv(kt);          // first tile's fragments were loaded before the staging
     const uint4 k0 = nk0, k1 = nk1, v0 = nv0, v1 = nv1;
@@ -375,29 +394,39 @@ __global__ __launch_bounds__(192) void cls_grad_finalize_kernel(const float* __r
   dqkv[(size_t)b * T * 3 * D + (t >> 6) * D + h * 64 + (t & 63)] = f32_to_bf16(atom_ws[((size_t)b * H + h) * 192 + t]);
 }
 
-template <int NKT, bool TEXT = false>
+template <int NKT, bool TEXT = false, int NW = 8, bool MASKALL = false>
 int launch_dq(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* delta, int B,
               int F, int N, int H, hipStream_t st) {
-  using L = DqLds<NKT>;
+  using L = DqLds<NKT, NW>;
   static_assert(L::total <= 160 * 1024, "LDS per CU");
   if (L::total > 64 * 1024)
-    if (int rc = lvl_allow_lds<space_bwd_dq_kernel<NKT, TEXT>>()) return rc;
-  hipLaunchKernelGGL((space_bwd_dq_kernel<NKT, TEXT>), dim3((unsigned)(B * F * H)), dim3(512), L::total, st,
-                     (const uint16_t*)qkv, (const uint16_t*)out, (const uint16_t*)dout, lse, (uint16_t*)dqkv, delta, F,
-                     N, H);
+    if (int rc = lvl_allow_lds<space_bwd_dq_kernel<NKT, TEXT, NW, MASKALL>>()) return rc;
+  hipLaunchKernelGGL((space_bwd_dq_kernel<NKT, TEXT, NW, MASKALL>), dim3((unsigned)(B * F * H)), dim3(NW * 64),
+                     L::total, st, (const uint16_t*)qkv, (const uint16_t*)out, (const uint16_t*)dout, lse,
+                     (uint16_t*)dqkv, delta, F, N, H);
   LVL_CHECK_LAUNCH("space_bwd_dq");
   return LVL_OK;
 }
 
+constexpr int kBigTiles = 37;          // large-group variant: up to 592 keys, 4 waves, one workgroup per CU
+
 template <bool TEXT>
 int launch_dkv(const void* qkv, const void* out, const void* dout, const float* lse, const float* delta, void* dqkv,
                float* atom_ws, int B, int F, int N, int H, hipStream_t st) {
-  const DkvGeom G = dkv_geometry(N);
-  if (G.total > 64 * 1024)
-    if (int rc = lvl_allow_lds<space_bwd_dkv_kernel<TEXT>>()) return rc;
-  hipLaunchKernelGGL(space_bwd_dkv_kernel<TEXT>, dim3((unsigned)(B * F * H)), dim3(512), G.total, st,
-                     (const uint16_t*)qkv, (const uint16_t*)out, (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv,
-                     atom_ws, F, N, H, G);
+  const bool big = !TEXT && N + 1 > 272;
+  const DkvGeom G = dkv_geometry(N, big ? 4 : 8);
+  if (big) {
+    if (int rc = lvl_allow_lds<space_bwd_dkv_kernel<TEXT, 4>>()) return rc;
+    hipLaunchKernelGGL((space_bwd_dkv_kernel<TEXT, 4>), dim3((unsigned)(B * F * H)), dim3(256), G.total, st,
+                       (const uint16_t*)qkv, (const uint16_t*)out, (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv,
+                       atom_ws, F, N, H, G);
+  } else {
+    if (G.total > 64 * 1024)
+      if (int rc = lvl_allow_lds<space_bwd_dkv_kernel<TEXT, 8>>()) return rc;
+    hipLaunchKernelGGL((space_bwd_dkv_kernel<TEXT, 8>), dim3((unsigned)(B * F * H)), dim3(512), G.total, st,
+                       (const uint16_t*)qkv, (const uint16_t*)out, (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv,
+                       atom_ws, F, N, H, G);
+  }
   LVL_CHECK_LAUNCH("space_bwd_dkv");
   return LVL_OK;
 }
@@ -412,6 +441,12 @@ int dispatch_dq(int nkeys, const void* qkv, const void* out, const void* dout, c
     SPACE_DQ_CASE(14) SPACE_DQ_CASE(15) SPACE_DQ_CASE(16) SPACE_DQ_CASE(17)
 #undef SPACE_DQ_CASE
   }
+  if (!TEXT) {
+    if ((nkeys + 15) / 16 == kBigTiles)
+      return launch_dq<kBigTiles, false, 4, false>(qkv, out, dout, lse, dqkv, delta, B, F, N, H, st);
+    if (nkeys <= kBigTiles * 16)
+      return launch_dq<kBigTiles, false, 4, true>(qkv, out, dout, lse, dqkv, delta, B, F, N, H, st);
+  }
   return lvl_fail(LVL_ENOSYS, "space_mfma_bwd: %d keys per group not supported", nkeys);
 }
 
@@ -422,7 +457,9 @@ void lvl_launch_cls_grad_finalize(const float* atom_ws, void* dqkv, int B, int T
 }
 
 bool lvl_space_mfma_bwd_supported(int F, int N) {
-  return N >= 1 && N + 1 <= 272 && dkv_geometry(N).QROWS <= 256 && dkv_geometry(N).total <= 160 * 1024 && F <= 64;
+  if (N < 1 || F > 64) return false;
+  if (N + 1 <= 272) return dkv_geometry(N).QROWS <= 256 && dkv_geometry(N).total <= 160 * 1024;
+  return N + 1 <= kBigTiles * 16 && dkv_geometry(N, 4).total <= 160 * 1024;      // large groups: 4-wave kernels
 }
 
 // ws layout: delta [B*H*T] f32, then atomics [B*H*192] f32 (d cls q | d cls k | d cls v)

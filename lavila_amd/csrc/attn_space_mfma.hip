@@ -18,6 +18,11 @@
 // (the cls key itself is taken by frame 0); a tiny combine kernel merges the F partials: K and V are read from
 // HBM once and no separate pass or barrier is spent on the CLS row.
 //
+// Groups of up to 272 keys (TSF-B/16 and TSF-L/14 at 224) use 8 waves and two workgroups per CU. Larger groups
+// (TSF-L/14 at 336: 577 keys) keep the SAME exact single-pass structure: the two images of 592 key rows fill
+// 148 KiB of the CU's 160 KiB LDS, one workgroup of 4 waves per CU (one per SIMD, up to 512 registers each: the 37
+// score tiles of a query tile stay in registers), no online-softmax rescaling and no second pass over K/V.
+//
 // Roofline: algorithmic HBM bytes per (b,f,h) = 4 * N * 64 * 2 (q,k,v in, o out); MFMA work is ~1/3 of
 // the HBM time at 8 TB/s on TSF-B, so the kernel is built to stream: 2
 // workgroups (16 waves) per CU (<= 80 KB LDS each) overlap one group's staging with the other's MFMA phase.
@@ -27,23 +32,25 @@ namespace {
 
 using namespace attn_mfma;
 constexpr int CLS_REC = 66;       // cls partial record: m, l, acc[64]
-constexpr int NT = 512, NW = 8;
+constexpr int kBigTiles = 37;     // large-group variant: up to 592 keys (TSF-L/14 at 336: 577)
 
-template <int NKT> struct SpaceLds {
+template <int NKT, int NW> struct SpaceLds {
   static constexpr int KROWS = NKT * 16;
   static constexpr int ks_off = 0;                                       // bytes
   static constexpr int vs_off = ks_off + KROWS * RS * 2;
-  static constexpr int ot_off = vs_off + KROWS * RS * 2;                 // 8 waves x [16][OS] bf16
+  static constexpr int ot_off = vs_off + KROWS * RS * 2;                 // NW waves x [16][OS] bf16
   static constexpr int total = ot_off + NW * 16 * OS * 2;
 };
 
 // TEXT = true reuses the kernel for the causal text tower (openai_model.py:196-198): one group per (b, h),
 // L queries x L keys, no cls row, key j visible to query i iff j <= i, no CLS partial.
-template <int NKT, bool TEXT>
-__global__ __launch_bounds__(NT, (NKT <= 13 ? 4 : 2)) void space_fwd_kernel(
+// MASKALL: the tile count is an upper bound of ceil(nkeys/16) (every tile is masked), for the large-group variant.
+template <int NKT, bool TEXT, int NW, bool MASKALL>
+__global__ __launch_bounds__(NW * 64, (NW == 4 ? 1 : (NKT <= 13 ? 4 : 2))) void space_fwd_kernel(
     const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, float* __restrict__ lse,
     float* __restrict__ cls_ws, int F, int N, int H) {
-  using L = SpaceLds<NKT>;
+  constexpr int NT = NW * 64;
+  using L = SpaceLds<NKT, NW>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint16_t* Ks = reinterpret_cast<uint16_t*>(smem + L::ks_off);
   uint16_t* Vs = reinterpret_cast<uint16_t*>(smem + L::vs_off);
@@ -72,8 +79,16 @@ __global__ __launch_bounds__(NT, (NKT <= 13 ? 4 : 2)) void space_fwd_kernel(
   // K and V rows -> LDS images. Key row r is token tok0 + r - 1 (r >= 1) or the cls token (r = 0).
   {
     const uint16_t* krow0 = base + (size_t)(TEXT ? 0 : tok0 - 1) * tstride + D;
-    stage_rows2<NT, (L::KROWS + 63) / 64>(Ks, krow0, tstride, TEXT ? nullptr : base + D, Vs, krow0 + D, tstride,
-                                          TEXT ? nullptr : base + 2 * D, L::KROWS, nkeys, tid);
+    // at most 8 passes (16 loads per thread) in flight at a time
+    constexpr int RPP = NT / 8, GROUP = 8 * RPP;
+#pragma unroll 1
+    for (int r0 = 0; r0 < L::KROWS; r0 += GROUP) {
+      const int pad = L::KROWS - r0 < GROUP ? L::KROWS - r0 : GROUP;
+      constexpr int MAXP = (L::KROWS < GROUP ? L::KROWS + RPP - 1 : GROUP) / RPP;
+      stage_rows2<NT, MAXP>(Ks + r0 * RS, krow0 + (size_t)r0 * tstride, tstride,
+                            (TEXT || r0 != 0) ? nullptr : base + D, Vs + r0 * RS, krow0 + D + (size_t)r0 * tstride,
+                            tstride, (TEXT || r0 != 0) ? nullptr : base + 2 * D, pad, nkeys - r0, tid);
+    }
   }
   __syncthreads();
 
@@ -89,72 +104,107 @@ __global__ __launch_bounds__(NT, (NKT <= 13 ? 4 : 2)) void space_fwd_kernel(
       qn0 = *reinterpret_cast<const uint4*>(q_ptr(qt + NW));
       qn1 = *reinterpret_cast<const uint4*>(q_ptr(qt + NW) + 32);
     }
-    // two sweeps over the key tiles (d 0..31, then d 32..63): consecutive MFMAs are independent, the
-    // accumulate of tile kt is NKT issue slots behind its first half, so nothing waits on MFMA latency
-    f32x4 acc[NKT];
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-      const bf16x8 a0 = as_bf16x8(tile_frag(Ks, kt, fo.a[0]));
-      acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, qf0, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-    }
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-      const bf16x8 a1 = as_bf16x8(tile_frag(Ks, kt, fo.a[1]));
-      acc[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, qf1, acc[kt], 0, 0, 0);
-    }
-    // acc[kt][r] = raw S[query c][key kt*16 + g*4 + r]. Space groups: NKT = ceil(nkeys/16) exactly, so only the
-    // last tile can hold padded keys (compile-time); text: causal mask on every tile. The CLS query sees the
-    // cls key (row 0) only in frame 0, so that the F partials count it once.
-    if (cls_tile && f != 0 && g == 0) acc[0][0] = -INFINITY;
-    float m = -INFINITY;
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-      if (TEXT || kt == NKT - 1) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = kt * 16 + g * 4 + r;
-          const bool vis = key < nkeys && (!TEXT || key <= qrow);
-          acc[kt][r] = vis ? acc[kt][r] : -INFINITY;
-        }
-      }
-      m = fmaxf(m, fmaxf(fmaxf(acc[kt][0], acc[kt][1]), fmaxf(acc[kt][2], acc[kt][3])));
-    }
-    m = fmaxf(m, __shfl_xor(m, 16, 64));
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
-    const float mk = m * kExp2;
-    float l = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float p = __builtin_amdgcn_exp2f(fmaf(acc[kt][r], kExp2, -mk));
-        acc[kt][r] = p;
-        l += p;
-      }
-    }
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
-
+    // Key tiles are swept in register groups of GS tiles (one group = all tiles for the 8-wave kernels: exact
+    // single pass; the large-group variant keeps 12 score tiles in registers at a time and rescales the running
+    // (max, sum, O) flash-style between groups -- K and V stay LDS-resident, nothing is re-read). Per group: two
+    // sweeps over its tiles (d 0..31, then d 32..63): consecutive MFMAs are independent, the accumulate of a tile
+    // is GS issue slots behind its first half, so nothing waits on MFMA latency.
+    constexpr int GS = NKT <= 17 ? NKT : 12;
+    constexpr int NG = (NKT + GS - 1) / GS;
+    float m = -INFINITY, l = 0.f;            // running max (raw score units) and this lane's share of the row sum
     f32x4 o[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < (NKT + 1) / 2; ++j) {
-      constexpr int last = NKT - 1;
-      const int j1 = 2 * j + 1 <= last ? 2 * j + 1 : last;
-      uint4 pa;
-      pa.x = pack_bf16x2(acc[2 * j][0], acc[2 * j][1]);
-      pa.y = pack_bf16x2(acc[2 * j][2], acc[2 * j][3]);
-      pa.z = 2 * j + 1 <= last ? pack_bf16x2(acc[j1][0], acc[j1][1]) : 0u;
-      pa.w = 2 * j + 1 <= last ? pack_bf16x2(acc[j1][2], acc[j1][3]) : 0u;
+    for (int gi = 0; gi < NG; ++gi) {
+      const int t0 = gi * GS;                         // first tile of the group (compile-time after unrolling)
+      const int gn = NKT - t0 < GS ? NKT - t0 : GS;   // tiles in this group
+      f32x4 acc[GS];
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        const uint2 lo = tile_frag_tr(Vs, 2 * j, fo.tr[dt]);
-        uint2 hi = make_uint2(0, 0);
-        if (2 * j + 1 <= last) hi = tile_frag_tr(Vs, 2 * j + 1, fo.tr[dt]);
-        o[dt] = mfma(pa, make_uint4(lo.x, lo.y, hi.x, hi.y), o[dt]);
+      for (int k = 0; k < GS; ++k) {
+        if (k < gn) {
+          const bf16x8 a0 = as_bf16x8(tile_frag(Ks, t0 + k, fo.a[0]));
+          acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, qf0, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < GS; ++k) {
+        if (k < gn) {
+          const bf16x8 a1 = as_bf16x8(tile_frag(Ks, t0 + k, fo.a[1]));
+          acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, qf1, acc[k], 0, 0, 0);
+        }
+      }
+      // acc[k][r] = raw S[query c][key (t0+k)*16 + g*4 + r]. Space groups: NKT = ceil(nkeys/16) exactly, so only
+      // the last tile can hold padded keys (compile-time); text: causal mask on every tile. The CLS query sees
+      // the cls key (row 0) only in frame 0, so that the F partials count it once.
+      if (gi == 0 && cls_tile && f != 0 && g == 0) acc[0][0] = -INFINITY;
+      float mg = -INFINITY;
+#pragma unroll
+      for (int k = 0; k < GS; ++k) {
+        if (k < gn) {
+          const int kt = t0 + k;
+          if (TEXT || MASKALL || kt == NKT - 1) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int key = kt * 16 + g * 4 + r;
+              const bool vis = key < nkeys && (!TEXT || key <= qrow);
+              acc[k][r] = vis ? acc[k][r] : -INFINITY;
+            }
+          }
+          mg = fmaxf(mg, fmaxf(fmaxf(acc[k][0], acc[k][1]), fmaxf(acc[k][2], acc[k][3])));
+        }
+      }
+      mg = fmaxf(mg, __shfl_xor(mg, 16, 64));
+      mg = fmaxf(mg, __shfl_xor(mg, 32, 64));
+      if (NG > 1) {
+        // rescale what the earlier groups accumulated; a group (or everything so far) may be fully masked: -inf
+        const float mn = fmaxf(m, mg);
+        const float al = (m == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((m - mn) * kExp2);
+        l *= al;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          // o[dt][r] belongs to query g*4+r; al belongs to query c: fetch the factor of the right query
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[dt][r] *= __shfl(al, g * 4 + r, 64);
+        }
+        m = mn;
+      } else {
+        m = mg;
+      }
+      const float mk = (m == -INFINITY) ? 0.f : m * kExp2;
+#pragma unroll
+      for (int k = 0; k < GS; ++k) {
+        if (k < gn) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float p = __builtin_amdgcn_exp2f(fmaf(acc[k][r], kExp2, -mk));
+            acc[k][r] = p;
+            l += p;
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < (GS + 1) / 2; ++j) {
+        if (2 * j < gn) {
+          const bool two = 2 * j + 1 < gn;
+          const int j1 = two ? 2 * j + 1 : 2 * j;
+          uint4 pa;
+          pa.x = pack_bf16x2(acc[2 * j][0], acc[2 * j][1]);
+          pa.y = pack_bf16x2(acc[2 * j][2], acc[2 * j][3]);
+          pa.z = two ? pack_bf16x2(acc[j1][0], acc[j1][1]) : 0u;
+          pa.w = two ? pack_bf16x2(acc[j1][2], acc[j1][3]) : 0u;
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+            const uint2 lo = tile_frag_tr(Vs, t0 + 2 * j, fo.tr[dt]);
+            uint2 hi = make_uint2(0, 0);
+            if (two) hi = tile_frag_tr(Vs, t0 + 2 * j + 1, fo.tr[dt]);
+            o[dt] = mfma(pa, make_uint4(lo.x, lo.y, hi.x, hi.y), o[dt]);
+          }
+        }
       }
     }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
     // o[dt][r] = O[query g*4+r][d = dt*16 + c]
     if (cls_tile) {
       // record of the CLS query over this frame's keys: (max, sum, un-normalised acc[64]) = column/row 0
@@ -202,14 +252,14 @@ __global__ __launch_bounds__(64) void cls_combine_kernel(const float* __restrict
   if (d == 0) lse[((size_t)b * H + h) * T] = M + __logf(Lsum);
 }
 
-template <int NKT, bool TEXT = false>
+template <int NKT, bool TEXT = false, int NW = 8, bool MASKALL = false>
 int launch_space_fwd(const void* qkv, void* out, float* lse, float* ws, int B, int F, int N, int H, hipStream_t st) {
-  using L = SpaceLds<NKT>;
+  using L = SpaceLds<NKT, NW>;
   static_assert(L::total <= 160 * 1024, "LDS per CU");   // <= 80 KB (NKT <= 13) keeps 2 workgroups per CU
   if (L::total > 64 * 1024)
-    if (int rc = lvl_allow_lds<space_fwd_kernel<NKT, TEXT>>()) return rc;
-  hipLaunchKernelGGL((space_fwd_kernel<NKT, TEXT>), dim3((unsigned)(B * F * H)), dim3(NT), L::total, st,
-                     (const uint16_t*)qkv, (uint16_t*)out, lse, ws, F, N, H);
+    if (int rc = lvl_allow_lds<space_fwd_kernel<NKT, TEXT, NW, MASKALL>>()) return rc;
+  hipLaunchKernelGGL((space_fwd_kernel<NKT, TEXT, NW, MASKALL>), dim3((unsigned)(B * F * H)), dim3(NW * 64), L::total,
+                     st, (const uint16_t*)qkv, (uint16_t*)out, lse, ws, F, N, H);
   LVL_CHECK_LAUNCH("space_fwd_mfma");
   if (TEXT) return LVL_OK;
   hipLaunchKernelGGL(cls_combine_kernel, dim3((unsigned)(B * H)), dim3(64), 0, st, ws, (uint16_t*)out, lse, F,
@@ -224,7 +274,7 @@ void lvl_launch_cls_combine(const float* ws, void* out, float* lse, int B, int H
   hipLaunchKernelGGL(cls_combine_kernel, dim3((unsigned)(B * H)), dim3(64), 0, st, ws, (uint16_t*)out, lse, nparts, T, H);
 }
 
-bool lvl_space_mfma_supported(int F, int N) { return N + 1 <= 272 && N >= 1 && F <= 64; }
+bool lvl_space_mfma_supported(int F, int N) { return N + 1 <= kBigTiles * 16 && N >= 1 && F <= 64; }
 
 int lvl_space_mfma_fwd(const void* qkv, void* out, float* lse, float* ws, int B, int F, int N, int H, hipStream_t st) {
   const int nkeys = N + 1;
@@ -235,6 +285,10 @@ int lvl_space_mfma_fwd(const void* qkv, void* out, float* lse, float* ws, int B,
     SPACE_FWD_CASE(13) SPACE_FWD_CASE(14) SPACE_FWD_CASE(15) SPACE_FWD_CASE(16) SPACE_FWD_CASE(17)
 #undef SPACE_FWD_CASE
   }
+  // large groups: 4 waves, up to 592 keys resident; the exact-tile-count instantiation for 577..592 keys
+  // (TSF-L/14 at 336), every tile masked otherwise
+  if ((nkeys + 15) / 16 == kBigTiles) return launch_space_fwd<kBigTiles, false, 4, false>(qkv, out, lse, ws, B, F, N, H, st);
+  if (nkeys <= kBigTiles * 16) return launch_space_fwd<kBigTiles, false, 4, true>(qkv, out, lse, ws, B, F, N, H, st);
   return lvl_fail(LVL_ENOSYS, "space_mfma_fwd: %d keys per group exceeds the LDS-resident kernel", nkeys);
 }
 

@@ -14,7 +14,7 @@ mode = sys.argv[1] if len(sys.argv) > 1 else 'space'
 what = sys.argv[2] if len(sys.argv) > 2 else 'fwd'
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 20
-F, N, H = int(os.environ.get('PROBE_F', '4')), 196, 12
+F, N, H = int(os.environ.get('PROBE_F', '4')), int(os.environ.get('PROBE_N', '196')), int(os.environ.get('PROBE_H', '12'))
 T, D = 1 + F * N, 64 * H
 g = torch.Generator(device='cuda').manual_seed(0)
 qkv = (torch.randn(B, T, 3 * D, device='cuda', generator=g) * 1.0).bfloat16().requires_grad_(True)
