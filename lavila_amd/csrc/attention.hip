@@ -12,6 +12,14 @@ int lvl_generic_causal_bwd(const void* qkv, const void* out, const void* dout, c
 bool lvl_space_mfma_supported(int F, int N);
 int lvl_space_mfma_fwd(const void* qkv, void* out, float* lse, float* ws, int B, int F, int N, int H, hipStream_t st);
 bool lvl_time_fast_supported(int F, int N, int H);
+bool lvl_time_mfma_supported(int F, int N, int H);
+int lvl_time_mfma_fwd(const void* qkv, void* out, float* lse, float* ws, int B, int F, int N, int H, hipStream_t st);
+int lvl_time_mfma_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* ws,
+                      int B, int F, int N, int H, hipStream_t st);
+// 5..16 frames: the MFMA kernels (attn_time_mfma.hip; 4.2 TB/s forward at 16 frames against 1.0 TB/s for the
+// register-tiled kernels, profiles/r02_time_attention_mfma_vs_valu.txt); up to 4 frames, or a head count that is not
+// a multiple of 4: the register-tiled kernels
+static bool time_use_mfma(int F, int N, int H) { return lvl_time_mfma_supported(F, N, H); }
 bool lvl_text_mfma_supported(int L);
 int lvl_text_mfma_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, hipStream_t st);
 bool lvl_text_mfma_bwd_supported(int L);
@@ -42,6 +50,8 @@ extern "C" int lvl_divided_attn_fwd(const void* qkv, void* out, float* lse, floa
   if (B == 0) return LVL_OK;
   if (dtype == LVL_BF16 && mode == LVL_ATTN_SPACE && lvl_space_mfma_supported(F, N))
     return lvl_space_mfma_fwd(qkv, out, lse, ws, B, F, N, H, (hipStream_t)stream);
+  if (dtype == LVL_BF16 && mode == LVL_ATTN_TIME && time_use_mfma(F, N, H))
+    return lvl_time_mfma_fwd(qkv, out, lse, ws, B, F, N, H, (hipStream_t)stream);
   if (dtype == LVL_BF16 && mode == LVL_ATTN_TIME && lvl_time_fast_supported(F, N, H))
     return lvl_time_fast_fwd(qkv, out, lse, ws, B, F, N, H, (hipStream_t)stream);
   return lvl_generic_divided_fwd(qkv, out, lse, B, F, N, H, mode, dtype, (hipStream_t)stream, true, true);
@@ -55,6 +65,8 @@ extern "C" int lvl_divided_attn_bwd(const void* qkv, const void* out, const void
   if (B == 0) return LVL_OK;
   if (dtype == LVL_BF16 && mode == LVL_ATTN_SPACE && lvl_space_mfma_bwd_supported(F, N))
     return lvl_space_mfma_bwd(qkv, out, dout, lse, dqkv, ws, B, F, N, H, (hipStream_t)stream);
+  if (dtype == LVL_BF16 && mode == LVL_ATTN_TIME && time_use_mfma(F, N, H))
+    return lvl_time_mfma_bwd(qkv, out, dout, lse, dqkv, ws, B, F, N, H, (hipStream_t)stream);
   if (dtype == LVL_BF16 && mode == LVL_ATTN_TIME && lvl_time_fast_bwd_supported(F, N, H))
     return lvl_time_fast_bwd(qkv, out, dout, lse, dqkv, ws, B, F, N, H, (hipStream_t)stream);
   return lvl_generic_divided_bwd(qkv, out, dout, lse, dqkv, ws, B, F, N, H, mode, dtype, (hipStream_t)stream);
@@ -86,7 +98,8 @@ extern "C" int lvl_causal_attn_bwd(const void* qkv, const void* out, const void*
 // the shape-generic kernels of attn_generic.hip (correct, latency-bound). Host-side query, no device work.
 extern "C" int lvl_attention_fast_path(int mode, int F, int N, int H) {
   if (mode == LVL_ATTN_SPACE) return lvl_space_mfma_supported(F, N) && lvl_space_mfma_bwd_supported(F, N);
-  if (mode == LVL_ATTN_TIME) return lvl_time_fast_supported(F, N, H) && lvl_time_fast_bwd_supported(F, N, H);
+  if (mode == LVL_ATTN_TIME)
+    return lvl_time_mfma_supported(F, N, H) || (lvl_time_fast_supported(F, N, H) && lvl_time_fast_bwd_supported(F, N, H));
   if (mode == LVL_ATTN_CAUSAL) return lvl_text_mfma_supported(N) && lvl_text_mfma_bwd_supported(N);
   return 0;
 }

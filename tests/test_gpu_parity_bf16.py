@@ -72,7 +72,9 @@ def _check_exact(qkv, dout, out_want, dv_want, run):
 
 @pytest.mark.parametrize('mode,B,Fr,N,H', [('space', 2, 4, 196, 12), ('time', 2, 4, 196, 12), ('space', 1, 2, 49, 3),
                                            ('time', 1, 16, 4, 2), ('time', 1, 8, 9, 2), ('space', 1, 1, 256, 16),
-                                           ('space', 1, 2, 576, 2), ('space', 1, 1, 400, 2), ('space', 1, 3, 591, 1)])
+                                           ('space', 1, 2, 576, 2), ('space', 1, 1, 400, 2), ('space', 1, 3, 591, 1),
+                                           ('time', 1, 16, 9, 4), ('time', 2, 8, 5, 4), ('time', 1, 12, 7, 8), ('time', 1, 5, 6, 4),
+                                           ('time', 1, 16, 100, 12)])
 def test_divided_attention_one_hot_exact(mode, B, Fr, N, H):
     """Every query picks one key of its group (cls | same frame | same location; cls query: any token): the bf16 MFMA /
     register-tiled kernels must reproduce v[target] and the scatter-added dv exactly (timesformer.py:110-140)."""
