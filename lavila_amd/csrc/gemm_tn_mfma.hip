@@ -239,13 +239,31 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
     const int64_t m0 = (int64_t)tm * TM;
     const int n0 = tn * TN;
     float csum[32];
+    // EPI 2: the 8 pre-activation pieces of a row group are loaded one row group AHEAD (issued before the previous
+    // group's stores, so their latency overlaps its arithmetic instead of serialising eight round trips per tile)
+    uint2 ub_next[EPI == 2 ? 8 : 1];
+    auto load_u = [&](int j) {
+      const int64_t m = m0 + (j >> 1) * 128 + wm * 64 + (j & 1) * 32 + r5;
+      const uint16_t* urow = aux_in + (m < M ? m : M - 1) * (int64_t)N + n0 + wn * 64 + 4 * hi;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) ub_next[i * 4 + rq] = *reinterpret_cast<const uint2*>(urow + i * 32 + 8 * rq);
+    };
     if (EPI == 2) {
 #pragma unroll
       for (int c = 0; c < 32; ++c) csum[c] = 0.f;
+      load_u(0);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {          // row group (qm, mt): 32 rows
       const int64_t mg = m0 + (j >> 1) * 128 + wm * 64 + (j & 1) * 32;
+      uint2 ub_cur[EPI == 2 ? 8 : 1];
+      if (EPI == 2) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) ub_cur[q] = ub_next[q];
+        if (j < 3) load_u(j + 1);
+      }
       uint4 yv[2][2], uv[2][2];           // [qn][jj]: 16 bytes = columns qn*32 + 16*jj + 8*hi .. +7 of row r5
 #pragma unroll
       for (int i = 0; i < 2; ++i) {        // column group qn
@@ -267,9 +285,8 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
             v[3] = quick_gelu(__uint_as_float(upk[rq].y & 0xffff0000u));
           }
           if (EPI == 2) {
-            const int64_t m = mg + r5;
-            const bool valid = m < M;
-            const uint2 ub = *reinterpret_cast<const uint2*>(aux_in + (valid ? m : M - 1) * (int64_t)N + n0 + nl);
+            const bool valid = mg + r5 < M;
+            const uint2 ub = ub_cur[i * 4 + rq];
             v[0] *= quick_gelu_grad(__uint_as_float(ub.x << 16));
             v[1] *= quick_gelu_grad(__uint_as_float(ub.x & 0xffff0000u));
             v[2] *= quick_gelu_grad(__uint_as_float(ub.y << 16));
