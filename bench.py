@@ -273,13 +273,14 @@ def main():
             or roofline_hbm
         roofline_wgrad = mfma_roofline(wtimer, 'lvl_linear_wgrad (wgrad_kernel<4,2,6,6,false> + its partial-tile '
                                        'reduction, all video-tower weight gradients)', 'r02_traffic_wgrad.json')
+        tower = 'TSF-L/14' if 'LARGE' in args.model else 'TSF-B/16'
         line = {
-            'metric': f'clip-text pairs/s (whole node), TSF-B/16 {Fr}x{img}^2 + CLIP text tower, fwd+loss+bwd+AdamW',
+            'metric': f'clip-text pairs/s (whole node), {tower} {Fr}x{img}^2 + CLIP text tower, fwd+loss+bwd+AdamW',
             'value': round(world * B * args.steps / elapsed, 2), 'unit': 'clip-text pairs/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'bf16' if amp is not None else 'f32', 'data': 'synthetic',
-            'config': {'workload': f'{args.model}: TSF-B/16 {Fr}x{img}^2 clips + 32-token captions (77 ctx), '
+            'config': {'workload': f'{args.model}: {tower} {Fr}x{img}^2 clips + 32-token captions (77 ctx), '
                                    f'local batch {B}, global batch {world * B}, contrastive all-gather over RCCL',
                        'global_batch': world * B, 'parallelism': f'dp{world}', 'final_loss': round(final_loss, 4),
                        'linear_gemms': 'lvl_linear_tn / lvl_linear_wgrad (hand-written MFMA; no library GEMM on the path)'},

@@ -6,6 +6,7 @@ reference's training loop (loss.backward(), DDP hooks, AdamW) works unchanged. P
 (gamma/beta/bias/embeddings) are always passed to the kernels as float32.
 """
 import os
+import weakref
 from typing import Optional
 
 import torch
@@ -33,6 +34,7 @@ def _rows_cols(x: torch.Tensor):
 # Linear layers: hand-written MFMA GEMMs (forward / input gradient: lvl_linear_tn, weight gradient: lvl_linear_wgrad)
 # --------------------------------------------------------------------------------------------------
 _warned = set()
+_copies = {}          # (id(parameter), shape) -> (version, bf16 copy, transposed bf16 copy, data_ptr)
 
 
 def warn_once(key, msg):
@@ -48,15 +50,16 @@ def weight_copies(weight: torch.Tensor):
     GEMM reads (both operands of lvl_linear_tn are contraction-contiguous). One lvl_cast_transpose pass per optimizer
     step: the pair is cached on the parameter and keyed by its version counter, so activation checkpointing's second
     forward and every backward reuse it."""
-    # a 2-D view of a parameter (the Conv2d weight of the patch embedding) caches on the parameter itself
+    # keyed by the identity of the parameter (a 2-D view of one -- the Conv2d weight of the patch embedding -- keys on
+    # its base); a weakref finaliser drops the entry with the parameter, nothing is attached to the parameter itself
+    # (pickling / deepcopy of the model see no extra state)
     holder = weight._base if weight._base is not None else weight
-    ver, key = weight._version, tuple(weight.shape)
-    cache = getattr(holder, '_lvl_copies', None)
-    if cache is None:
-        cache = holder._lvl_copies = {}
-    c = cache.get(key)
-    if c is not None and c[0] == ver and c[1].device == weight.device:
+    ver, key = weight._version, (id(holder), tuple(weight.shape))
+    c = _copies.get(key)
+    if c is not None and c[0] == ver and c[3] == weight.data_ptr():      # same values, same storage
         return c[1], c[2]
+    if c is None:
+        weakref.finalize(holder, _copies.pop, key, None)
     src = weight.detach()
     if src.dtype == torch.float32 and src.is_contiguous():
         w = torch.empty_like(src, dtype=torch.bfloat16)
@@ -66,7 +69,7 @@ def weight_copies(weight: torch.Tensor):
     else:
         w = src.to(torch.bfloat16).contiguous()
         wt = w.t().contiguous()
-    cache[key] = (ver, w, wt)
+    _copies[key] = (ver, w, wt, weight.data_ptr())
     return w, wt
 
 
