@@ -61,7 +61,20 @@ def _worker(rank, world, port, q):
              if k in ('visual.blocks.0.timeattn.qkv.weight', 'visual.blocks.1.attn.qkv.bias', 'visual.blocks.1.mlp.fc1.weight',
                       'transformer.resblocks.0.attn.in_proj_bias', 'transformer.resblocks.1.mlp.c_fc.weight', 'logit_scale',
                       'visual.cls_token', 'text_projection')}
-    q.put((rank, losses, grads))
+    # main_pretrain.py:215-219 (--use-zero): ZeroRedundancyOptimizer shards the AdamW state over the ranks; one step of
+    # it must move the parameters exactly like a plain AdamW step on the same (DDP-averaged) gradients
+    from torch.distributed.optim import ZeroRedundancyOptimizer
+    kw = dict(lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    before = {k: p.detach().clone() for k, p in model.named_parameters()}
+    zero = ZeroRedundancyOptimizer(model.parameters(), optimizer_class=torch.optim.AdamW, **kw)
+    zero.step()
+    after_zero = {k: p.detach().clone() for k, p in model.named_parameters()}
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            p.copy_(before[k])
+    torch.optim.AdamW(model.parameters(), **kw).step()
+    zero_diff = max((after_zero[k] - p.detach()).abs().max().item() for k, p in model.named_parameters())
+    q.put((rank, losses, grads, zero_diff))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -100,7 +113,8 @@ def test_ddp_two_ranks_on_one_device_match_global_oracle_gradient():
     oo = O.clip_forward(video, tokens, wo, CFG['heads'], CFG['t_heads'], norm_embed=True)
     lo = O.clip_loss(oo['image_embed'], oo['text_embed'], oo['logit_scale'])
     lo['loss'].backward()
-    for rank, losses, grads in got:
+    for rank, losses, grads, zero_diff in got:
+        assert zero_diff < 1e-6, zero_diff        # ZeRO-sharded AdamW == plain AdamW on the same gradients
         assert abs(losses[0] - lo['loss'].item()) < 1e-4 and abs(losses[1] - losses[0]) < 1e-6
         for k, g in grads.items():
             g = torch.tensor(g)
