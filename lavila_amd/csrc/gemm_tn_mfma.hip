@@ -482,10 +482,18 @@ __global__ __launch_bounds__(256) void colpart_reduce_kernel(const float* __rest
   const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
   const int n = blockIdx.x * 64 + cx;
   const int G = gridDim.y, g = blockIdx.y;
-  float a = 0.f;
-  if (n < N)
-    for (int p = g + ry * G; p < P; p += 4 * G) a += part[(size_t)p * N + n];
-  red[ry][cx] = a;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  if (n < N) {                          // 4 loads in flight: a latency chain otherwise
+    int p = g + ry * G;
+    for (; p + 12 * G < P; p += 16 * G) {
+      a0 += part[(size_t)p * N + n];
+      a1 += part[(size_t)(p + 4 * G) * N + n];
+      a2 += part[(size_t)(p + 8 * G) * N + n];
+      a3 += part[(size_t)(p + 12 * G) * N + n];
+    }
+    for (; p < P; p += 4 * G) a0 += part[(size_t)p * N + n];
+  }
+  red[ry][cx] = (a0 + a1) + (a2 + a3);
   __syncthreads();
   if (ry == 0 && n < N) out[(size_t)g * N + n] = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
 }

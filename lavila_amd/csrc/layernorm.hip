@@ -297,18 +297,18 @@ __global__ __launch_bounds__(256) void column_reduce_kernel(const float* __restr
   __shared__ float red[16][16];
   const int col = threadIdx.x & 15, pg = threadIdx.x >> 4;
   const int k = blockIdx.x * 16 + col;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (k < width) {
+    // 8 independent loads in flight per thread: the kernel is a latency chain (7 MB behind 144 workgroups), the
+    // slab rows a thread walks are 16 apart
     int p = pg;
-    for (; p + 48 < nparts; p += 64) {
-      a0 += part[(size_t)p * width + k];
-      a1 += part[(size_t)(p + 16) * width + k];
-      a2 += part[(size_t)(p + 32) * width + k];
-      a3 += part[(size_t)(p + 48) * width + k];
+    for (; p + 112 < nparts; p += 128) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a[i] += part[(size_t)(p + 16 * i) * width + k];
     }
-    for (; p < nparts; p += 16) a0 += part[(size_t)p * width + k];
+    for (; p < nparts; p += 16) a[0] += part[(size_t)p * width + k];
   }
-  red[pg][col] = (a0 + a1) + (a2 + a3);
+  red[pg][col] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   __syncthreads();
   if (pg == 0 && k < width) {
     float acc = 0.f;
