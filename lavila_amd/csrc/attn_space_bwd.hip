@@ -9,7 +9,10 @@
 // read (ds_read_b64_tr_b16, attn_mfma_common.h) as B operands, while the A operand is the freshly computed
 // tile itself: the C layout of S^T (resp. S) puts one query (resp. key) per lane, which is exactly the
 // A-fragment layout with a permuted k-order (same trick as the forward's P.V). No transposed copies exist.
-// Two kernels, each one workgroup of 8 waves per (b, f, h), two workgroups per CU (<= 80 KB LDS, <= 128 VGPRs):
+// Video groups of up to 288 keys run on the FUSED kernel further down (one kernel, every operand staged once,
+// 32 x 32 register blocks, the cls query handled as one more query row). The causal text tower and the large groups
+// (289..592 keys, whose K+V or Q+dO images alone fill the LDS) use the two-kernel form, each kernel one workgroup
+// per (b, f, h):
 //   dq kernel : waves own 16-query tiles, all keys resident (K, V images) -> dQ, delta
 //   dkv kernel: waves own 16-key tiles, all queries resident (Q, dO images) -> dK, dV; also folds in the CLS
 //               query's rank-1 contributions to dK/dV (it attends to every key, timesformer.py:116-119) and
@@ -386,6 +389,345 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 1 : 4)) void space_bwd_dkv_kern
   if (tid < 64) atomicAdd(atom_ws + ((size_t)b * H + h) * 192 + tid, dqc[tid] * 0.125f);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Fused backward of the video groups: ONE kernel stages every operand once
+// ------------------------------------------------------------------------------------------------------------
+// The two kernels above read q, k, v, dO from HBM twice and block 16 keys (queries) per wave, so every Q/dO (K/V)
+// fragment is re-read from LDS for every tile; the cls query is folded in by a separate scalar section. Here a
+// workgroup of 4 waves (two workgroups per CU, <= 256 VGPRs) runs both passes over ONE pair of LDS images, blocks
+// 32 x 32, and treats the cls query as query row N of the group (it attends to the frame's patch keys, and to the cls
+// key in frame 0 only -- timesformer.py:116-119 -- with its own global lse):
+//   phase 1  images = K, V. A wave owns 32 queries (fragments straight from global): every K/V fragment read feeds
+//            two query tiles; dQ is accumulated as soon as a key pair's dS is packed; delta and lse of the group's
+//            queries stay in LDS for phase 2. The partial dQ of the cls row goes to the f32 atomic slab.
+//   phase 2  images = Q, dO (re-staged over K, V; the loads fly while the slower waves finish phase 1). A wave owns
+//            32 keys: every Q/dO fragment and every transpose read feeds two key tiles.
+// All gradient tiles are accumulated TRANSPOSED (channels x rows: the weight-like operand goes first), so a lane ends
+// up with 4 consecutive channels of one token and stores them directly -- no LDS transposition of the results.
+template <int NKP> struct FusedLds {
+  static constexpr int R = NKP * 32;                       // image rows: keys padded to whole pairs of tiles
+  static constexpr int img0_off = 0;
+  static constexpr int img1_off = R * RS * 2;
+  static constexpr int lse_off = 2 * R * RS * 2;
+  static constexpr int del_off = lse_off + R * 4;
+  static constexpr int total = del_off + R * 4;
+};
+
+// o[dt][r] = X^T[channel dt*16 + g*4 + r][token lane&15] -> 4 x 8-byte stores of one token row
+__device__ __forceinline__ void store_token_channels(uint16_t* row, const f32x4 (&o)[4], float mul, int g) {
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+    *reinterpret_cast<uint2*>(row + dt * 16 + g * 4) =
+        make_uint2(pack_bf16x2(o[dt][0] * mul, o[dt][1] * mul), pack_bf16x2(o[dt][2] * mul, o[dt][3] * mul));
+}
+__device__ __forceinline__ void atomic_token_channels(float* dst, const f32x4 (&o)[4], float mul, int g) {
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) atomicAdd(dst + dt * 16 + g * 4 + r, o[dt][r] * mul);
+}
+
+template <int NKP>
+__global__ __launch_bounds__(256, 2) void space_bwd_fused_kernel(
+    const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out, const uint16_t* __restrict__ dout,
+    const float* __restrict__ lse, uint16_t* __restrict__ dqkv, float* __restrict__ atom_ws, int F, int N, int H) {
+  constexpr int NW = 4, NT = 256, R = NKP * 32;
+  using L = FusedLds<NKP>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint16_t* img0 = reinterpret_cast<uint16_t*>(smem + L::img0_off);      // K, then Q
+  uint16_t* img1 = reinterpret_cast<uint16_t*>(smem + L::img1_off);      // V, then dO
+  float* lse_s = reinterpret_cast<float*>(smem + L::lse_off);            // log2 units
+  float* del_s = reinterpret_cast<float*>(smem + L::del_off);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int h = blockIdx.x % H, f = (blockIdx.x / H) % F, b = blockIdx.x / (H * F);
+  const int D = H * 64, T = 1 + F * N, nkeys = N + 1, tok0 = 1 + f * N;
+  const int nqp = (N + 1 + 31) / 32;                    // query pairs: N patch queries + the cls query (row N)
+  const size_t ts = (size_t)3 * D;
+  const uint16_t* base = qkv + (size_t)b * T * ts + h * 64;
+  const uint16_t* obase = out + (size_t)b * T * D + h * 64;
+  const uint16_t* dobase = dout + (size_t)b * T * D + h * 64;
+  const float* lrow = lse + ((size_t)b * H + h) * T;
+  float* cls_ws = atom_ws + ((size_t)b * H + h) * 192;  // d cls q | d cls k | d cls v
+  const int c = lane & 15, g = lane >> 4;
+  const FragOff fo = frag_offsets(lane);
+  // token of query row qr: patch rows, then the cls token; padding rows alias a valid token (never stored)
+  auto tok_of_row = [&](int qr) { return qr < N ? tok0 + qr : (qr == N ? 0 : tok0); };
+
+  // ---- phase 1: dQ (and delta) --------------------------------------------------------------------------------
+  uint4 qf[2][2], gf[2][2], yf[2][2];
+  float lraw[2];
+  auto load_qfrags = [&](int qp) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int tk = tok_of_row((2 * qp + t) * 16 + c);
+      lraw[t] = lrow[tk];
+      const uint16_t* qptr = base + (size_t)tk * ts + g * 8;
+      qf[t][0] = *reinterpret_cast<const uint4*>(qptr);
+      qf[t][1] = *reinterpret_cast<const uint4*>(qptr + 32);
+      gf[t][0] = *reinterpret_cast<const uint4*>(dobase + (size_t)tk * D + g * 8);
+      gf[t][1] = *reinterpret_cast<const uint4*>(dobase + (size_t)tk * D + g * 8 + 32);
+      yf[t][0] = *reinterpret_cast<const uint4*>(obase + (size_t)tk * D + g * 8);
+      yf[t][1] = *reinterpret_cast<const uint4*>(obase + (size_t)tk * D + g * 8 + 32);
+    }
+  };
+  load_qfrags(wave < nqp ? wave : 0);                    // in flight together with the staging
+
+  for (int i = tid; i < R; i += NT) { lse_s[i] = INFINITY; del_s[i] = 0.f; }      // padded queries: exp2(-inf) = 0
+  {   // key row r = token tok0 + r - 1 (r >= 1) or the cls token (r = 0)
+    const uint16_t* krow0 = base + (size_t)(tok0 - 1) * ts + D;
+    stage_rows2<NT, NKP>(img0, krow0, ts, base + D, img1, krow0 + D, ts, base + 2 * D, R, nkeys, tid);
+  }
+  __syncthreads();
+
+#pragma unroll 1
+  for (int qp = wave; qp < nqp; qp += NW) {
+    if (qp != wave) load_qfrags(qp);
+    float dl[2], Lk[2];
+    bool kill0[2];                                       // (cls query, cls key) outside frame 0: not attended
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      float a[8], bb[8], acc = 0.f;
+      Elem<bf16_t>::load8(reinterpret_cast<const bf16_t*>(&gf[t][0]), a);
+      Elem<bf16_t>::load8(reinterpret_cast<const bf16_t*>(&yf[t][0]), bb);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc = fmaf(a[i], bb[i], acc);
+      Elem<bf16_t>::load8(reinterpret_cast<const bf16_t*>(&gf[t][1]), a);
+      Elem<bf16_t>::load8(reinterpret_cast<const bf16_t*>(&yf[t][1]), bb);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc = fmaf(a[i], bb[i], acc);
+      acc += __shfl_xor(acc, 16, 64);
+      acc += __shfl_xor(acc, 32, 64);
+      dl[t] = acc;
+      const int qrow = (2 * qp + t) * 16 + c;
+      Lk[t] = lraw[t] * kLog2e;
+      kill0[t] = f != 0 && qrow == N && g == 0;
+      if (g == 0 && qrow <= N) { del_s[qrow] = acc; lse_s[qrow] = Lk[t]; }
+    }
+    f32x4 o[2][4];                                       // dQ^T: [channel dt*16 + g*4 + r][query c]
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) o[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int j = 0; j < NKP; ++j) {
+      // S^T = K.Q^T and dP^T = V.dO^T for key tiles 2j, 2j+1 x query tiles 0, 1: each K/V fragment feeds two MFMAs
+      uint4 kf[2][2], vf[2][2];
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          kf[kt][hh] = tile_frag(img0, 2 * j + kt, fo.a[hh]);
+          vf[kt][hh] = tile_frag(img1, 2 * j + kt, fo.a[hh]);
+        }
+      uint4 pa[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+        f32x4 p0 = {-dl[t], -dl[t], -dl[t], -dl[t]}, p1 = p0;     // dP - delta: delta rides in the accumulator
+        s0 = mfma(kf[0][0], qf[t][0], s0);
+        p0 = mfma(vf[0][0], gf[t][0], p0);
+        s1 = mfma(kf[1][0], qf[t][0], s1);
+        p1 = mfma(vf[1][0], gf[t][0], p1);
+        s0 = mfma(kf[0][1], qf[t][1], s0);
+        p0 = mfma(vf[0][1], gf[t][1], p0);
+        s1 = mfma(kf[1][1], qf[t][1], s1);
+        p1 = mfma(vf[1][1], gf[t][1], p1);
+        float d0[4], d1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float e0 = __builtin_amdgcn_exp2f(fmaf(s0[r], kExp2, -Lk[t]));
+          float e1 = __builtin_amdgcn_exp2f(fmaf(s1[r], kExp2, -Lk[t]));
+          if (j == 0 && r == 0) e0 = kill0[t] ? 0.f : e0;
+          if (j == NKP - 1) {            // the padded key rows are zero, but exp2(-lse) may overflow: mask them
+            e0 = (2 * j) * 16 + g * 4 + r < nkeys ? e0 : 0.f;
+            e1 = (2 * j + 1) * 16 + g * 4 + r < nkeys ? e1 : 0.f;
+          }
+          d0[r] = e0 * p0[r];
+          d1[r] = e1 * p1[r];
+        }
+        pa[t] = make_uint4(pack_bf16x2(d0[0], d0[1]), pack_bf16x2(d0[2], d0[3]), pack_bf16x2(d1[0], d1[1]),
+                           pack_bf16x2(d1[2], d1[3]));
+      }
+      // dQ^T += K^T . dS^T for the 32 keys of this pair: A fragments are transpose reads of the K image
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const uint2 lo = tile_frag_tr(img0, 2 * j, fo.tr[dt]);
+        const uint2 hi = tile_frag_tr(img0, 2 * j + 1, fo.tr[dt]);
+        const uint4 kb = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        o[0][dt] = mfma(kb, pa[0], o[0][dt]);
+        o[1][dt] = mfma(kb, pa[1], o[1][dt]);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int qrow = (2 * qp + t) * 16 + c;
+      if (qrow < N)
+        store_token_channels(dqkv + (size_t)b * T * ts + (size_t)(tok0 + qrow) * ts + h * 64, o[t], 0.125f, g);
+      else if (qrow == N)
+        atomic_token_channels(cls_ws, o[t], 0.125f, g);          // this frame's share of d(cls q)
+    }
+  }
+
+  // ---- phase 2: dK, dV ----------------------------------------------------------------------------------------
+  uint4 kk[2][2], vv[2][2];
+  auto load_kv = [&](int kp) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int krow = (2 * kp + t) * 16 + c;
+      kk[t][0] = make_uint4(0, 0, 0, 0); kk[t][1] = kk[t][0]; vv[t][0] = kk[t][0]; vv[t][1] = kk[t][0];
+      if (krow < nkeys) {
+        const uint16_t* kptr = base + (size_t)(krow == 0 ? 0 : tok0 + krow - 1) * ts + D + g * 8;
+        kk[t][0] = *reinterpret_cast<const uint4*>(kptr);
+        kk[t][1] = *reinterpret_cast<const uint4*>(kptr + 32);
+        vv[t][0] = *reinterpret_cast<const uint4*>(kptr + D);
+        vv[t][1] = *reinterpret_cast<const uint4*>(kptr + D + 32);
+      }
+    }
+  };
+  load_kv(wave < NKP ? wave : 0);
+  {   // Q and dO rows (patch queries, then the cls query as row N): the loads fly while the slower waves finish
+      // phase 1, the images are overwritten after the barrier
+    constexpr int RPP = NT / 8;
+    const int c8 = tid & 7, r_in = tid >> 3;
+    uint4 va[NKP], vb[NKP];
+#pragma unroll
+    for (int p = 0; p < NKP; ++p) {
+      const int qr = p * RPP + r_in;
+      va[p] = make_uint4(0, 0, 0, 0);
+      vb[p] = va[p];
+      if (qr <= N) {
+        const int tk = qr < N ? tok0 + qr : 0;
+        va[p] = *reinterpret_cast<const uint4*>(base + (size_t)tk * ts + c8 * 8);
+        vb[p] = *reinterpret_cast<const uint4*>(dobase + (size_t)tk * D + c8 * 8);
+      }
+    }
+    __syncthreads();                                      // every wave is done with the K, V images
+#pragma unroll
+    for (int p = 0; p < NKP; ++p) {
+      *reinterpret_cast<uint4*>(img0 + img_off(p * RPP + r_in, c8)) = va[p];
+      *reinterpret_cast<uint4*>(img1 + img_off(p * RPP + r_in, c8)) = vb[p];
+    }
+  }
+  __syncthreads();
+
+  const int cls_qp = N >> 5, cls_sub = N & 31;            // where the cls query sits in the pair loop
+#pragma unroll 1
+  for (int kp = wave; kp < NKP; kp += NW) {
+    if (kp != wave) load_kv(kp);
+    f32x4 adk[2][4], adv[2][4];                          // dK^T, dV^T: [channel dt*16 + g*4 + r][key c]
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) { adk[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; adv[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+#pragma unroll 1
+    for (int qp = 0; qp < nqp; ++qp) {
+      const uint16_t* Qp = img0 + qp * 32 * RS;          // 32-query slab of the two images
+      const uint16_t* Gp = img1 + qp * 32 * RS;
+      uint4 qa[2][2], ga[2][2];
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          qa[qt][hh] = tile_frag(Qp, qt, fo.a[hh]);
+          ga[qt][hh] = tile_frag(Gp, qt, fo.a[hh]);
+        }
+      const float4 ls0 = *reinterpret_cast<const float4*>(lse_s + qp * 32 + g * 4);
+      const float4 ls1 = *reinterpret_cast<const float4*>(lse_s + qp * 32 + 16 + g * 4);
+      const float4 de0 = *reinterpret_cast<const float4*>(del_s + qp * 32 + g * 4);
+      const float4 de1 = *reinterpret_cast<const float4*>(del_s + qp * 32 + 16 + g * 4);
+      const float lsa[8] = {ls0.x, ls0.y, ls0.z, ls0.w, ls1.x, ls1.y, ls1.z, ls1.w};
+      const float dea[8] = {de0.x, de0.y, de0.z, de0.w, de1.x, de1.y, de1.z, de1.w};
+      // (cls query, cls key) outside frame 0 is not attended: one element of key tile 0
+      const bool kill_pair = f != 0 && kp == 0 && qp == cls_qp && c == 0;
+      uint4 pa[2], da[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+        f32x4 p0 = {-dea[0], -dea[1], -dea[2], -dea[3]}, p1 = {-dea[4], -dea[5], -dea[6], -dea[7]};    // dP - delta
+        s0 = mfma(qa[0][0], kk[t][0], s0);
+        s1 = mfma(qa[1][0], kk[t][0], s1);
+        p0 = mfma(ga[0][0], vv[t][0], p0);
+        p1 = mfma(ga[1][0], vv[t][0], p1);
+        s0 = mfma(qa[0][1], kk[t][1], s0);
+        s1 = mfma(qa[1][1], kk[t][1], s1);
+        p0 = mfma(ga[0][1], vv[t][1], p0);
+        p1 = mfma(ga[1][1], vv[t][1], p1);
+        float e0[4], e1[4], d0[4], d1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          e0[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], kExp2, -lsa[r]));
+          e1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], kExp2, -lsa[4 + r]));
+          if (t == 0) {
+            e0[r] = (kill_pair && g * 4 + r == cls_sub) ? 0.f : e0[r];
+            e1[r] = (kill_pair && 16 + g * 4 + r == cls_sub) ? 0.f : e1[r];
+          }
+          d0[r] = e0[r] * p0[r];
+          d1[r] = e1[r] * p1[r];
+        }
+        pa[t] = make_uint4(pack_bf16x2(e0[0], e0[1]), pack_bf16x2(e0[2], e0[3]), pack_bf16x2(e1[0], e1[1]),
+                           pack_bf16x2(e1[2], e1[3]));
+        da[t] = make_uint4(pack_bf16x2(d0[0], d0[1]), pack_bf16x2(d0[2], d0[3]), pack_bf16x2(d1[0], d1[1]),
+                           pack_bf16x2(d1[2], d1[3]));
+      }
+      // dV^T += dO^T P, dK^T += Q^T dS: every transpose read feeds both key tiles
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const uint2 g_lo = tile_frag_tr(Gp, 0, fo.tr[dt]), g_hi = tile_frag_tr(Gp, 1, fo.tr[dt]);
+        const uint2 q_lo = tile_frag_tr(Qp, 0, fo.tr[dt]), q_hi = tile_frag_tr(Qp, 1, fo.tr[dt]);
+        const uint4 gb = make_uint4(g_lo.x, g_lo.y, g_hi.x, g_hi.y), qb = make_uint4(q_lo.x, q_lo.y, q_hi.x, q_hi.y);
+        adv[0][dt] = mfma(gb, pa[0], adv[0][dt]);
+        adk[0][dt] = mfma(qb, da[0], adk[0][dt]);
+        adv[1][dt] = mfma(gb, pa[1], adv[1][dt]);
+        adk[1][dt] = mfma(qb, da[1], adk[1][dt]);
+      }
+    }
+
+    uint16_t* dkb = dqkv + (size_t)b * T * ts + D + h * 64;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int krow = (2 * kp + t) * 16 + c;
+      if (krow >= 1 && krow < nkeys) {
+        uint16_t* row = dkb + (size_t)(tok0 + krow - 1) * ts;
+        store_token_channels(row, adk[t], 0.125f, g);
+        store_token_channels(row + D, adv[t], 1.0f, g);
+      } else if (krow == 0) {          // the cls KEY collects gradient from every frame: f32 atomics
+        atomic_token_channels(cls_ws + 64, adk[t], 0.125f, g);
+        atomic_token_channels(cls_ws + 128, adv[t], 1.0f, g);
+      }
+    }
+  }
+}
+
+template <int NKP>
+int launch_fused(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* atom_ws,
+                 int B, int F, int N, int H, hipStream_t st) {
+  using L = FusedLds<NKP>;
+  static_assert(L::total <= 160 * 1024, "LDS per CU");
+  if (L::total > 64 * 1024)
+    if (int rc = lvl_allow_lds<space_bwd_fused_kernel<NKP>>()) return rc;
+  hipLaunchKernelGGL((space_bwd_fused_kernel<NKP>), dim3((unsigned)(B * F * H)), dim3(256), L::total, st,
+                     (const uint16_t*)qkv, (const uint16_t*)out, (const uint16_t*)dout, lse, (uint16_t*)dqkv, atom_ws,
+                     F, N, H);
+  LVL_CHECK_LAUNCH("space_bwd_fused");
+  return LVL_OK;
+}
+
+constexpr int kFusedPairs = 9;         // fused kernel: up to 288 keys per group
+
+int dispatch_fused(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* atom_ws,
+                   int B, int F, int N, int H, hipStream_t st) {
+  switch ((N + 1 + 31) / 32) {
+#define SPACE_FUSED_CASE(K) case K: return launch_fused<K>(qkv, out, dout, lse, dqkv, atom_ws, B, F, N, H, st);
+    SPACE_FUSED_CASE(1) SPACE_FUSED_CASE(2) SPACE_FUSED_CASE(3) SPACE_FUSED_CASE(4) SPACE_FUSED_CASE(5)
+    SPACE_FUSED_CASE(6) SPACE_FUSED_CASE(7) SPACE_FUSED_CASE(8) SPACE_FUSED_CASE(9)
+#undef SPACE_FUSED_CASE
+  }
+  return lvl_fail(LVL_ENOSYS, "space_mfma_bwd: %d keys per group not supported by the fused kernel", N + 1);
+}
+
 // dqkv[b, token 0, :] = (d cls q | d cls k | d cls v) from the f32 atomic workspace
 __global__ __launch_bounds__(192) void cls_grad_finalize_kernel(const float* __restrict__ atom_ws,
                                                                 uint16_t* __restrict__ dqkv, int T, int H) {
@@ -434,7 +776,7 @@ int launch_dkv(const void* qkv, const void* out, const void* dout, const float* 
 template <bool TEXT>
 int dispatch_dq(int nkeys, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
                 float* delta, int B, int F, int N, int H, hipStream_t st) {
-  switch ((nkeys + 15) / 16) {          // exact tile count: the kernel masks only the last key tile
+  if constexpr (TEXT) switch ((nkeys + 15) / 16) {      // exact tile count: the kernel masks only the last key tile
 #define SPACE_DQ_CASE(K) case K: return launch_dq<K, TEXT>(qkv, out, dout, lse, dqkv, delta, B, F, N, H, st);
     SPACE_DQ_CASE(1) SPACE_DQ_CASE(2) SPACE_DQ_CASE(3) SPACE_DQ_CASE(4) SPACE_DQ_CASE(5) SPACE_DQ_CASE(6) SPACE_DQ_CASE(7)
     SPACE_DQ_CASE(8) SPACE_DQ_CASE(9) SPACE_DQ_CASE(10) SPACE_DQ_CASE(11) SPACE_DQ_CASE(12) SPACE_DQ_CASE(13)
@@ -458,7 +800,7 @@ void lvl_launch_cls_grad_finalize(const float* atom_ws, void* dqkv, int B, int T
 
 bool lvl_space_mfma_bwd_supported(int F, int N) {
   if (N < 1 || F > 64) return false;
-  if (N + 1 <= 272) return dkv_geometry(N).QROWS <= 256 && dkv_geometry(N).total <= 160 * 1024;
+  if (N + 1 <= kFusedPairs * 32) return true;                                      // fused kernel
   return N + 1 <= kBigTiles * 16 && dkv_geometry(N, 4).total <= 160 * 1024;      // large groups: 4-wave kernels
 }
 
@@ -470,8 +812,12 @@ int lvl_space_mfma_bwd(const void* qkv, const void* out, const void* dout, const
   float* atom_ws = ws + (size_t)B * H * T;
   hipError_t e = hipMemsetAsync(atom_ws, 0, (size_t)B * H * 192 * sizeof(float), st);
   if (e != hipSuccess) return lvl_fail(LVL_EHIP, "space_bwd memset: %s", hipGetErrorString(e));
-  if (int rc = dispatch_dq<false>(N + 1, qkv, out, dout, lse, dqkv, delta, B, F, N, H, st)) return rc;
-  if (int rc = launch_dkv<false>(qkv, out, dout, lse, delta, dqkv, atom_ws, B, F, N, H, st)) return rc;
+  if (N + 1 <= kFusedPairs * 32) {
+    if (int rc = dispatch_fused(qkv, out, dout, lse, dqkv, atom_ws, B, F, N, H, st)) return rc;
+  } else {
+    if (int rc = dispatch_dq<false>(N + 1, qkv, out, dout, lse, dqkv, delta, B, F, N, H, st)) return rc;
+    if (int rc = launch_dkv<false>(qkv, out, dout, lse, delta, dqkv, atom_ws, B, F, N, H, st)) return rc;
+  }
   lvl_launch_cls_grad_finalize(atom_ws, dqkv, B, T, H, st);
   LVL_CHECK_LAUNCH("cls_grad_finalize");
   return LVL_OK;
