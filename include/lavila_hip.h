@@ -54,14 +54,17 @@ int64_t lvl_workspace_floats(const char* op, int64_t rows, int64_t cols);
  *   dx = rstd * (dy*gamma - mean(dy*gamma) - shat * mean(dy*gamma*shat)) (+ dadd)
  *   dgamma = sum_rows dy*shat, dbeta = sum_rows dy, dxsum (nullable) = sum_rows dx (= d xbias).
  *   dadd (nullable): [rows, cols] dtype, extra gradient arriving at s through s_out.
+ *   dx_plain (nullable): when given, receives the normalisation's own input gradient WITHOUT dadd (and dxsum sums
+ *   that one), while dx = dx_plain + dadd: the two-consumer case of the odd residual wiring of SpaceTimeBlock
+ *   (timesformer.py:183-196: x feeds x + time_out AND x + space_out), one pass instead of a separate add.
  * cols % 8 == 0, cols <= 4096. bwd workspace: lvl_workspace_floats("layernorm_bwd", rows, cols). */
 int lvl_layernorm_fwd(const void* x, const void* x2, const float* xbias, const float* gamma,
                       const float* beta, void* s_out, void* y, float* mean, float* rstd,
                       int64_t rows, int cols, float eps, int dtype, void* stream);
 int lvl_layernorm_bwd(const void* dy, const void* x, const void* x2, const float* xbias,
                       const float* gamma, const float* mean, const float* rstd, const void* dadd,
-                      void* dx, float* dgamma, float* dbeta, float* dxsum, float* ws, int64_t rows,
-                      int cols, int dtype, void* stream);
+                      void* dx, void* dx_plain, float* dgamma, float* dbeta, float* dxsum, float* ws,
+                      int64_t rows, int cols, int dtype, void* stream);
 
 /* ---- bias + QuickGELU --------------------------------------------------------------------------
  * a = (u + bias) * sigmoid(1.702 (u + bias)); replaces the bias add of Mlp.fc1 / mlp.c_fc and

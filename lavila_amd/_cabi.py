@@ -25,7 +25,7 @@ SIGNATURES = {
     'lvl_last_error': (_c.c_char_p, []),
     'lvl_workspace_floats': (_L, [_c.c_char_p, _L, _L]),
     'lvl_layernorm_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P]),
-    'lvl_layernorm_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
+    'lvl_layernorm_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
     'lvl_bias_quickgelu_fwd': (_I, [_P, _P, _P, _L, _I, _I, _P]),
     'lvl_bias_quickgelu_bwd': (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
     'lvl_patchify': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),

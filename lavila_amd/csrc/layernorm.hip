@@ -159,7 +159,7 @@ template <typename T, int VPL, int W>
 __global__ __launch_bounds__(256, (VPL * W <= 12 ? (sizeof(T) == 2 ? 3 : 2) : 1)) void ln_bwd_kernel(
     const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ x2,
     const float* __restrict__ bias, const float* __restrict__ gamma, const float* __restrict__ mean,
-    const float* __restrict__ rstd, const T* __restrict__ dadd, T* __restrict__ dx,
+    const float* __restrict__ rstd, const T* __restrict__ dadd, T* __restrict__ dx, T* __restrict__ dx_plain,
     float* __restrict__ part, int64_t rows, int cols) {
   extern __shared__ __attribute__((aligned(16))) float smem[];   // [3 waves][3][cols]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -234,14 +234,21 @@ __global__ __launch_bounds__(256, (VPL * W <= 12 ? (sizeof(T) == 2 ? 3 : 2) : 1)
         cur.dy[i].unpack(dv);
 #pragma unroll
         for (int j = 0; j < W; ++j) o[j] = rs * (dv[j] * g[i][j] - c1 - xh[j] * c2);
+        if (dx_plain != nullptr) {       // the normalisation's own input gradient leaves separately (see header)
+#pragma unroll
+          for (int j = 0; j < W; ++j) ax[i][j] += Elem<T>::round(o[j]);
+          VecIO<T, W>::store(dx_plain + row * cols + c * W, o);
+        }
         if (dadd != nullptr) {
           float e[W];
           cur.dadd[i].unpack(e);
 #pragma unroll
           for (int j = 0; j < W; ++j) o[j] += e[j];
         }
+        if (dx_plain == nullptr) {
 #pragma unroll
-        for (int j = 0; j < W; ++j) ax[i][j] += Elem<T>::round(o[j]);
+          for (int j = 0; j < W; ++j) ax[i][j] += Elem<T>::round(o[j]);
+        }
         VecIO<T, W>::store(dx + row * cols + c * W, o);
       }
     }
@@ -373,13 +380,13 @@ extern "C" int lvl_layernorm_fwd(const void* x, const void* x2, const float* xbi
 
 extern "C" int lvl_layernorm_bwd(const void* dy, const void* x, const void* x2, const float* xbias,
                                  const float* gamma, const float* mean, const float* rstd, const void* dadd,
-                                 void* dx, float* dgamma, float* dbeta, float* dxsum, float* ws, int64_t rows,
-                                 int cols, int dtype, void* stream) {
+                                 void* dx, void* dx_plain, float* dgamma, float* dbeta, float* dxsum, float* ws,
+                                 int64_t rows, int cols, int dtype, void* stream) {
   LVL_REQUIRE((rows == 0 || (dy && x && mean && rstd && dx)) && gamma && ws, "layernorm_bwd: null pointer");
   LVL_REQUIRE(rows >= 0 && cols > 0 && cols % 8 == 0 && cols <= 4096,
               "layernorm_bwd: cols=%d must be a multiple of 8, <= 4096", cols);
   LVL_REQUIRE(lvl_aligned16(dy) && lvl_aligned16(x) && lvl_aligned16(x2) && lvl_aligned16(xbias) &&
-                  lvl_aligned16(dadd) && lvl_aligned16(dx) && lvl_aligned16(gamma),
+                  lvl_aligned16(dadd) && lvl_aligned16(dx) && lvl_aligned16(dx_plain) && lvl_aligned16(gamma),
               "layernorm_bwd: pointers must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   int64_t blocks = (rows + kRowsPerBlock - 1) / kRowsPerBlock;
@@ -391,7 +398,8 @@ extern "C" int lvl_layernorm_bwd(const void* dy, const void* x, const void* x2, 
     if (shmem > 64 * 1024)                                                                                      \
       if (int rc = lvl_allow_lds<ln_bwd_kernel<TT, VPL, W>>()) return rc;                                       \
     hipLaunchKernelGGL((ln_bwd_kernel<TT, VPL, W>), dim3((unsigned)blocks), dim3(256), shmem, st, (const TT*)dy, \
-                       (const TT*)x, (const TT*)x2, xbias, gamma, mean, rstd, (const TT*)dadd, (TT*)dx, ws, rows, \
+                       (const TT*)x, (const TT*)x2, xbias, gamma, mean, rstd, (const TT*)dadd, (TT*)dx,          \
+                       (TT*)dx_plain, ws, rows,                                                                   \
                        cols);                                                                                   \
   } while (0)
 #define LN_BWD(VPL, W) LN_BWD_T(T, VPL, W)

@@ -250,18 +250,22 @@ def layernorm_fwd_raw(x, x2, xbias, gamma, beta, eps, keep_sum):
     return y, s, mean, rstd
 
 
-def layernorm_bwd_raw(dy, x, x2, xbias, gamma, mean, rstd, dadd, want_dxsum):
+def layernorm_bwd_raw(dy, x, x2, xbias, gamma, mean, rstd, dadd, want_dxsum, want_plain=False):
+    """want_plain: also return the normalisation's own input gradient without dadd (dx = dx_plain + dadd)."""
     C.require_device(dy, x, x2, xbias, gamma, mean, rstd, dadd)
     rows, cols = _rows_cols(x)
     dx = torch.empty_like(x)
+    dx_plain = torch.empty_like(x) if want_plain else None
     dgamma = torch.empty(cols, dtype=torch.float32, device=x.device)
     dbeta = torch.empty(cols, dtype=torch.float32, device=x.device)
     dxsum = torch.empty(cols, dtype=torch.float32, device=x.device) if want_dxsum else None
     ws = C.workspace('layernorm_bwd', rows, cols, x.device)
     C.check(C.lib().lvl_layernorm_bwd(C.ptr(dy), C.ptr(x), C.ptr(x2), C.ptr(xbias), C.ptr(gamma), C.ptr(mean),
-                                      C.ptr(rstd), C.ptr(dadd), C.ptr(dx), C.ptr(dgamma), C.ptr(dbeta),
-                                      C.ptr(dxsum), C.ptr(ws), rows, cols, C.dtype_code(x), C.stream_ptr()),
-            'lvl_layernorm_bwd')
+                                      C.ptr(rstd), C.ptr(dadd), C.ptr(dx), C.ptr(dx_plain), C.ptr(dgamma),
+                                      C.ptr(dbeta), C.ptr(dxsum), C.ptr(ws), rows, cols, C.dtype_code(x),
+                                      C.stream_ptr()), 'lvl_layernorm_bwd')
+    if want_plain:
+        return dx, dgamma, dbeta, dxsum, dx_plain
     return dx, dgamma, dbeta, dxsum
 
 
@@ -320,6 +324,40 @@ class _AddLayerNormFn(torch.autograd.Function):
             dx, dg, db, dsum = layernorm_bwd_raw(dh.contiguous(), res, y, yb, g, mean, rstd, None, ctx.has_ybias)
         dyb = dsum.to(ctx.pdt[2]) if ctx.has_ybias else None
         return dx, dx, dyb, dg.to(ctx.pdt[0]), db.to(ctx.pdt[1]), None, None
+
+
+class _AddLayerNormPassFn(torch.autograd.Function):
+    """(res, h) = (res, LN(res + y + ybias)): the sum is not materialised and `res` is handed through, so that a
+    SECOND consumer of res (SpaceTimeBlock: x feeds both x + time_out and x + space_out, timesformer.py:183-196) can
+    take it from here. Its gradient then arrives in THIS node and is added inside the LayerNorm backward kernel
+    (dx = dx_plain + d_res_out) instead of by a separate full-size add of the autograd engine."""
+
+    @staticmethod
+    def forward(ctx, res, y, ybias, weight, bias, eps):
+        res, y = res.contiguous(), y.contiguous()
+        yb, g, b = _f32(ybias), _f32(weight), _f32(bias)
+        h, _, mean, rstd = layernorm_fwd_raw(res, y, yb, g, b, eps, False)
+        ctx.save_for_backward(res, y, yb, g, mean, rstd)
+        ctx.has_ybias = ybias is not None
+        ctx.pdt = (weight.dtype, bias.dtype, ybias.dtype if ybias is not None else None)
+        return res.view_as(res), h
+
+    @staticmethod
+    def backward(ctx, dres, dh):
+        res, y, yb, g, mean, rstd = ctx.saved_tensors
+        if dres is None:
+            dx, dg, db, dsum = layernorm_bwd_raw(dh.contiguous(), res, y, yb, g, mean, rstd, None, ctx.has_ybias)
+            dy = dx
+        else:
+            dx, dg, db, dsum, dy = layernorm_bwd_raw(dh.contiguous(), res, y, yb, g, mean, rstd, dres.contiguous(),
+                                                     ctx.has_ybias, want_plain=True)
+        dyb = dsum.to(ctx.pdt[2]) if ctx.has_ybias else None
+        return dx, dy, dyb, dg.to(ctx.pdt[0]), db.to(ctx.pdt[1]), None
+
+
+def add_layer_norm_pass(res, y, ybias, weight, bias, eps):
+    """Returns (res_again, h) with h = LayerNorm(res + y (+ ybias)); use res_again for the next consumer of res."""
+    return _AddLayerNormPassFn.apply(res, y, ybias, weight, bias, eps)
 
 
 def add_layer_norm(res, y, ybias, weight, bias, eps, keep_sum=True):

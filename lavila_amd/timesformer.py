@@ -224,7 +224,9 @@ class SpaceTimeBlock(nn.Module):
             y_t, b_t = torch.tanh(self.alpha_timeattn).to(o_t.dtype) * ta.proj(o_t), None
         else:
             y_t, b_t = ops.linear(o_t, ta.proj.weight), ta.proj.bias
-        _, h1 = ops.add_layer_norm(x, y_t, b_t, n1.weight, n1.bias, n1.eps, keep_sum=False)   # t never stored
+        # t = x + time_out is never stored; x is handed through so that its second use below sends its gradient into
+        # norm1's backward kernel instead of a separate add
+        x, h1 = ops.add_layer_norm_pass(x, y_t, b_t, n1.weight, n1.bias, n1.eps)
         o_s = sa.core(h1, 'space', frames, n_per_frame)
         if self._dropping():
             y_s, b_s = self.drop_path(sa.proj(o_s)), None

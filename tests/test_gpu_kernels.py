@@ -87,6 +87,38 @@ def test_add_layernorm_fused(dt, keep_sum, with_bias):
 
 
 @pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('with_bias,second_use', [(True, True), (False, True), (True, False)])
+def test_add_layernorm_pass_through(dt, with_bias, second_use):
+    """h = LN(res + y + b) with res handed through for a second consumer (the x + space_out use of SpaceTimeBlock):
+    d res = LN-backward + gradient of the second use, d y and d b see the LN-backward only."""
+    from lavila_amd import ops
+    rows, cols, eps = 93, 768, 1e-6
+    g = torch.Generator().manual_seed(17)
+    res, y = _r(torch.randn(rows, cols, generator=g), dt), _r(torch.randn(rows, cols, generator=g), dt)
+    yb = 0.3 * torch.randn(cols, generator=g) if with_bias else None
+    w, b = 1 + 0.2 * torch.randn(cols, generator=g), 0.1 * torch.randn(cols, generator=g)
+    dh, d2 = _r(torch.randn(rows, cols, generator=g), dt), _r(torch.randn(rows, cols, generator=g), dt)
+    ro, yo, ybo, wo, bo = [t.clone().requires_grad_(True) if t is not None else None for t in (res, y, yb, w, b)]
+    ho = O.layer_norm(ro + yo + (ybo if with_bias else 0), wo, bo, eps)
+    ((ho * dh).sum() + ((ro * d2).sum() if second_use else 0)).backward()
+    dev = [t.to(DEV, dt if i < 2 else torch.float32).requires_grad_(True) if t is not None else None
+           for i, t in enumerate((res, y, yb, w, b))]
+    r2, h = ops.add_layer_norm_pass(dev[0], dev[1], dev[2], dev[3], dev[4], eps)
+    assert torch.equal(r2, dev[0])
+    loss = (h.float() * dh.to(DEV)).sum()
+    if second_use:
+        loss = loss + (r2.float() * d2.to(DEV)).sum()
+    loss.backward()
+    _close(h, ho.detach(), dt, 6, 'h')
+    _close(dev[0].grad, ro.grad, dt, 6, 'dres')
+    _close(dev[1].grad, yo.grad, dt, 6, 'dy')
+    if with_bias:
+        _close(dev[2].grad, ybo.grad, dt, 10, 'dybias')
+    _close(dev[3].grad, wo.grad, dt, 8, 'dgamma')
+    _close(dev[4].grad, bo.grad, dt, 8, 'dbeta')
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('rows,cols,with_bias', [(33, 3072, True), (5, 512, True), (300, 4096, True), (9, 2048, False)])
 def test_bias_quickgelu(dt, rows, cols, with_bias):
     from lavila_amd import ops
