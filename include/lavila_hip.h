@@ -134,13 +134,16 @@ int lvl_causal_attn_bwd(const void* qkv, const void* out, const void* dout, cons
  * logits (optional, may be NULL): [2,B,G] f32 slab of the scaled logits (for parity checks).
  * bwd: lse_all [2,G] f32 = gathered row LSEs of both directions; upstream (nullable): DEVICE pointer
  * to d(objective)/d(loss); coef: host factor mult/(2G). Writes coef*upstream*d(sum of both CE
- * sums)/d(img_local | txt_local): [B,E] f32. No gradient collective is needed. */
+ * sums)/d(img_local | txt_local): [B,E] f32. No gradient collective is needed.
+ * rows_only != 0: CLIPLoss(local_loss=True) without gather_with_grad (loss.py:34-43,86-88): the gathered
+ * partner rows are constants, so each local row receives only the gradient of its own two cross-entropies
+ * (only the local entries of lse_all are read; coef = 1/(2B)). */
 int lvl_clip_loss_fwd(const void* img_all, const void* txt_all, const float* scale, int B, int G,
                       int E, int row0, float* stats, int32_t* argmax, float* logits, int dtype,
                       void* stream);
 int lvl_clip_loss_bwd(const void* img_all, const void* txt_all, const float* lse_all,
                       const float* scale, const float* upstream, float coef, int B, int G, int E,
-                      int row0, float* dimg, float* dtxt, int dtype, void* stream);
+                      int row0, int rows_only, float* dimg, float* dtxt, int dtype, void* stream);
 
 /* ---- contrastive head with per-pair temperature (SSLCLIPLoss, loss.py:121-217) ---------------------------
  * Same slab structure as lvl_clip_loss_*; ind_all: [G] int32 gt_indicators in rank order (1 = ground-truth

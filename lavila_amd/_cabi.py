@@ -36,7 +36,7 @@ SIGNATURES = {
     'lvl_causal_attn_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     'lvl_causal_attn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'lvl_clip_loss_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P]),
-    'lvl_clip_loss_bwd': (_I, [_P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _P, _P, _I, _P]),
+    'lvl_clip_loss_bwd': (_I, [_P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
     'lvl_ssl_clip_loss_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P]),
     'lvl_ssl_clip_loss_bwd': (_I, [_P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _P, _P, _I, _P]),
     'lvl_linear_tn': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),

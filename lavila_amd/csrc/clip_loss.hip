@@ -93,8 +93,8 @@ __global__ __launch_bounds__(256) void clip_bwd_kernel(const T* __restrict__ img
                                                        const float* __restrict__ lse_all,
                                                        const float* __restrict__ scale_p,
                                                        const float* __restrict__ upstream_p, float coef, int B,
-                                                       int G, int E, int row0, float* __restrict__ dimg,
-                                                       float* __restrict__ dtxt) {
+                                                       int G, int E, int row0, int rows_only,
+                                                       float* __restrict__ dimg, float* __restrict__ dtxt) {
   extern __shared__ __attribute__((aligned(16))) float smem[];   // a_s[E], c[G]
   float* a_s = smem;
   float* c = smem + E;
@@ -108,7 +108,10 @@ __global__ __launch_bounds__(256) void clip_bwd_kernel(const T* __restrict__ img
   const float* L_other = lse_all + (int64_t)(1 - dir) * G;
   for (int j = threadIdx.x; j < G; j += blockDim.x) {
     const float z = dot_row(Bm + (int64_t)j * E, a_s, E);
-    c[j] = __expf(z - L_own) + __expf(z - L_other[j]) - (j == gi ? 2.f : 0.f);
+    // rows_only (CLIPLoss(local_loss=True) without gather_with_grad, loss.py:86-88): the gathered partner rows carry
+    // no gradient, so only this row's own cross-entropy contributes
+    c[j] = rows_only ? __expf(z - L_own) - (j == gi ? 1.f : 0.f)
+                     : __expf(z - L_own) + __expf(z - L_other[j]) - (j == gi ? 2.f : 0.f);
   }
   __syncthreads();
   float* dst = (dir == 0 ? dimg : dtxt) + (int64_t)i * E;
@@ -144,8 +147,8 @@ extern "C" int lvl_clip_loss_fwd(const void* img_all, const void* txt_all, const
 }
 
 extern "C" int lvl_clip_loss_bwd(const void* img_all, const void* txt_all, const float* lse_all, const float* scale,
-                                 const float* upstream, float coef, int B, int G, int E, int row0, float* dimg,
-                                 float* dtxt, int dtype, void* stream) {
+                                 const float* upstream, float coef, int B, int G, int E, int row0, int rows_only,
+                                 float* dimg, float* dtxt, int dtype, void* stream) {
   LVL_REQUIRE(img_all && txt_all && lse_all && scale && dimg && dtxt, "clip_loss_bwd: null pointer");
   LVL_REQUIRE(B >= 0 && G > 0 && E > 0 && E % 8 == 0 && row0 >= 0 && row0 + B <= G,
               "clip_loss_bwd: bad shape B=%d G=%d E=%d row0=%d", B, G, E, row0);
@@ -157,7 +160,7 @@ extern "C" int lvl_clip_loss_bwd(const void* img_all, const void* txt_all, const
     if (shmem > 64 * 1024)
       if (int rc = lvl_allow_lds<clip_bwd_kernel<T>>()) return rc;
     hipLaunchKernelGGL((clip_bwd_kernel<T>), dim3(B, 2), dim3(256), shmem, (hipStream_t)stream, (const T*)img_all,
-                       (const T*)txt_all, lse_all, scale, upstream, coef, B, G, E, row0, dimg, dtxt);
+                       (const T*)txt_all, lse_all, scale, upstream, coef, B, G, E, row0, rows_only, dimg, dtxt);
   });
   LVL_CHECK_LAUNCH("clip_loss_bwd");
   return LVL_OK;

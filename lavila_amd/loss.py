@@ -50,17 +50,30 @@ class _ContrastiveFn(torch.autograd.Function):
         labels = torch.arange(row0, row0 + B, device=argmax.device, dtype=torch.int32)
         part = torch.stack([(lse - diag).sum(), (expect - diag).sum(),
                             (argmax[0] == labels).sum().float()])
-        if W > 1:
+        # local_loss (loss.py:86-88, 99-100; only on the gather_features path): every rank's loss is the mean over
+        # ITS rows of the two slabs -- exactly what _slab_forward produced -- and is not averaged over ranks
+        local = bool(crit.local_loss) and W > 1 and not crit.use_vissl
+        if W > 1 and (not local or crit.gather_with_grad):
             packed = torch.cat([lse.reshape(-1), part])[None]                  # [1, 2B+3]
             allp = all_gather_rows(packed)                                     # [W, 2B+3]
             lse_all = allp[:, :2 * B].reshape(W, 2, B).permute(1, 0, 2).reshape(2, G).contiguous()
             sums = allp[:, 2 * B:].sum(0)
+        elif W > 1:                            # local rows only: the kernel reads nothing but the own entries
+            lse_all = lse.new_zeros(2, G)
+            lse_all[:, row0:row0 + B] = lse
+            sums = part
         else:
             lse_all, sums = lse.contiguous(), part
-        loss = sums[0] / (2 * G)
-        acc = 100.0 * sums[2] / G
+        if local:
+            sums = part
+            loss = part[0] / (2 * B)
+            acc = 100.0 * part[2] / B
+        else:
+            loss = sums[0] / (2 * G)
+            acc = 100.0 * sums[2] / G
         ctx.save_for_backward(img_all, txt_all, lse_all, scale, sums)
         ctx.cfg = (B, G, row0, W, crit, image_embed.dtype, text_embed.dtype, logit_scale.dtype)
+        ctx.local = local
         ctx.mark_non_differentiable(acc)
         crit._last_pred = argmax[0]
         return loss, acc
@@ -69,8 +82,16 @@ class _ContrastiveFn(torch.autograd.Function):
     def backward(ctx, dloss, dacc):
         img_all, txt_all, lse_all, scale, sums = ctx.saved_tensors
         B, G, row0, W, crit, idt, tdt, sdt = ctx.cfg
-        mult = float(W) if (crit.use_vissl or crit.gather_with_grad) else 1.0
         up = dloss.detach().float().reshape(1).contiguous()
+        if ctx.local:
+            # with gather_with_grad the all-gather's backward sums, on the owner of a row, the column terms of EVERY
+            # rank's local loss (each weighted 1/(2B)): rows + columns over the global batch, as in the vissl path;
+            # without it the gathered rows are constants and only the row terms of the own loss remain
+            dimg, dtxt = crit._slab_backward(img_all, txt_all, lse_all, scale, up, 1.0 / (2 * B), B, row0,
+                                             rows_only=not crit.gather_with_grad)
+            dscale = up[0] * sums[1] / (2 * B) / scale[0]
+            return dimg.to(idt), dtxt.to(tdt), dscale.to(sdt), None
+        mult = float(W) if (crit.use_vissl or crit.gather_with_grad) else 1.0
         dimg, dtxt = crit._slab_backward(img_all, txt_all, lse_all, scale, up, mult / (2 * G), B, row0)
         dscale = up[0] * sums[1] / (2 * G) / scale[0]
         return dimg.to(idt), dtxt.to(tdt), dscale.to(sdt), None
@@ -82,9 +103,6 @@ class CLIPLoss(nn.Module):
     def __init__(self, use_vissl=False, local_loss=False, gather_with_grad=False, cache_labels=False, rank=0,
                  world_size=1):
         super().__init__()
-        if local_loss:
-            raise NotImplementedError('local_loss=True is never enabled by lavila.models.models.get_loss '
-                                      '(models.py:295-300) and is not built')
         self.use_vissl = use_vissl
         self.local_loss = local_loss
         self.gather_with_grad = gather_with_grad
@@ -101,8 +119,8 @@ class CLIPLoss(nn.Module):
         stats, argmax, _ = ops.clip_loss_fwd_raw(img_all, txt_all, scale, B, row0, want_logits=False)
         return stats, argmax
 
-    def _slab_backward(self, img_all, txt_all, lse_all, scale, upstream, coef, B, row0):
-        return ops.clip_loss_bwd_raw(img_all, txt_all, lse_all, scale, upstream, coef, B, row0)
+    def _slab_backward(self, img_all, txt_all, lse_all, scale, upstream, coef, B, row0, rows_only=False):
+        return ops.clip_loss_bwd_raw(img_all, txt_all, lse_all, scale, upstream, coef, B, row0, rows_only)
 
     def forward(self, outputs):
         image_features = outputs['image_embed']
@@ -219,10 +237,8 @@ class SSLCLIPLoss(nn.Module):
                  world_size=1, scale_init=0.08, freeze_scale=False):
         super().__init__()
         import numpy as np
-        if local_loss:
-            raise NotImplementedError('local_loss=True is not built (never enabled by the reference drivers)')
         self.use_vissl = use_vissl
-        self.local_loss = local_loss
+        self.local_loss = local_loss          # ignored on one rank, as in the reference; see forward() for W > 1
         self.gather_with_grad = gather_with_grad
         self.cache_labels = cache_labels
         self.rank = rank
@@ -245,6 +261,11 @@ class SSLCLIPLoss(nn.Module):
         if self.world_size > 1:
             if not self.use_vissl:
                 raise NotImplementedError      # as the reference (loss.py:167-168)
+            if self.local_loss:
+                # the reference offsets the labels by num_logits * rank although its vissl logits are already global
+                # (loss.py:185-186): out-of-range targets, an error there too
+                raise NotImplementedError('SSLCLIPLoss(local_loss=True) on several ranks indexes labels out of range '
+                                          'in the reference (loss.py:185-186); not reproduced')
             if not (dist.is_available() and dist.is_initialized()):
                 raise RuntimeError('SSLCLIPLoss(world_size>1) needs an initialised torch.distributed process group')
         loss, acc, acc_gt, acc_pseudo, num_gt, num_pseudo = _SSLContrastiveFn.apply(

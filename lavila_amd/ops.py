@@ -575,13 +575,15 @@ def clip_loss_fwd_raw(img_all, txt_all, scale, B: int, row0: int, want_logits=Fa
     return stats, argmax, logits
 
 
-def clip_loss_bwd_raw(img_all, txt_all, lse_all, scale, upstream, coef: float, B: int, row0: int):
+def clip_loss_bwd_raw(img_all, txt_all, lse_all, scale, upstream, coef: float, B: int, row0: int,
+                      rows_only: bool = False):
     C.require_device(img_all, txt_all, lse_all, scale, upstream)
     G, E = img_all.shape
     dimg = torch.empty(B, E, dtype=torch.float32, device=img_all.device)
     dtxt = torch.empty(B, E, dtype=torch.float32, device=img_all.device)
     C.check(C.lib().lvl_clip_loss_bwd(C.ptr(img_all), C.ptr(txt_all), C.ptr(lse_all), C.ptr(scale), C.ptr(upstream),
-                                      float(coef), B, G, E, row0, C.ptr(dimg), C.ptr(dtxt), C.dtype_code(img_all),
+                                      float(coef), B, G, E, row0, int(rows_only), C.ptr(dimg), C.ptr(dtxt),
+                                      C.dtype_code(img_all),
                                       C.stream_ptr()), 'lvl_clip_loss_bwd')
     return dimg, dtxt
 

@@ -153,7 +153,7 @@ def run_var_attention_golden(ref):
     print(f'[golden] var_attention: {len(cases)} cases')
 
 
-def _rank_worker(rank, world, port, use_vissl, q):
+def _rank_worker(rank, world, port, use_vissl, q, local_loss=False, gather_with_grad=False):
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -166,7 +166,8 @@ def _rank_worker(rank, world, port, use_vissl, q):
     li = img[rank * Bl:(rank + 1) * Bl].clone().requires_grad_(True)
     lt = txt[rank * Bl:(rank + 1) * Bl].clone().requires_grad_(True)
     scale = torch.tensor(14.285714).requires_grad_(True)
-    crit = ref.loss.CLIPLoss(use_vissl=use_vissl, cache_labels=True, rank=rank, world_size=world)
+    crit = ref.loss.CLIPLoss(use_vissl=use_vissl, local_loss=local_loss, gather_with_grad=gather_with_grad,
+                             cache_labels=True, rank=rank, world_size=world)
     out = crit({'image_embed': li, 'text_embed': lt, 'logit_scale': scale})
     out['loss'].backward()
     q.put((rank, out['loss'].item(), out['clip_acc'].item(), li.grad.tolist(), lt.grad.tolist(),
@@ -241,6 +242,22 @@ def run_multirank_loss_golden():
                 'dtxt': torch.cat([torch.tensor(g[4]) for g in got]),
                 'dscale': [g[5] for g in got]}
             print(f'[golden] multirank world={world} vissl={use_vissl} loss={got[0][1]:.6f}')
+    # local_loss=True (loss.py:86-88, 99-100): every rank keeps its own loss; with / without gather_with_grad
+    for world, with_grad in ((2, False), (2, True), (3, False)):
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_rank_worker, args=(r, world, port, False, q, True, with_grad)) for r in range(world)]
+        port += 1
+        for p in procs:
+            p.start()
+        got = sorted([q.get(timeout=300) for _ in range(world)], key=lambda t: t[0])
+        for p in procs:
+            p.join()
+        results[(world, 'local', with_grad)] = {
+            'loss': [g[1] for g in got], 'acc': [g[2] for g in got],
+            'dimg': torch.cat([torch.tensor(g[3]) for g in got]),
+            'dtxt': torch.cat([torch.tensor(g[4]) for g in got]),
+            'dscale': [g[5] for g in got]}
+        print(f'[golden] multirank local_loss world={world} gather_with_grad={with_grad} losses={[round(g[1], 5) for g in got]}')
     torch.save({'E': 16, 'B_local': 3, 'seed': 77, 'scale': 14.285714, 'results': results},
                os.path.join(GOLDEN, 'clip_loss_multirank.pt'))
 

@@ -48,10 +48,22 @@ def oracle_slab_forward(img_all, txt_all, scale, B, row0):
     return stats, slabs.argmax(-1).to(torch.int32)
 
 
-def oracle_slab_backward(img_all, txt_all, lse_all, scale, upstream, coef, B, row0):
+def oracle_slab_backward(img_all, txt_all, lse_all, scale, upstream, coef, B, row0, rows_only=False):
     """CPU restatement of lvl_clip_loss_bwd via autograd on the oracle's full loss:
-    coef*upstream*d(sum of both CE sums)/d(local rows) = coef*upstream*2G * d(loss)/d(local rows)."""
+    coef*upstream*d(sum of both CE sums)/d(local rows) = coef*upstream*2G * d(loss)/d(local rows).
+    rows_only: the local rows' own two cross-entropy sums against CONSTANT gathered partners (loss.py:34-43,86-88)."""
     G = img_all.shape[0]
+    if rows_only:
+        with torch.enable_grad():
+            il = img_all[row0:row0 + B].float().clone().requires_grad_(True)
+            tl = txt_all[row0:row0 + B].float().clone().requires_grad_(True)
+            s = scale.float().reshape(())
+            labels = torch.arange(row0, row0 + B)
+            tot = (torch.nn.functional.cross_entropy(s * il @ txt_all.float().t(), labels, reduction='sum') +
+                   torch.nn.functional.cross_entropy(s * tl @ img_all.float().t(), labels, reduction='sum'))
+            gi, gt = torch.autograd.grad(tot, [il, tl])
+        k = coef * upstream.reshape(())
+        return (k * gi).contiguous(), (k * gt).contiguous()
     with torch.enable_grad():          # may be called from inside an autograd backward (grad mode off)
         ia = img_all.float().clone().requires_grad_(True)
         ta = txt_all.float().clone().requires_grad_(True)

@@ -16,7 +16,7 @@ import torch.multiprocessing as mp
 from conftest import ROOT, load_golden
 
 
-def _worker(rank, world, port, use_vissl, fx, q):
+def _worker(rank, world, port, use_vissl, fx, q, local_loss=False, gather_with_grad=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     os.environ['MASTER_ADDR'] = '127.0.0.1'
@@ -31,8 +31,8 @@ def _worker(rank, world, port, use_vissl, fx, q):
         def _slab_forward(self, img_all, txt_all, scale, B, row0):
             return oracle_slab_forward(img_all, txt_all, scale[0], B, row0)
 
-        def _slab_backward(self, img_all, txt_all, lse_all, scale, upstream, coef, B, row0):
-            return oracle_slab_backward(img_all, txt_all, lse_all, scale, upstream, coef, B, row0)
+        def _slab_backward(self, img_all, txt_all, lse_all, scale, upstream, coef, B, row0, rows_only=False):
+            return oracle_slab_backward(img_all, txt_all, lse_all, scale, upstream, coef, B, row0, rows_only)
 
     g = torch.Generator().manual_seed(fx['seed'])
     E, Bl = fx['E'], fx['B_local']
@@ -41,7 +41,8 @@ def _worker(rank, world, port, use_vissl, fx, q):
     li = img[rank * Bl:(rank + 1) * Bl].clone().requires_grad_(True)
     lt = txt[rank * Bl:(rank + 1) * Bl].clone().requires_grad_(True)
     scale = torch.tensor(fx['scale']).requires_grad_(True)
-    crit = OracleBackedLoss(use_vissl=use_vissl, cache_labels=True, rank=rank, world_size=world)
+    crit = OracleBackedLoss(use_vissl=use_vissl, local_loss=local_loss, gather_with_grad=gather_with_grad,
+                            cache_labels=True, rank=rank, world_size=world)
     out = crit({'image_embed': li, 'text_embed': lt, 'logit_scale': scale})
     out['loss'].backward()
     # gather_from_all: rank-ordered, gradient-preserving (sum over ranks of the own slice)
@@ -80,6 +81,33 @@ def test_sharded_loss_matches_reference_multirank(world, use_vissl):
         exp_rows = torch.cat([torch.arange(Bl * 2, dtype=torch.float32).reshape(Bl, 2) + 100 * k for k in range(world)])
         assert torch.equal(torch.tensor(gx), exp_rows)
         assert torch.equal(torch.tensor(dx), torch.full((Bl, 2), float(sum(range(1, world + 1)))))
+
+
+@pytest.mark.parametrize('world,with_grad', [(2, False), (2, True), (3, False)])
+def test_local_loss_matches_reference_multirank(world, with_grad):
+    """CLIPLoss(local_loss=True) (loss.py:86-88, 99-100): per-rank loss / accuracy, and the two gradient conventions
+    (gathered partners constant vs. gather_with_grad) against the reference's own multi-rank outputs."""
+    fx = load_golden('clip_loss_multirank.pt')
+    want = fx['results'][(world, 'local', with_grad)]
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29760 + world * 10 + int(with_grad)
+    light = {k: fx[k] for k in ('seed', 'E', 'B_local', 'scale')}
+    procs = [ctx.Process(target=_worker, args=(r, world, port, False, light, q, True, with_grad)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    Bl = fx['B_local']
+    assert len({round(v, 4) for v in want['loss']}) == world          # the ranks really hold different losses
+    for r, (rank, loss, acc, dimg, dtxt, dscale, gx, dx) in enumerate(got):
+        assert rank == r
+        assert abs(loss - want['loss'][r]) < 1e-5
+        assert abs(acc - want['acc'][r]) < 1e-4
+        assert abs(dscale - want['dscale'][r]) < 1e-5
+        torch.testing.assert_close(torch.tensor(dimg), want['dimg'][r * Bl:(r + 1) * Bl], atol=1e-6, rtol=1e-4)
+        torch.testing.assert_close(torch.tensor(dtxt), want['dtxt'][r * Bl:(r + 1) * Bl], atol=1e-6, rtol=1e-4)
 
 
 def _ssl_worker(rank, world, port, fx, q):

@@ -274,6 +274,14 @@ def test_clip_loss_slabs(dt, B, G, E, row0):
     di, dtx = ops.clip_loss_bwd_raw(ig, tg, lse_all.to(DEV), scale.to(DEV), up.to(DEV), 3.0 / (2 * G), B, row0)
     torch.testing.assert_close(di.cpu(), di_o, atol=2e-5, rtol=1e-3)
     torch.testing.assert_close(dtx.cpu(), dt_o, atol=2e-5, rtol=1e-3)
+    # rows_only (local_loss without gather_with_grad): only the local entries of lse_all may be read
+    lse_loc = torch.full_like(lse_all, float('nan'))
+    lse_loc[:, row0:row0 + B] = lse_all[:, row0:row0 + B]
+    di_o, dt_o = oracle_slab_backward(img, txt, lse_all, scale, up, 1.0 / (2 * B), B, row0, rows_only=True)
+    di, dtx = ops.clip_loss_bwd_raw(ig, tg, lse_loc.to(DEV), scale.to(DEV), up.to(DEV), 1.0 / (2 * B), B, row0,
+                                    rows_only=True)
+    torch.testing.assert_close(di.cpu(), di_o, atol=2e-5, rtol=1e-3)
+    torch.testing.assert_close(dtx.cpu(), dt_o, atol=2e-5, rtol=1e-3)
 
 
 @pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
