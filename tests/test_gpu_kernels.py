@@ -194,7 +194,10 @@ def _check_qkv_bias_grad(got, dqkv_oracle, dt):
 @pytest.mark.parametrize('mode', ['space', 'time'])
 @pytest.mark.parametrize('B,Fr,N,H', [(2, 3, 5, 2), (2, 2, 49, 3), (3, 1, 7, 2), (2, 16, 4, 1), (1, 4, 196, 2), (1, 2, 256, 12), (1, 4, 196, 16), (2, 8, 33, 3),
                                       (2, 4, 70, 1), (1, 16, 10, 12), (1, 8, 20, 16), (2, 16, 33, 2), (1, 2, 576, 2), (1, 1, 400, 3),
-                                      (1, 2, 591, 1), (1, 1, 272, 1), (2, 12, 7, 4), (1, 5, 9, 4), (1, 16, 196, 4), (2, 7, 3, 8)])
+                                      (1, 2, 591, 1), (1, 1, 272, 1), (2, 12, 7, 4), (1, 5, 9, 4), (1, 16, 196, 4), (2, 7, 3, 8),
+                                      # 32-key block boundaries of the fused space backward (cls query = query row N)
+                                      (2, 2, 1, 2), (1, 3, 31, 2), (2, 2, 32, 1), (1, 2, 63, 2), (1, 1, 64, 3), (1, 2, 287, 1),
+                                      (1, 1, 288, 1)])
 def test_divided_attention_core(dt, mode, B, Fr, N, H):
     from lavila_amd import ops
     qkv, dout = _attn_case(B, Fr, N, H, 17 + Fr + N)
