@@ -60,6 +60,10 @@ def parse():
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-batch', type=int, default=8)
     p.add_argument('--no-events', action='store_true', help='skip per-launch HIP events (A/B their overhead)')
+    p.add_argument('--reuse-tokens', action='store_true',
+                   help='feed the SAME token tensor object every step (A/B only: the caption-length read-back of the '
+                        'text tower is memoised per tensor object; the default hands over a new tensor per step, as a '
+                        'data loader does)')
     return p.parse_args()
 
 
@@ -204,8 +208,10 @@ def main():
     amp = torch.bfloat16 if args.dtype == 'bf16' else None
 
     def step():
+        # a training loop receives a NEW token tensor every iteration (main_pretrain.py:489-498)
+        toks = tokens if args.reuse_tokens else tokens.clone()
         with torch.autocast('cuda', dtype=amp, enabled=amp is not None):
-            out = net(video, tokens, use_checkpoint=False, norm_embed=True)
+            out = net(video, toks, use_checkpoint=False, norm_embed=True)
             loss = crit(out)['loss']
         loss.backward()
         opt.step()

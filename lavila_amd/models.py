@@ -33,21 +33,22 @@ def _amp_region():
 
 _TEXT_STREAM = os.environ.get('LAVILA_TEXT_STREAM', '1') != '0'
 _TEXT_TRIM = os.environ.get('LAVILA_TEXT_TRIM', '1') != '0'
+_TEXT_AFTER_BLOCK = 1          # video blocks enqueued before the text tower's caption-length read-back
 _text_streams = {}
 
 
 _lmax_memo = [None, -1, 0]          # (weakref to the token tensor, its version, longest caption)
 
 
-def _longest_caption(text, rows):
-    """1 + the largest EOT position of the batch. One scalar read back from the device; memoised on the identity
-    (weak reference) and version of the token tensor, so a driver that feeds the SAME tensor object again (synthetic
-    benchmarks) does not pay the host synchronisation twice. A new batch is a new tensor object: always re-read."""
+def _longest_caption(text, rows, rows_max=None):
+    """1 + the largest EOT position of the batch. One scalar read back from the device (`rows_max`: the reduction
+    already enqueued by the caller, so that the read-back finds it finished); memoised on the identity (weak reference)
+    and version of the token tensor, so calling encode_text twice on one batch reads it once."""
     ref, ver, lmax = _lmax_memo
     if ref is not None and ref() is text and ver == text._version:
         return lmax
     import weakref
-    lmax = int(rows.max().item()) + 1
+    lmax = int((rows.max() if rows_max is None else rows_max).item()) + 1
     _lmax_memo[:] = [weakref.ref(text), text._version, lmax]
     return lmax
 
@@ -119,7 +120,13 @@ class CLIP(nn.Module):
                 return x
             return x @ self.image_projection
 
-    def encode_text(self, text, use_checkpoint=False):
+    def _eot_rows(self, text):
+        """(EOT row of every caption, their maximum as a device scalar or None): enqueued without a host read."""
+        rows = text.argmax(dim=-1)
+        trim = _TEXT_TRIM and text.is_cuda and not torch.cuda.is_current_stream_capturing()
+        return rows, (rows.max() if trim else None)
+
+    def encode_text(self, text, use_checkpoint=False, _eot=None):
         with _amp_region():
             # Only the EOT row (highest token id, models.py:158-160) of the last layer feeds the output, and under
             # the causal mask a row never sees later positions: everything behind the longest caption of the batch
@@ -127,9 +134,9 @@ class CLIP(nn.Module):
             # on columns [0, max EOT] only -- bit-for-bit the same rows, 32/77 of the work on 32-token captions.
             # Costs one host read of a scalar (the reference driver reads loss.item() every step anyway);
             # LAVILA_TEXT_TRIM=0 (or stream capture) keeps all 77 positions.
-            rows = text.argmax(dim=-1)
-            if _TEXT_TRIM and text.is_cuda and not torch.cuda.is_current_stream_capturing():
-                text = text[:, :_longest_caption(text, rows)]
+            rows, rows_max = self._eot_rows(text) if _eot is None else _eot
+            if rows_max is not None:
+                text = text[:, :_longest_caption(text, rows, rows_max)]
             x = self.token_embedding(text) + self.positional_embedding[:text.shape[1]]          # [B, L, W]
             if torch.is_autocast_enabled():
                 x = x.to(torch.get_autocast_dtype('cuda'))
@@ -145,11 +152,33 @@ class CLIP(nn.Module):
             side = _text_stream(image.device)
             side.wait_stream(main)
             text.record_stream(side)
+            # The text tower needs the longest caption length on the host, and that read-back has to wait for the
+            # PREVIOUS step to drain (the token tensor was produced behind it on the main stream). So: enqueue the
+            # reduction, enqueue the first blocks of the video tower, and only then read the length and enqueue the text
+            # tower (from a hook inside the video forward): while the host waits the GPU still has work queued, and the
+            # text tower starts early enough to finish long before the video tower does.
             with torch.cuda.stream(side):
-                text_embed = self.encode_text(text, use_checkpoint=use_checkpoint)
-                if norm_embed:
-                    text_embed = F.normalize(text_embed.float(), dim=-1)
-            image_embed = self.encode_image(image, use_checkpoint=use_checkpoint)
+                eot = self._eot_rows(text)
+            box = []
+
+            def text_tower():
+                with torch.cuda.stream(side):
+                    t = self.encode_text(text, use_checkpoint=use_checkpoint, _eot=eot)
+                    box.append(F.normalize(t.float(), dim=-1) if norm_embed else t)
+
+            hooked = hasattr(self.visual, '_after_block')
+            if hooked:
+                self.visual._after_block = (_TEXT_AFTER_BLOCK, text_tower)
+            else:
+                text_tower()
+            try:
+                image_embed = self.encode_image(image, use_checkpoint=use_checkpoint)
+            finally:
+                if hooked:
+                    self.visual._after_block = None
+            if not box:                       # fewer blocks than the hook position
+                text_tower()
+            text_embed = box[0]
             if norm_embed:
                 image_embed = F.normalize(image_embed.float(), dim=-1)
             main.wait_stream(side)

@@ -280,6 +280,7 @@ class SpaceTimeTransformer(nn.Module):
         self.pos_drop = nn.Dropout(p=drop_rate)
 
         dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth)]
+        self._after_block = None      # transient (index, callable) hook of one forward call; never state
         self.blocks = nn.ModuleList([
             SpaceTimeBlock(dim=embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias,
                            qk_scale=qk_scale, drop=drop_rate, attn_drop=attn_drop_rate, drop_path=dpr[i],
@@ -353,12 +354,15 @@ class SpaceTimeTransformer(nn.Module):
             x = self.ln_pre(x)
         x = self.pos_drop(x)
         res, pend, pend_b = x, None, None
-        for blk in self.blocks:
+        hook = self._after_block          # (index, callable) set by CLIP.forward for one call, see models.py
+        for i, blk in enumerate(self.blocks):
             if use_checkpoint:
                 res, pend, pend_b = checkpoint.checkpoint(blk.chain, res, pend, pend_b, frames, n,
                                                           use_reentrant=False)
             else:
                 res, pend, pend_b = blk.chain(res, pend, pend_b, frames, n)
+            if hook is not None and i == hook[0]:
+                hook[1]()
         nm = self.norm
         if cls_at_last:
             # only row 0 of every sample feeds the output: final residual add + LayerNorm on [B, D]

@@ -66,7 +66,10 @@ def test_multirank_loss_equals_single_process_on_concatenation():
     """every rank's CLIPLoss equals the single-process loss on the rank-ordered
     concatenation; vissl local grads = W x the global-loss gradient slice, non-vissl = 1 x."""
     fx = load_golden('clip_loss_multirank.pt')
-    for (world, use_vissl), r in fx['results'].items():
+    for key, r in fx['results'].items():
+        if len(key) != 2:
+            continue                        # local_loss cases: next test
+        world, use_vissl = key
         g = torch.Generator().manual_seed(fx['seed'])
         G = world * fx['B_local']
         img = O.l2_normalize(torch.randn(G, fx['E'], generator=g)).requires_grad_(True)
@@ -81,6 +84,46 @@ def test_multirank_loss_equals_single_process_on_concatenation():
         mult = world if use_vissl else 1
         torch.testing.assert_close(r['dimg'], mult * img.grad, atol=1e-6, rtol=1e-5)
         torch.testing.assert_close(r['dtxt'], mult * txt.grad, atol=1e-6, rtol=1e-5)
+
+
+def test_multirank_local_loss_is_the_mean_over_the_rank_rows():
+    """CLIPLoss(local_loss=True) (loss.py:86-88, 99-100): rank r's loss = mean over ITS rows of the two cross-entropies
+    against all gathered partners. Without gather_with_grad the partners are constants (row terms only); with it every
+    rank's loss reaches every embedding, i.e. the local gradient is that of the SUM of the per-rank losses."""
+    import torch.nn.functional as F
+    fx = load_golden('clip_loss_multirank.pt')
+    seen = 0
+    for key, r in fx['results'].items():
+        if len(key) != 3:
+            continue
+        world, _, with_grad = key
+        seen += 1
+        g = torch.Generator().manual_seed(fx['seed'])
+        Bl, G = fx['B_local'], world * fx['B_local']
+        img = O.l2_normalize(torch.randn(G, fx['E'], generator=g))
+        txt = O.l2_normalize(torch.randn(G, fx['E'], generator=g))
+        dimg, dtxt = torch.zeros_like(img), torch.zeros_like(txt)
+        for rank in range(world):
+            sl = slice(rank * Bl, (rank + 1) * Bl)
+            ia, ta = img.clone().requires_grad_(True), txt.clone().requires_grad_(True)
+            scale = torch.tensor(fx['scale']).requires_grad_(True)
+            il = ia[sl] if with_grad else img[sl].clone().requires_grad_(True)
+            tl = ta[sl] if with_grad else txt[sl].clone().requires_grad_(True)
+            labels = torch.arange(rank * Bl, (rank + 1) * Bl)
+            li, lt = scale * il @ (ta if with_grad else txt).t(), scale * tl @ (ia if with_grad else img).t()
+            loss = (F.cross_entropy(li, labels) + F.cross_entropy(lt, labels)) / 2
+            loss.backward()
+            assert abs(r['loss'][rank] - loss.item()) < 1e-6
+            assert abs(r['acc'][rank] - 100.0 * (li.argmax(-1) == labels).float().mean().item()) < 1e-4
+            assert abs(r['dscale'][rank] - scale.grad.item()) < 1e-6
+            if with_grad:
+                dimg += ia.grad
+                dtxt += ta.grad
+            else:
+                dimg[sl], dtxt[sl] = il.grad, tl.grad
+        torch.testing.assert_close(r['dimg'], dimg, atol=1e-6, rtol=1e-5)
+        torch.testing.assert_close(r['dtxt'], dtxt, atol=1e-6, rtol=1e-5)
+    assert seen == 3
 
 
 def test_ssl_clip_loss_matches_reference():
