@@ -229,8 +229,11 @@ def main():
     fence()
     timer.enabled = wtimer.enabled = gtimer.enabled = not args.no_events
     t0 = time.perf_counter()
+    host_s = 0.0
     for _ in range(args.steps):
+        h0 = time.perf_counter()
         loss = step()
+        host_s += time.perf_counter() - h0
     fence()
     elapsed = time.perf_counter() - t0
     timer.enabled = wtimer.enabled = gtimer.enabled = False
@@ -289,7 +292,8 @@ def main():
             'config': {'workload': f'{args.model}: {tower} {Fr}x{img}^2 clips + 32-token captions (77 ctx), '
                                    f'local batch {B}, global batch {world * B}, contrastive all-gather over RCCL',
                        'global_batch': world * B, 'parallelism': f'dp{world}', 'final_loss': round(final_loss, 4),
-                       'linear_gemms': 'lvl_linear_tn / lvl_linear_wgrad (hand-written MFMA; no library GEMM on the path)'},
+                       'linear_gemms': 'lvl_linear_tn / lvl_linear_wgrad (hand-written MFMA; no library GEMM on the path)',
+                       'host_enqueue_ms_per_step': round(1e3 * host_s / args.steps, 1)},
             'roofline': roofline,
             'roofline_wgrad': roofline_wgrad,
             'roofline_hbm': roofline_hbm,
