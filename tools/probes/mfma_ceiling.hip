@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdint>
 #include <chrono>
+#include <cstdlib>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -106,7 +107,13 @@ int main() {
   const int iters = 40000;
   char* src;
   hipMalloc(&src, 64u << 20);
-  hipMemset(src, 0x3e, 64u << 20);
+  {   // random bf16 payload for the DMA stream too (data-dependent power)
+    uint32_t* h = (uint32_t*)malloc(64u << 20);
+    uint32_t x = 12345u;
+    for (size_t i = 0; i < (64u << 20) / 4; ++i) { x = x * 1664525u + 1013904223u; h[i] = ((x >> 1) & 0x807f807fu) | 0x3e003e00u; }
+    hipMemcpy(src, h, 64u << 20, hipMemcpyHostToDevice);
+    free(h);
+  }
   for (int rnd = 0; rnd < 2; ++rnd) {
     run<0, 8>("regs only", out, clk, iters, rnd);
     run<6, 8>("0.75 rd/mfma", out, clk, iters, rnd);
