@@ -275,7 +275,12 @@ def main():
             return {'bound': 'mfma', 'kernel': kernel, 'achieved': round(ach, 1), 'peak': MFMA_PEAK_TFLOPS,
                     'unit': 'TFLOP/s', 'frac': round(ach / MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
                     'avg_ms': round(tot_ms / len(tm.pairs), 4), 'launches': len(tm.pairs),
-                    'alg_flops_per_launch': round(tot_fl / len(tm.pairs)), 'traffic_note': note}
+                    'alg_flops_per_launch': round(tot_fl / len(tm.pairs)), 'traffic_note': note,
+                    # not the roofline peak: what an MFMA + fragment-read + barrier + LDS-DMA loop at this kernel's
+                    # rates sustains on random bf16 data on this part (power-limited), measured by
+                    # tools/probes/mfma_ceiling.hip
+                    'measured_loop_ceiling': {'value': 1434.0, 'unit': 'TFLOP/s',
+                                              'source': 'profiles/r02_mfma_ceiling_microbench.txt'}}
         # dominant kernel: the forward / input-gradient GEMM, aggregated over all its launches in the timed region
         roofline = mfma_roofline(gtimer, 'lvl_linear_tn (gemm_tn_kernel<0|1|2>, all video-tower forward and '
                                  'input-gradient GEMMs incl. their fused epilogues)', 'r02_traffic_gemm_tn.json') \
