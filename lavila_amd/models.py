@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import loss
+from . import loss, ops
 from .openai_model import QuickGELU, Transformer
 from .timesformer import LayerNorm, SpaceTimeTransformer
 from .utils import remap_keys, rsetattr  # noqa: F401  (re-exported like the reference)
@@ -138,7 +138,7 @@ class CLIP(nn.Module):
             if rows_max is not None:
                 text = text[:, :_longest_caption(text, rows, rows_max)]
             x = self.token_embedding(text) + self.positional_embedding[:text.shape[1]]          # [B, L, W]
-            if torch.is_autocast_enabled():
+            if torch.is_autocast_enabled() and not ops.RESIDUAL_F32:
                 x = x.to(torch.get_autocast_dtype('cuda'))
             x = self.transformer.forward_batch_major(x, self.ln_final, use_checkpoint=use_checkpoint, rows=rows)
             return x @ self.text_projection

@@ -288,8 +288,29 @@ class _LayerNormFn(torch.autograd.Function):
         return dx, dg.to(ctx.pdt[0]), db.to(ctx.pdt[1]), None
 
 
-def layer_norm(x, weight, bias, eps):
-    return _LayerNormFn.apply(x, weight, bias, eps)
+# Residual stream dtype under autocast. Default: the autocast dtype (bf16) from the patch embedding to the final norm
+# (INTEGRATION.md section 3). LAVILA_RESIDUAL_F32=1 (or ops.RESIDUAL_F32 = True) keeps the stream -- and its gradient --
+# in float32 as the reference's AMP does (timesformer.py:353-366, 183-196: cat with the f32 cls_token, f32 LayerNorm
+# outputs, only GEMM outputs are half): the LayerNorm kernels then run in their f32 instantiation, branch outputs are
+# widened on the way in and the normalised rows narrowed on the way out (two extra element-wise passes per site: a
+# fidelity mode, not a fast path).
+RESIDUAL_F32 = os.environ.get('LAVILA_RESIDUAL_F32', '0') == '1'
+
+
+def _gemm_input_dtype():
+    """dtype a LayerNorm output takes when it feeds GEMMs: the autocast dtype, or None (= leave as is)."""
+    return torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled() else None
+
+
+def _narrow(h):
+    lp = _gemm_input_dtype()
+    return h.to(lp) if (lp is not None and h.dtype == torch.float32) else h
+
+
+def layer_norm(x, weight, bias, eps, stream=False):
+    """stream=True: the output IS the residual stream (ln_pre): it keeps the dtype of x."""
+    y = _LayerNormFn.apply(x, weight, bias, eps)
+    return y if stream else _narrow(y)
 
 
 class _AddLayerNormFn(torch.autograd.Function):
@@ -357,13 +378,18 @@ class _AddLayerNormPassFn(torch.autograd.Function):
 
 def add_layer_norm_pass(res, y, ybias, weight, bias, eps):
     """Returns (res_again, h) with h = LayerNorm(res + y (+ ybias)); use res_again for the next consumer of res."""
-    return _AddLayerNormPassFn.apply(res, y, ybias, weight, bias, eps)
+    if y.dtype != res.dtype:
+        y = y.to(res.dtype)
+    r, h = _AddLayerNormPassFn.apply(res, y, ybias, weight, bias, eps)
+    return r, _narrow(h)
 
 
 def add_layer_norm(res, y, ybias, weight, bias, eps, keep_sum=True):
     """Returns (s, h) with s = res + y (+ ybias) and h = LayerNorm(s). With keep_sum=False s is None."""
+    if y.dtype != res.dtype:
+        y = y.to(res.dtype)
     s, h = _AddLayerNormFn.apply(res, y, ybias, weight, bias, eps, keep_sum)
-    return (s if keep_sum else None), h
+    return (s if keep_sum else None), _narrow(h)
 
 
 # --------------------------------------------------------------------------------------------------

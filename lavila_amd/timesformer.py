@@ -349,9 +349,11 @@ class SpaceTimeTransformer(nn.Module):
         if tok.shape[1] != frames * n:
             raise ValueError(f'got {tok.shape[1]} patch tokens for {frames} frames; this model was built for '
                              f'{n} patches per frame (img_size / patch_size are fixed at construction)')
+        if ops.RESIDUAL_F32 and tok.dtype != torch.float32:
+            tok = tok.float()                  # the stream starts in f32, as cat([cls_token f32, half]) does in the reference
         x = ops.embed_tokens(tok, self.cls_token, self.pos_embed, self.temporal_embed, frames, n)
         if self.ln_pre is not None:
-            x = self.ln_pre(x)
+            x = ops.layer_norm(x, self.ln_pre.weight, self.ln_pre.bias, self.ln_pre.eps, stream=True)
         x = self.pos_drop(x)
         res, pend, pend_b = x, None, None
         hook = self._after_block          # (index, callable) set by CLIP.forward for one call, see models.py

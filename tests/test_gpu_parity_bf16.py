@@ -159,7 +159,11 @@ def test_clip_loss_slabs_at_global_batch_2048(dtype):
 # --------------------------------------------------------------------------------------------------------------------
 # the benchmarked model, bf16 autocast, one training step vs the float32 oracle
 # --------------------------------------------------------------------------------------------------------------------
-def test_tsfb_bf16_training_step_vs_oracle_f32():
+_oracle_step_cache = {}
+
+
+@pytest.mark.parametrize('residual_f32', [False, True])
+def test_tsfb_bf16_training_step_vs_oracle_f32(residual_f32, monkeypatch):
     """CLIP_OPENAI_TIMESFORMER_BASE (12 x 768 video blocks, 12 x 512 text blocks), 4 frames of 224^2, batch 4,
     bf16 autocast, forward + CLIPLoss + backward on the MFMA kernels, against oracle.clip_forward / clip_loss in
     float32 on the same float32 master weights.
@@ -170,20 +174,26 @@ def test_tsfb_bf16_training_step_vs_oracle_f32():
     an independent relative perturbation of a branch that is O(1) of the stream. Over L = 12 blocks they add as a
     random walk: relative error of the final features ~ eps * sqrt(r * L) = 1.1e-3 * 11 = 1.2e-2; LayerNorm / softmax
     Lipschitz factors are O(1-2) here, so the unit-norm embeddings are expected within ~1.2-2.5e-2 (relative L2).
-    Bound used: 2.5e-2 (measured 0.9e-2). A logit is 14.3 * <img, txt> with |<img, txt>| <= c: its error is at most
+    Bound used: 2.5e-2 (measured 1.0e-2; 0.6e-2 with the float32 residual stream). A logit is 14.3 * <img, txt> with |<img, txt>| <= c: its error is at most
     14.3 * (e_img + e_txt) * max(c, e) -- here c ~ 0.1 (random towers), i.e. <= 0.07 (bound 0.1, measured 0.015); the
     loss averages 2B of them (bound 2e-2, measured 5e-6). Gradients cross every block a second time in backward with
     the same number of roundings, relative error ~ eps * sqrt(2 r L) * (1-2) = 1.7-3.4e-2 per parameter; bound used
     for EVERY parameter gradient: relative L2 <= 1e-1, with the aggregate (all parameters concatenated) <= 5e-2
-    (measured: aggregate 3.0e-2, median 3.0e-2, worst tensor 4.9e-2 -- the predicted range).
+    (measured: aggregate 3.7e-2, median 3.6e-2, worst tensor 5.2e-2 -- the predicted range; with the float32
+    residual stream 2.0e-2 / 2.0e-2 / 3.7e-2).
     Parameters whose true gradient is ~0 (key biases: softmax is invariant to them; masked-out positional rows) are
     compared absolutely against the gradient scale of their tensor family.
     Index outputs (labels, argmax of the logits) are compared exactly whenever the oracle's own top-2 logit margin
-    exceeds the logit bound."""
+    exceeds the logit bound.
+
+    residual_f32=True repeats the step with LAVILA_RESIDUAL_F32 semantics (the token stream and its gradient stay
+    float32 between the blocks, as under the reference's AMP): the same bounds hold, with fewer roundings per block."""
     import contextlib
     import io
     from lavila.models import models
     from lavila.models.loss import CLIPLoss
+    from lavila_amd import ops
+    monkeypatch.setattr(ops, 'RESIDUAL_F32', residual_f32)
     torch.manual_seed(0)
     with contextlib.redirect_stdout(io.StringIO()):
         model = models.CLIP_OPENAI_TIMESFORMER_BASE(num_frames=4, project_embed_dim=256)
@@ -201,11 +211,14 @@ def test_tsfb_bf16_training_step_vs_oracle_f32():
     dbg = crit.debug_slabs(out)
     torch.cuda.synchronize()
 
-    torch.set_num_threads(min(32, torch.get_num_threads() or 1))
-    wo = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in w.items()}
-    oo = O.clip_forward(video, tokens, wo, 12, 8, norm_embed=True)
-    lo = O.clip_loss(oo['image_embed'], oo['text_embed'], oo['logit_scale'])
-    lo['loss'].backward()
+    if 'oracle' not in _oracle_step_cache:         # the float32 CPU step is the slow part: once for both variants
+        torch.set_num_threads(min(32, torch.get_num_threads() or 1))
+        wo = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in w.items()}
+        oo = O.clip_forward(video, tokens, wo, 12, 8, norm_embed=True)
+        lo = O.clip_loss(oo['image_embed'], oo['text_embed'], oo['logit_scale'])
+        lo['loss'].backward()
+        _oracle_step_cache['oracle'] = (wo, oo, lo)
+    wo, oo, lo = _oracle_step_cache['oracle']
 
     def rel(a, b):
         return ((a.float().cpu() - b).norm() / b.norm().clamp_min(1e-30)).item()
@@ -234,7 +247,7 @@ def test_tsfb_bf16_training_step_vs_oracle_f32():
     scale = math.sqrt(den / len(worst))            # RMS gradient norm of a parameter tensor
     bad = [(r, d, n, k) for r, d, n, k in worst if r > 1e-1 and d > 1e-3 * scale]
     worst.sort(reverse=True)
-    print(f'[bf16 TSF-B step] rel L2: image_embed {e_img:.2e} text_embed {e_txt:.2e}; max |d logit| {dlogit:.3f}; '
+    print(f'[bf16 TSF-B step, residual stream {"f32" if residual_f32 else "bf16"}] rel L2: image_embed {e_img:.2e} text_embed {e_txt:.2e}; max |d logit| {dlogit:.3f}; '
           f'|d loss| {dloss:.2e}; gradients: aggregate {agg:.2e}, worst {worst[0][0]:.2e} ({worst[0][3]}), '
           f'median {worst[len(worst) // 2][0]:.2e} over {len(worst)} tensors')
     assert agg < 5e-2, agg
