@@ -3,8 +3,9 @@
 
 Same class names, constructor signatures and state_dict keys (attn.in_proj_weight, attn.in_proj_bias,
 attn.out_proj.*, ln_1.*, ln_2.*, mlp.c_fc.*, mlp.c_proj.*). The execution is batch-major ([B, L, W]; the
-reference's NLD<->LND permutes disappear), residual adds are fused into the LayerNorms, bias+QuickGELU is one
-kernel, and the causal attention core is a C-ABI call (lvl_causal_attn_fwd/_bwd).
+reference's NLD<->LND permutes disappear), residual adds are fused into the LayerNorms, bias+QuickGELU and its
+backward are epilogues of the c_fc / c_proj GEMMs (lvl_linear_tn), and the causal attention core is a C-ABI call
+(lvl_causal_attn_fwd/_bwd).
 """
 from collections import OrderedDict
 
