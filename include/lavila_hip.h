@@ -34,6 +34,12 @@ enum { LVL_EPI_BIAS = 0, LVL_EPI_BIAS_QUICKGELU = 1, LVL_EPI_QUICKGELU_BWD = 2 }
 
 /* library identification / diagnostics (host pointers) */
 const char* lvl_version(void);
+/* Compute units the two persistent GEMM kernels (lvl_linear_tn, lvl_linear_wgrad: one workgroup per CU holding the
+ * whole register file) size their grids for. 0 (default) = every CU of the device; a multiple of 8 below that leaves
+ * the remaining CUs to whatever runs beside the step (e.g. the channel workgroups of an RCCL collective), which
+ * otherwise force a whole extra round of tiles (tools/probe_cu_contention.py). Process-wide; call before sizing
+ * workspaces (lvl_workspace_floats("linear_wgrad") depends on it). Nothing in the reference corresponds to it. */
+int lvl_set_compute_units(int n);
 const char* lvl_last_error(void);
 /* number of float32 workspace elements a call needs (host-side query, no device work) */
 int64_t lvl_workspace_floats(const char* op, int64_t rows, int64_t cols);

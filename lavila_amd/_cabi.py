@@ -22,6 +22,7 @@ _P, _I, _L, _F = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float
 # name -> (restype, argtypes); must list every function of include/lavila_hip.h
 SIGNATURES = {
     'lvl_version': (_c.c_char_p, []),
+    'lvl_set_compute_units': (_I, [_I]),
     'lvl_last_error': (_c.c_char_p, []),
     'lvl_workspace_floats': (_L, [_c.c_char_p, _L, _L]),
     'lvl_layernorm_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P]),
@@ -72,6 +73,9 @@ def lib():
                 fn = getattr(handle, name)
                 fn.restype = res
                 fn.argtypes = args
+            cus = os.environ.get('LAVILA_COMPUTE_UNITS')        # CUs for the persistent GEMM kernels (see the header)
+            if cus and handle.lvl_set_compute_units(int(cus)) != 0:
+                raise HipExtensionError('LAVILA_COMPUTE_UNITS: ' + handle.lvl_last_error().decode(errors='replace'))
             _lib = handle
     return _lib
 

@@ -31,6 +31,9 @@ int lvl_fail(int code, const char* fmt, ...);
 static inline bool lvl_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // Kernels that use more than 64 KiB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised once.
+// compute units the persistent kernels size their grids for: the device's, or the limit set by lvl_set_compute_units
+int lvl_persistent_cus();
+
 // One call per (kernel instantiation, device), thread-safe, never inside the hot launch path afterwards (and
 // therefore harmless under stream capture once warmed up); the limit is set to the whole 160 KiB of a gfx950 CU.
 template <auto Kernel>

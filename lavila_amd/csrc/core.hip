@@ -19,6 +19,29 @@ int lvl_qkv_bias_row_blocks();
 int64_t lvl_wgrad_workspace_floats(int64_t N, int64_t K);
 int64_t lvl_linear_tn_workspace_floats(int64_t M, int64_t N);
 
+// Compute units the persistent kernels (lvl_linear_tn, lvl_linear_wgrad) size their grids for; 0 = all of the device.
+static std::atomic<int> g_cu_limit{0};
+
+int lvl_persistent_cus() {
+  static std::atomic<int> cached[64];
+  int dev = 0, v = 256;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    v = cached[dev & 63].load(std::memory_order_relaxed);
+    if (v == 0) {
+      if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+      cached[dev & 63].store(v, std::memory_order_relaxed);
+    }
+  }
+  const int lim = g_cu_limit.load(std::memory_order_relaxed);
+  return (lim > 0 && lim < v) ? lim : v;
+}
+
+extern "C" int lvl_set_compute_units(int n) {
+  if (n < 0 || (n != 0 && (n < 8 || n % 8))) return lvl_fail(LVL_EINVAL, "set_compute_units: %d is not 0 or a multiple of 8", n);
+  g_cu_limit.store(n, std::memory_order_relaxed);
+  return LVL_OK;
+}
+
 extern "C" const char* lvl_version(void) { return "lavila_hip 0.1 (gfx950)"; }
 extern "C" const char* lvl_last_error(void) { return lvl_err_buf; }
 

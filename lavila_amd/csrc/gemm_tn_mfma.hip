@@ -498,17 +498,7 @@ __global__ __launch_bounds__(256) void colpart_reduce_kernel(const float* __rest
   if (ry == 0 && n < N) out[(size_t)g * N + n] = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
 }
 
-int num_cus() {                    // compute units of the current device (one persistent workgroup each)
-  static std::atomic<int> cached[64];
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return 256;
-  int v = cached[dev & 63].load(std::memory_order_relaxed);
-  if (v == 0) {
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-    cached[dev & 63].store(v, std::memory_order_relaxed);
-  }
-  return v;
-}
+int num_cus() { return lvl_persistent_cus(); }      // one persistent workgroup per compute unit
 
 template <int EPI>
 int launch_tn(const void* x, const void* w, const float* bias, void* y, void* aux_out, const void* aux_in,

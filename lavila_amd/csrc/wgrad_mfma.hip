@@ -295,9 +295,10 @@ Plan make_plan(int N, int K) {
     const int tn = 16 * c[2] * c[0], tk = 16 * c[3] * c[1];
     if (N % tn || K % tk) continue;
     const int ntiles = (N / tn) * (K / tk);
-    if (ntiles > 256) continue;
-    // one resident workgroup per CU: S * ntiles <= 256 and a multiple of 8 (XCD mapping)
-    int S = 256 / ntiles;
+    const int cus = lvl_persistent_cus();
+    if (ntiles > cus) continue;
+    // one resident workgroup per CU: S * ntiles <= CUs and a multiple of 8 (XCD mapping)
+    int S = cus / ntiles;
     while (S > 1 && (ntiles * S) % 8) --S;
     if ((ntiles * S) % 8) continue;
     // score = busy SIMD slots x tile area: 6 waves load the 4 SIMDs 2:2:1:1, 4 waves leave every SIMD one wave

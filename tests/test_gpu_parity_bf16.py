@@ -128,6 +128,30 @@ def test_linear_wgrad_exact_on_integer_operands(M, N, K):
     assert torch.equal(dw.cpu(), want)
 
 
+@pytest.mark.parametrize('cus', [240, 64, 8])
+def test_persistent_gemms_exact_with_fewer_compute_units(cus):
+    """lvl_set_compute_units: the persistent kernels size their grids (and the weight gradient its row splits and
+    workspace) for fewer CUs; the results stay exact."""
+    from lavila_amd import _cabi as C
+    from lavila_amd import ops
+    lib = C.lib()
+    assert lib.lvl_set_compute_units(12) != 0 and lib.lvl_set_compute_units(-8) != 0      # not a multiple of 8 / negative
+    assert lib.lvl_set_compute_units(cus) == 0
+    try:
+        g = torch.Generator().manual_seed(cus)
+        M, N, K = 9000, 768, 768
+        x = torch.randint(-2, 3, (M, K), generator=g).float()
+        w = torch.randint(-1, 2, (N, K), generator=g).float() * (torch.rand(N, K, generator=g) < 0.08)
+        b = torch.randint(-8, 9, (N,), generator=g).float()
+        y = ops.linear_tn_raw(x.to(DEV).bfloat16(), w.to(DEV).bfloat16(), b.to(DEV), C.EPI_BIAS)
+        assert torch.equal(y.float().cpu(), x @ w.t() + b)
+        dy = torch.randint(-2, 3, (M, N), generator=g).float() * (torch.rand(M, N, generator=g) < 0.05)
+        dw, _ = ops.linear_wgrad_raw(dy.to(DEV).bfloat16(), x.to(DEV).bfloat16(), False)
+        assert torch.equal(dw.cpu(), dy.t() @ x)
+    finally:
+        assert lib.lvl_set_compute_units(0) == 0
+
+
 # --------------------------------------------------------------------------------------------------------------------
 # contrastive slabs at the global batch of BASELINE.json configs[2] (G = 2048 = 8 ranks x 256)
 # --------------------------------------------------------------------------------------------------------------------

@@ -10,3 +10,5 @@ int lvl_fail(int code, const char* fmt, ...) {
   fprintf(stderr, "lvl_fail: %s\n", lvl_err_buf);
   return code;
 }
+
+int lvl_persistent_cus() { return 256; }
