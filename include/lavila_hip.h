@@ -83,13 +83,15 @@ int lvl_bias_quickgelu_bwd(const void* da, const void* u, const float* bias, voi
                            float* ws, int64_t rows, int cols, int dtype, void* stream);
 
 /* ---- patch embedding, gather side ----------------------------------------------------------------
- * video [B,C,F,H,W] f32 (the batch contract of datasets.py:360-387) -> patch matrix
- * [B*F*N, C*P*P] dtype, rows frame-major then (py,px), columns (c,i,j) = Conv2d weight flattening.
- * Replaces permute(0,2,1,3,4).contiguous() (timesformer.py:387) and the im2col half of
+ * video [B,C,F,H,W] f32 (frame_major = 0: the batch contract of datasets.py:360-387, what
+ * SpaceTimeTransformer.forward receives, timesformer.py:384-390) or [B,F,C,H,W] f32 (frame_major = 1:
+ * what forward_features receives, timesformer.py:345-348, the narrator's entry narrator.py:74)
+ * -> patch matrix [B*F*N, C*P*P] dtype, rows frame-major then (py,px), columns (c,i,j) = Conv2d weight
+ * flattening. Replaces permute(0,2,1,3,4).contiguous() (timesformer.py:387) and the im2col half of
  * nn.Conv2d(k=stride=P) (timesformer.py:77,79-84); the contraction with the [D, C*P*P] weight is a
  * plain GEMM. H % P == 0, W % P == 0. */
 int lvl_patchify(const float* video, void* patches, int B, int C, int F, int H, int W, int P,
-                 int dtype, void* stream);
+                 int frame_major, int dtype, void* stream);
 
 /* ---- token assembly: cls concat + positional/temporal embedding add --------------------------------
  * x[b,0,:] = cls + pos[0];  x[b,1+f*N+n,:] = pe[b,f*N+n,:] + pos[1+n] + temporal[f]
@@ -178,9 +180,16 @@ int lvl_ssl_clip_loss_bwd(const void* img_all, const void* txt_all, const int32_
  *   LVL_EPI_QUICKGELU_BWD    y = acc * d quickgelu(aux_in); colsum[N] f32 = column sums of y (= d fc1.bias);
  *                            acc = dA = dY . W2 is the input gradient of fc2, y = d(fc1 output)
  * aux_out / aux_in: [M,N] bf16. N % 256 == 0 and K % 64 == 0 (operands < 4 GiB), else LVL_ENOSYS. Workspace (QUICKGELU_BWD only):
- * lvl_workspace_floats("linear_tn", M, N) floats. */
+ * lvl_workspace_floats("linear_tn", M, N) floats.
+ * sched (nullable): the launch's TILE-COUNTER block, 16 x uint32 (64-byte aligned), ZERO on entry; the kernel leaves it
+ * zero again when its last workgroup exits, so a caller may hand the same block to the next launch on the SAME stream
+ * (launches that can run concurrently -- other streams, graph branches -- need distinct blocks). With it the persistent
+ * workgroups take their 256x256 tiles from per-XCD device counters instead of static ranges: a compute unit held by
+ * another kernel (an RCCL channel during DDP's gradient all-reduce, main_pretrain.py:180-183) then costs one tile, not
+ * a range. NULL = static ranges (identical results: the schedule does not change any tile's arithmetic). */
 int lvl_linear_tn(const void* x, const void* w, const float* bias, void* y, void* aux_out, const void* aux_in,
-                  float* colsum, float* ws, int64_t M, int N, int K, int epilogue, int dtype, void* stream);
+                  float* colsum, float* ws, uint32_t* sched, int64_t M, int N, int K, int epilogue, int dtype,
+                  void* stream);
 
 /* ---- Linear-layer weight gradient ------------------------------------------------------------------------
  * dW[N,K] = dY[M,N]^T X[M,K], dbias[N] (nullable) = column sums of dY: what torch.autograd computes for the weight

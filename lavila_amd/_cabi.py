@@ -29,7 +29,7 @@ SIGNATURES = {
     'lvl_layernorm_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
     'lvl_bias_quickgelu_fwd': (_I, [_P, _P, _P, _L, _I, _I, _P]),
     'lvl_bias_quickgelu_bwd': (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P]),
-    'lvl_patchify': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'lvl_patchify': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'lvl_embed_tokens_fwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     'lvl_divided_attn_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'lvl_divided_attn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
@@ -40,7 +40,7 @@ SIGNATURES = {
     'lvl_clip_loss_bwd': (_I, [_P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P, _P, _I, _P]),
     'lvl_ssl_clip_loss_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P]),
     'lvl_ssl_clip_loss_bwd': (_I, [_P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _P, _P, _I, _P]),
-    'lvl_linear_tn': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
+    'lvl_linear_tn': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
     'lvl_linear_wgrad': (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _P]),
     'lvl_cast_transpose': (_I, [_P, _P, _P, _I, _I, _P]),
     'lvl_qkv_bias_grad': (_I, [_P, _P, _P, _P, _L, _I, _I, _P]),

@@ -96,12 +96,13 @@ __global__ __launch_bounds__(128) void bias_gelu_bwd_kernel(const T* __restrict_
   }
 }
 
-// ---- patchify: [B,C,F,H,W] f32 -> [B*F*gh*gw, C*P*P] -------------------------------------------------
+// ---- patchify: [B,C,F,H,W] (or [B,F,C,H,W]) f32 -> [B*F*gh*gw, C*P*P] ------------------------------------
 // thread = one patch row (P pixels). Thread order follows the INPUT (.., y, px) so reads of a full
 // image row are contiguous across the wave; each thread writes P contiguous output elements.
+// sc / sf: distance between consecutive channels / frames of one clip in H*W planes (BCFHW: F, 1; BFCHW: 1, C).
 template <typename T, int P>
 __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ video, T* __restrict__ out, int B,
-                                                       int C, int F, int H, int W) {
+                                                       int C, int F, int H, int W, int sc, int sf) {
   const int gw = W / P, gh = H / P;
   const int64_t total = (int64_t)B * C * F * H * gw;
   for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total;
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
     const int c = (int)(t % C); t /= C;
     const int b = (int)t;
     const int py = y / P, i = y - py * P;
-    const float* src = video + ((((int64_t)b * C + c) * F + f) * H + y) * W + (int64_t)px * P;
+    const float* src = video + ((((int64_t)b * C * F + (int64_t)c * sc + (int64_t)f * sf)) * H + y) * W + (int64_t)px * P;
     const int64_t m = (((int64_t)b * F + f) * gh + py) * gw + px;
     T* dst = out + m * ((int64_t)C * P * P) + ((int64_t)c * P + i) * P;
     if constexpr (P % 8 == 0) {
@@ -136,7 +137,8 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
 
 template <typename T>
 __global__ __launch_bounds__(256) void patchify_generic_kernel(const float* __restrict__ video, T* __restrict__ out,
-                                                               int B, int C, int F, int H, int W, int P) {
+                                                               int B, int C, int F, int H, int W, int P, int sc,
+                                                               int sf) {
   const int gw = W / P, gh = H / P;
   const int64_t total = (int64_t)B * C * F * H * W;
   for (int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; id < total;
@@ -149,7 +151,8 @@ __global__ __launch_bounds__(256) void patchify_generic_kernel(const float* __re
     const int b = (int)t;
     const int py = y / P, i = y - py * P, px = x / P, j = x - px * P;
     const int64_t m = (((int64_t)b * F + f) * gh + py) * gw + px;
-    Elem<T>::store(out + m * ((int64_t)C * P * P) + ((int64_t)c * P + i) * P + j, video[id]);
+    Elem<T>::store(out + m * ((int64_t)C * P * P) + ((int64_t)c * P + i) * P + j,
+                   video[((((int64_t)b * C * F + (int64_t)c * sc + (int64_t)f * sf)) * H + y) * W + x]);
   }
 }
 
@@ -293,9 +296,10 @@ extern "C" int lvl_bias_quickgelu_bwd(const void* da, const void* u, const float
 
 int lvl_gelu_bwd_row_blocks() { return kGeluBwdRowBlocks; }
 
-extern "C" int lvl_patchify(const float* video, void* patches, int B, int C, int F, int H, int W, int P, int dtype,
-                            void* stream) {
+extern "C" int lvl_patchify(const float* video, void* patches, int B, int C, int F, int H, int W, int P,
+                            int frame_major, int dtype, void* stream) {
   LVL_REQUIRE(video && patches, "patchify: null pointer");
+  const int sc = frame_major ? 1 : F, sf = frame_major ? C : 1;
   LVL_REQUIRE(B >= 0 && C > 0 && F > 0 && H > 0 && W > 0 && P > 0 && H % P == 0 && W % P == 0,
               "patchify: bad shape B=%d C=%d F=%d H=%d W=%d P=%d", B, C, F, H, W, P);
   LVL_REQUIRE(lvl_aligned16(video) && lvl_aligned16(patches), "patchify: pointers must be 16-byte aligned");
@@ -304,14 +308,14 @@ extern "C" int lvl_patchify(const float* video, void* patches, int B, int C, int
   const int64_t rows_total = (int64_t)B * C * F * H * (W / P);
   if (P == 16 && W % 4 == 0) {
     LVL_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((patchify_kernel<T, 16>), dim3(grid_for(rows_total, 256)), dim3(256),
-                                                 0, st, video, (T*)patches, B, C, F, H, W));
+                                                 0, st, video, (T*)patches, B, C, F, H, W, sc, sf));
   } else if (P == 14 && W % 2 == 0 && dtype == LVL_BF16) {
     hipLaunchKernelGGL((patchify_kernel<bf16_t, 14>), dim3(grid_for(rows_total, 256)), dim3(256), 0, st, video,
-                       (bf16_t*)patches, B, C, F, H, W);
+                       (bf16_t*)patches, B, C, F, H, W, sc, sf);
   } else {
     LVL_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((patchify_generic_kernel<T>),
                                                  dim3(grid_for((int64_t)B * C * F * H * W, 256)), dim3(256), 0, st,
-                                                 video, (T*)patches, B, C, F, H, W, P));
+                                                 video, (T*)patches, B, C, F, H, W, P, sc, sf));
   }
   LVL_CHECK_LAUNCH("patchify");
   return LVL_OK;

@@ -40,7 +40,15 @@
 //     flight across the next tile's first blocks (the vmcnt allowances account for them);
 //   * blockIdx -> tile is XCD-aware (workgroup i runs on XCD i % 8): each XCD owns a contiguous range of the
 //     N-fastest tile order, so the N/256 tiles that read the same 256 rows of X sit behind one L2 and X comes from
-//     HBM once; W (<= 4.7 MB) lives in L2 / Infinity Cache.
+//     HBM once; W (<= 4.7 MB) lives in L2 / Infinity Cache;
+//   * inside an XCD's range the tiles are handed out by a DEVICE TILE COUNTER (one word per XCD, `sched`): a
+//     workgroup takes the next tile of its XCD's queue with one returning atomic add, issued at the top of the tile
+//     before, so that its latency never shows (the reply is parked in a register, published to the other waves
+//     through an LDS mailbox two K blocks later -- by then the counted vmcnt waits of the K loop have covered it --
+//     and read by the fetch cursor when it wraps to the next tile, three K blocks before the end).
+//     A compute unit that another kernel holds (an RCCL channel during the gradient all-reduce) therefore costs
+//     the launch one tile's worth of throughput, not a static range of tiles: its workgroup starts late, finds
+//     the queues drained and leaves. The last workgroup out zeroes the counters again.
 #include <type_traits>
 
 #include "common.h"
@@ -58,7 +66,9 @@ constexpr int TM = 256, TN = 256;      // workgroup tile
 constexpr int SLOT = 128 * 128;        // bytes of one slot: 128 rows x 128 B
 constexpr int NSLOT = 8;               // two K blocks x {X0, X1, W0, W1}
 constexpr int BIAS_OFF = NSLOT * SLOT; // four 1-KiB images of bias[n0 .. n0+255] behind the ring (tile index & 3)
-constexpr int SMEM_B = BIAS_OFF + 4 * 1024;
+constexpr int MBOX_OFF = BIAS_OFF + 4 * 1024;   // one word: the tile-queue reply wave 0 publishes to the workgroup
+constexpr int SMEM_B = MBOX_OFF + 64;
+constexpr int DYN_MIN_NB = 5;          // K blocks a tile needs for the publish (block 2) -> read (block nb-3) hand-off
 enum { S_X0 = 0, S_X1 = 1, S_W0 = 2, S_W1 = 3 };
 
 __device__ __forceinline__ gm_f32x16 mfma32(uint4 a, uint4 b, gm_f32x16 c) {
@@ -66,9 +76,12 @@ __device__ __forceinline__ gm_f32x16 mfma32(uint4 a, uint4 b, gm_f32x16 c) {
                                                  c, 0, 0, 0);
 }
 
-__device__ __forceinline__ float quick_gelu(float u) { return u / (1.f + __expf(-1.702f * u)); }
+// sigmoid through v_exp_f32 + v_rcp_f32 (1 ulp each; the results are rounded to bf16): an IEEE division here costs
+// ~10 VALU instructions per element of a 256x256 tile's epilogue
+__device__ __forceinline__ float sigmoid1702(float u) { return __builtin_amdgcn_rcpf(1.f + __expf(-1.702f * u)); }
+__device__ __forceinline__ float quick_gelu(float u) { return u * sigmoid1702(u); }
 __device__ __forceinline__ float quick_gelu_grad(float u) {
-  const float s = 1.f / (1.f + __expf(-1.702f * u));
+  const float s = sigmoid1702(u);
   return s * (1.f + 1.702f * u * (1.f - s));
 }
 
@@ -87,22 +100,61 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
                                                       uint16_t* __restrict__ aux_out,
                                                       const uint16_t* __restrict__ aux_in,
                                                       float* __restrict__ colpart, int64_t M, int N, int K,
-                                                      int tiles_n, int ntiles) {
+                                                      int tiles_n, int ntiles, unsigned* __restrict__ sched) {
   extern __shared__ __attribute__((aligned(1024))) uint8_t smem[];      // [NSLOT][128 rows][128 B]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   const int nb = K / BK;
-  // PERSISTENT workgroups, one per CU: workgroup b sits on XCD b % 8 and walks the tiles first, first + wpx, ... of
-  // that XCD's contiguous range of the N-fastest tile order (bijective for any tile count): at any time the
-  // workgroups of an XCD work on neighbouring tiles, so the N/256 tiles that read the same rows of X share one L2.
+  // PERSISTENT workgroups, one per CU: workgroup b sits on XCD b % 8 and works on that XCD's contiguous range
+  // [xstart, xstart + cnt) of the N-fastest tile order (bijective for any tile count): at any time the workgroups of
+  // an XCD work on neighbouring tiles, so the N/256 tiles that read the same rows of X share one L2.
+  //   static schedule (sched == nullptr): tiles xstart + bid/8, + wpx, + 2 wpx, ...
+  //   dynamic schedule: tiles xstart + (value of the XCD's counter when the workgroup asked), see the file header.
   const int nx = gridDim.x >= 8 ? 8 : 1;
   const int bid = blockIdx.x, xcd = bid % nx, wpx = gridDim.x / nx;
   const int tq = ntiles / nx, tr = ntiles % nx;
   const int cnt = tq + (xcd < tr ? 1 : 0);
-  if (bid / nx >= cnt) return;
-  const int first = (xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq) + bid / nx;
-  const int my_tiles = (cnt - bid / nx + wpx - 1) / wpx;
+  const int xstart = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+  const bool dyn = sched != nullptr;            // the host passes a counter block only when nb >= DYN_MIN_NB
+  if (!dyn && bid / nx >= cnt) return;
+  int my_tiles = dyn ? 0x7fffffff : (cnt - bid / nx + wpx - 1) / wpx;
+  int pair_even = xstart + bid / nx, pair_odd = pair_even;    // tile index (N-fastest order) of tile ordinal i, by i & 1
+  auto set_pair = [&](int i, int v) { if (i & 1) pair_odd = v; else pair_even = v; };
+  auto get_pair = [&](int i) { return (i & 1) ? pair_odd : pair_even; };
+  // wave 0 / lane 0 of a dynamic workgroup: the counter reply in flight. Written by the memory system when the atomic
+  // returns, NOT at the asm statement that issues it: it is only ever read by `publish` below, behind a vmcnt wait
+  // that covers the atomic (tests/test_boundary_cpu.py checks in the ISA that nothing else touches the register).
+  uint32_t pend = 0;
+  unsigned* const ctr = sched + xcd;
+  // (lane 0 only: EXEC is narrowed inside the asm -- a divergent C++ branch here would make the compiler treat the
+  // loop-carried tile cursor as divergent and move the DMA base addresses into vector registers)
+  uint64_t exec_save;
+  auto pull = [&]() {
+    if (wave == 0)
+      asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add %0, %2, %3, %4 sc0\n\ts_mov_b64 exec, %1"
+                   : "=v"(pend), "=&s"(exec_save) : "v"(0u), "v"(1u), "s"(ctr) : "memory");
+  };
+  auto publish = [&]() {
+    if (wave == 0)
+      asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_write_b32 %1, %2\n\ts_mov_b64 exec, %0"
+                   : "=&s"(exec_save) : "v"((uint32_t)(uintptr_t)smem + MBOX_OFF), "v"(pend) : "memory");
+  };
+  auto mailbox = [&]() -> int {
+    return __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(smem + MBOX_OFF));
+  };
+  if (dyn) {
+    // first tile: the one synchronous hand-out (nothing is in flight yet, ~1 us once per launch)
+    pull();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    publish();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const int v = mailbox();
+    if (v >= cnt) my_tiles = 0;                 // queue already drained (this workgroup got its CU late)
+    pair_even = xstart + v;
+    __builtin_amdgcn_s_barrier();               // everyone has read the mailbox before it is written again
+  }
 
   // Tile order: all N/256 column tiles of a row block are neighbours (N-fastest). (Panels of 3-6 column tiles, to keep
   // a weight panel L2-resident, measured no faster: the weight re-reads are served by the Infinity Cache.)
@@ -136,7 +188,8 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
   uint32_t f_xrow;                 // byte offset of the fetch tile's first X row
   const char* f_wbase;             // first W row of the fetch tile
   auto fetch_tile = [&](int i) {
-    const int pair = first + i * wpx;
+    if (!dyn) set_pair(i, xstart + bid / nx + i * wpx);
+    const int pair = __builtin_amdgcn_readfirstlane(get_pair(i));
     int tm, tn;
     decode_tile(pair, tm, tn);
     f_xrow = (uint32_t)tm * (uint32_t)(TM * K * 2);
@@ -154,6 +207,15 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
   };
   auto fetch_advance = [&]() {
     if (++f_j == nb) {
+      if (dyn && f_i + 1 < my_tiles) {
+        // the reply wave 0 published at K block 2 of the tile being multiplied (>= 4 barriers ago)
+        const int v = mailbox();
+        if (v < cnt) {
+          set_pair(f_i + 1, xstart + v);
+        } else {
+          my_tiles = f_i + 1;      // the XCD's queue is drained
+        }
+      }
       if (f_i + 1 < my_tiles) {
         f_j = 0;
         fetch_tile(++f_i);
@@ -357,6 +419,7 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
 #endif
   GM_STAMP();
   uint4 xA[8], xB[8], wA[4], wB[4];
+  if (my_tiles > 0) {
   fetch_tile(0);
 #pragma unroll
   for (int b0 = 0; b0 < 2; ++b0) {         // blocks 0 and 1, groups in the order the phases will read them
@@ -452,16 +515,28 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
   using IS = std::integral_constant<int, NS>;
   for (int i = 0; i < my_tiles; ++i) {
     int j = 0;
+    // ask for the NEXT tile now: the reply lands during K blocks 0-1, is published at block 2 and read by the fetch
+    // cursor at block nb-3 (the register that receives it is live only across these first blocks, not across the
+    // epilogue, where the accumulators, the packed results and the next tile's first fragments fill the file)
+    if (dyn) pull();
     if (i > 0) {                     // the slots read here were filled before the previous tile's epilogue
       k_block(IS{}, IS{});
       if (nb > 1) k_block(IS{}, I0{});
       j = 2;
     }
-    for (; j < nb; ++j) k_block(I0{}, I0{});
+    for (; j < nb; ++j) {
+      if (dyn && j == 2) {
+        // K block 2: the counter reply asked for at the top of this tile is 16 fills old; "all but the 10 newest" --
+        // the wait the next barrier performs anyway -- has it in its register
+        if (wave == 0) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        publish();
+      }
+      k_block(I0{}, I0{});
+    }
     // the fills of the next tile's first blocks are in flight and its first X0 / W0 fragments already in registers
     // while this tile's results leave
     GM_STAMP();
-    const int pair = first + i * wpx;
+    const int pair = get_pair(i);
     int tm, tn;
     decode_tile(pair, tm, tn);
     epilogue(tm, tn, i);
@@ -469,9 +544,19 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
     init_acc(i + 1);
     __builtin_amdgcn_sched_barrier(0);
   }
+  }
 #undef GM_BAR
 #undef GM_PHASE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the run-ahead fills before this workgroup's LDS is freed
+  if (dyn && wave == 0 && lane == 0) {
+    // every workgroup of the launch signs off once (its counter atomics are complete: vmcnt(0) above); the last one
+    // out leaves the counter block zeroed for the next launch that is handed the same block
+    const unsigned gone = __hip_atomic_fetch_add(sched + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (gone == gridDim.x - 1) {
+#pragma unroll
+      for (int q = 0; q < 9; ++q) __hip_atomic_store(sched + q, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 // out[g][n] = sum over the rows p = g, g + G, g + 2G, ... of part[p][n] (deterministic, no atomics). Launched twice:
@@ -502,7 +587,7 @@ int num_cus() { return lvl_persistent_cus(); }      // one persistent workgroup 
 
 template <int EPI>
 int launch_tn(const void* x, const void* w, const float* bias, void* y, void* aux_out, const void* aux_in,
-              float* colpart, int64_t M, int N, int K, hipStream_t st) {
+              float* colpart, int64_t M, int N, int K, unsigned* sched, hipStream_t st) {
   constexpr int shmem = SMEM_B;
   const int rc = lvl_allow_lds<gemm_tn_kernel<EPI>>();
   if (rc != LVL_OK) return rc;
@@ -512,9 +597,10 @@ int launch_tn(const void* x, const void* w, const float* bias, void* y, void* au
   if (ntiles > 0x7fffffff) return lvl_fail(LVL_EINVAL, "linear_tn: too many tiles");
   int grid = (int)(ntiles < num_cus() ? ntiles : num_cus());
   if (grid >= 8) grid -= grid % 8;          // whole XCD rounds (the kernel maps workgroup b to XCD b % 8)
+  if (K / BK < DYN_MIN_NB) sched = nullptr; // too few K blocks per tile for the counter hand-off: static schedule
   hipLaunchKernelGGL((gemm_tn_kernel<EPI>), dim3((unsigned)grid), dim3(512), shmem, st, (const uint16_t*)x,
                      (const uint16_t*)w, bias, (uint16_t*)y, (uint16_t*)aux_out, (const uint16_t*)aux_in, colpart, M,
-                     N, K, tiles_n, (int)ntiles);
+                     N, K, tiles_n, (int)ntiles, sched);
   LVL_CHECK_LAUNCH("linear_tn");
   return LVL_OK;
 }
@@ -526,13 +612,13 @@ int64_t lvl_linear_tn_workspace_floats(int64_t M, int64_t N) { return (2 * ((M +
 #ifdef GM_TRACE
 extern "C" int lvl_linear_tn_trace(const void* x, const void* w, const float* bias, void* y, void* trace, int64_t M,
                                    int N, int K, void* stream) {
-  return launch_tn<0>(x, w, bias, y, nullptr, nullptr, (float*)trace, M, N, K, (hipStream_t)stream);
+  return launch_tn<0>(x, w, bias, y, nullptr, nullptr, (float*)trace, M, N, K, nullptr, (hipStream_t)stream);
 }
 #endif
 
 extern "C" int lvl_linear_tn(const void* x, const void* w, const float* bias, void* y, void* aux_out,
-                             const void* aux_in, float* colsum, float* ws, int64_t M, int N, int K, int epilogue,
-                             int dtype, void* stream) {
+                             const void* aux_in, float* colsum, float* ws, uint32_t* sched, int64_t M, int N, int K,
+                             int epilogue, int dtype, void* stream) {
   LVL_REQUIRE(x && w && y, "linear_tn: null pointer");
   LVL_REQUIRE(dtype == LVL_BF16, "linear_tn: bf16 operands only (dtype=%d)", dtype);
   LVL_REQUIRE(M > 0 && N > 0 && K > 0, "linear_tn: empty problem");
@@ -546,14 +632,14 @@ extern "C" int lvl_linear_tn(const void* x, const void* w, const float* bias, vo
   hipStream_t st = (hipStream_t)stream;
   switch (epilogue) {
     case LVL_EPI_BIAS:
-      return launch_tn<0>(x, w, bias, y, nullptr, nullptr, nullptr, M, N, K, st);
+      return launch_tn<0>(x, w, bias, y, nullptr, nullptr, nullptr, M, N, K, sched, st);
     case LVL_EPI_BIAS_QUICKGELU:
       LVL_REQUIRE(aux_out != nullptr, "linear_tn: the QuickGELU epilogue writes the pre-activation to aux_out");
-      return launch_tn<1>(x, w, bias, y, aux_out, nullptr, nullptr, M, N, K, st);
+      return launch_tn<1>(x, w, bias, y, aux_out, nullptr, nullptr, M, N, K, sched, st);
     case LVL_EPI_QUICKGELU_BWD: {
       LVL_REQUIRE(aux_in != nullptr && colsum != nullptr && ws != nullptr && lvl_aligned16(ws),
                   "linear_tn: the QuickGELU-backward epilogue needs aux_in, colsum and a workspace");
-      const int rc = launch_tn<2>(x, w, nullptr, y, nullptr, aux_in, ws, M, N, K, st);
+      const int rc = launch_tn<2>(x, w, nullptr, y, nullptr, aux_in, ws, M, N, K, sched, st);
       if (rc != LVL_OK) return rc;
       const int P = (int)(2 * ((M + TM - 1) / TM));
       float* mid = ws + (size_t)P * N;          // [32][N]

@@ -86,7 +86,11 @@ class _ContrastiveFn(torch.autograd.Function):
         if ctx.local:
             # with gather_with_grad the all-gather's backward sums, on the owner of a row, the column terms of EVERY
             # rank's local loss (each weighted 1/(2B)): rows + columns over the global batch, as in the vissl path;
-            # without it the gathered rows are constants and only the row terms of the own loss remain
+            # without it the gathered rows are constants and only the row terms of the own loss remain.
+            # ASSUMPTION (holds for loss.backward() and any rank-uniform loss scaling such as GradScaler): every rank
+            # feeds the same upstream gradient `dloss` -- this rank's value stands in for the other ranks' in the column
+            # terms, which is what lets the backward run without a collective. Per-rank loss weights would need the
+            # reference's torch.distributed.nn.all_gather backward instead.
             dimg, dtxt = crit._slab_backward(img_all, txt_all, lse_all, scale, up, 1.0 / (2 * B), B, row0,
                                              rows_only=not crit.gather_with_grad)
             dscale = up[0] * sums[1] / (2 * B) / scale[0]
@@ -128,6 +132,12 @@ class CLIPLoss(nn.Module):
         logit_scale = outputs['logit_scale']
         if self.world_size > 1 and not (dist.is_available() and dist.is_initialized()):
             raise RuntimeError('CLIPLoss(world_size>1) needs an initialised torch.distributed process group')
+        if self.world_size > 1 and self.use_vissl and self.local_loss:
+            # the reference builds GLOBAL logits on the vissl path and then offsets the labels by num_logits * rank
+            # (loss.py:74-79,99-100): out-of-range targets, an error there as well. Not silently turned into the
+            # global loss here.
+            raise NotImplementedError('CLIPLoss(use_vissl=True, local_loss=True) on several ranks indexes labels out of '
+                                      'range in the reference (loss.py:99-100); not reproduced')
         loss, acc = _ContrastiveFn.apply(image_features, text_features, logit_scale, self)
         return {'loss': loss, 'clip_loss': loss, 'clip_acc': acc}
 

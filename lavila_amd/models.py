@@ -7,6 +7,7 @@ main_pretrain.py / eval_zeroshot.py drive it unchanged. Only the dual-encoder pr
 """
 import contextlib
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -31,25 +32,34 @@ def _amp_region():
         yield
 
 
+def _half_out(x, *given):
+    """`model.half()` / `images.half()` callers (eval_zeroshot.py:212-213,256-261,293-304,340-354; no autocast there)
+    get fp16 back; inside, fp16 parameters and activations are computed in bf16 (ops.lowp, ops.weight_copies)."""
+    if not torch.is_autocast_enabled() and x.dtype != torch.float16 and \
+            any(g.dtype == torch.float16 for g in given):
+        return x.to(torch.float16)
+    return x
+
+
 _TEXT_STREAM = os.environ.get('LAVILA_TEXT_STREAM', '1') != '0'
 _TEXT_TRIM = os.environ.get('LAVILA_TEXT_TRIM', '1') != '0'
 _TEXT_AFTER_BLOCK = 1          # video blocks enqueued before the text tower's caption-length read-back
 _text_streams = {}
 
 
-_lmax_memo = [None, -1, 0]          # (weakref to the token tensor, its version, longest caption)
+_lmax_memos = weakref.WeakKeyDictionary()      # model -> (weakref to the token tensor, its version, longest caption)
 
 
-def _longest_caption(text, rows, rows_max=None):
+def _longest_caption(owner, text, rows, rows_max=None):
     """1 + the largest EOT position of the batch. One scalar read back from the device (`rows_max`: the reduction
-    already enqueued by the caller, so that the read-back finds it finished); memoised on the identity (weak reference)
-    and version of the token tensor, so calling encode_text twice on one batch reads it once."""
-    ref, ver, lmax = _lmax_memo
-    if ref is not None and ref() is text and ver == text._version:
-        return lmax
-    import weakref
+    already enqueued by the caller, so that the read-back finds it finished); memoised per model on the identity (weak
+    reference) and version of the token tensor, so calling encode_text twice on one batch reads it once. The memo lives
+    beside the model (not on it: the model stays picklable), one slot per model instance."""
+    memo = _lmax_memos.get(owner)
+    if memo is not None and memo[0]() is text and memo[1] == text._version:
+        return memo[2]
     lmax = int((rows.max() if rows_max is None else rows_max).item()) + 1
-    _lmax_memo[:] = [weakref.ref(text), text._version, lmax]
+    _lmax_memos[owner] = (weakref.ref(text), text._version, lmax)
     return lmax
 
 
@@ -110,15 +120,22 @@ class CLIP(nn.Module):
         mask.triu_(1)
         return mask
 
-    def encode_image(self, image, use_checkpoint=False, apply_project=True):
+    def encode_image(self, image, use_checkpoint=False, apply_project=True, _after_block=None):
+        """models.py:139-148. `_after_block` (not in the reference signature) is handed to the video tower, see
+        SpaceTimeTransformer._features_from_tokens."""
         with _amp_region():
-            x = self.visual(image, use_checkpoint=use_checkpoint)
+            if _after_block is not None:
+                x = self.visual(image, use_checkpoint=use_checkpoint, _after_block=_after_block)
+            else:
+                x = self.visual(image, use_checkpoint=use_checkpoint)
             if isinstance(x, list):
                 assert len(x) == 1
                 x = x[0]
             if not apply_project:
-                return x
-            return x @ self.image_projection
+                return _half_out(x, image, self.image_projection)
+            if x.dtype != self.image_projection.dtype and not torch.is_autocast_enabled():
+                x = x.to(self.image_projection.dtype)        # fp16 clip into an f32 model, or the reverse
+            return _half_out(x @ self.image_projection, image, self.image_projection)
 
     def _eot_rows(self, text):
         """(EOT row of every caption, their maximum as a device scalar or None): enqueued without a host read."""
@@ -127,6 +144,7 @@ class CLIP(nn.Module):
         return rows, (rows.max() if trim else None)
 
     def encode_text(self, text, use_checkpoint=False, _eot=None):
+        ops.training_forward_begins()
         with _amp_region():
             # Only the EOT row (highest token id, models.py:158-160) of the last layer feeds the output, and under
             # the causal mask a row never sees later positions: everything behind the longest caption of the batch
@@ -136,14 +154,19 @@ class CLIP(nn.Module):
             # LAVILA_TEXT_TRIM=0 (or stream capture) keeps all 77 positions.
             rows, rows_max = self._eot_rows(text) if _eot is None else _eot
             if rows_max is not None:
-                text = text[:, :_longest_caption(text, rows, rows_max)]
+                text = text[:, :_longest_caption(self, text, rows, rows_max)]
             x = self.token_embedding(text) + self.positional_embedding[:text.shape[1]]          # [B, L, W]
-            if torch.is_autocast_enabled() and not ops.RESIDUAL_F32:
-                x = x.to(torch.get_autocast_dtype('cuda'))
+            if x.dtype == torch.float16:                   # model.half(): compute in bf16 (f32 stream if asked for)
+                x = x.float() if ops.RESIDUAL_F32 else x.to(torch.bfloat16)
+            elif torch.is_autocast_enabled() and not ops.RESIDUAL_F32:
+                x = x.to(ops.autocast_dtype())
             x = self.transformer.forward_batch_major(x, self.ln_final, use_checkpoint=use_checkpoint, rows=rows)
-            return x @ self.text_projection
+            if x.dtype != self.text_projection.dtype and not torch.is_autocast_enabled():
+                x = x.to(self.text_projection.dtype)
+            return _half_out(x @ self.text_projection, self.text_projection)
 
     def forward(self, image, text, use_checkpoint=False, norm_embed=False):
+        ops.training_forward_begins()
         if _TEXT_STREAM and image.is_cuda:
             # The two towers are independent until the loss: the (small) text tower runs on a second HIP stream so that
             # its short kernels fill the tails of the video tower's launches. Autograd replays each tower's backward on
@@ -166,16 +189,13 @@ class CLIP(nn.Module):
                     t = self.encode_text(text, use_checkpoint=use_checkpoint, _eot=eot)
                     box.append(F.normalize(t.float(), dim=-1) if norm_embed else t)
 
-            hooked = hasattr(self.visual, '_after_block')
-            if hooked:
-                self.visual._after_block = (_TEXT_AFTER_BLOCK, text_tower)
+            if isinstance(self.visual, SpaceTimeTransformer):
+                # the hook travels as an argument of this call (no module state: concurrent forwards are independent)
+                image_embed = self.encode_image(image, use_checkpoint=use_checkpoint,
+                                                _after_block=(_TEXT_AFTER_BLOCK, text_tower))
             else:
                 text_tower()
-            try:
                 image_embed = self.encode_image(image, use_checkpoint=use_checkpoint)
-            finally:
-                if hooked:
-                    self.visual._after_block = None
             if not box:                       # fewer blocks than the hook position
                 text_tower()
             text_embed = box[0]

@@ -30,11 +30,35 @@ def _rows_cols(x: torch.Tensor):
     return x.numel() // cols, cols
 
 
+def autocast_dtype():
+    """The activation dtype of an active autocast region, or None. The kernels compute in f32 or bf16: the reference
+    drivers' fp16 autocast (`torch.cuda.amp.autocast()`, main_pretrain.py:490) means bf16 here."""
+    if not torch.is_autocast_enabled():
+        return None
+    dt = torch.get_autocast_dtype('cuda')
+    return torch.bfloat16 if dt == torch.float16 else dt
+
+
+def lowp(x: torch.Tensor) -> torch.Tensor:
+    """fp16 activations (model.half() + images.half(): eval_zeroshot.py:212-213,256-257,293-304) are computed in bf16;
+    the model wrappers hand fp16 back to the caller."""
+    return x.to(torch.bfloat16) if x.dtype == torch.float16 else x
+
+
+def _act(x: torch.Tensor) -> torch.Tensor:
+    """Activation entering a GEMM: f32 -> the autocast dtype when autocast is on, fp16 -> bf16."""
+    if x.dtype == torch.float16:
+        return x.to(torch.bfloat16)
+    lp = autocast_dtype()
+    return x.to(lp) if (lp is not None and x.dtype == torch.float32) else x
+
+
 # --------------------------------------------------------------------------------------------------
 # Linear layers: hand-written MFMA GEMMs (forward / input gradient: lvl_linear_tn, weight gradient: lvl_linear_wgrad)
 # --------------------------------------------------------------------------------------------------
 _warned = set()
-_copies = {}          # (id(parameter), shape) -> (version, bf16 copy, transposed bf16 copy, data_ptr)
+_copies = {}          # (id(parameter), shape) -> (version, bf16 copy, transposed bf16 copy, data_ptr, generation)
+_generation = 0       # bumped whenever parameter VALUES may have changed behind the version counter's back
 
 
 def warn_once(key, msg):
@@ -45,31 +69,72 @@ def warn_once(key, msg):
         warnings.warn('lavila_amd: ' + msg, stacklevel=3)
 
 
+def invalidate_weight_cache():
+    """Forget every cached bf16 weight copy (they are re-cast on their next use).
+
+    The cache key (tensor version counter + storage pointer) does not see writes through `param.data`
+    (ZeroRedundancyOptimizer's broadcast of updated shards into `param.data`, `logit_scale.data.clamp_`-style edits,
+    bucket-view updates). Two automatic triggers cover the training loop: every optimizer step (a global
+    `register_optimizer_step_post_hook`, installed on import) and the start of every grad-enabled model forward
+    (`training_forward_begins`). Call this by hand after any other out-of-band write to a Linear weight."""
+    global _generation
+    _generation += 1
+
+
+def training_forward_begins():
+    """Called by the model wrappers (CLIP.forward / encode_*, SpaceTimeTransformer.forward*) at the top of a forward:
+    with gradients enabled the copies are re-cast once per forward -- the same one lvl_cast_transpose pass per optimizer
+    step as before, now independent of HOW the optimizer wrote the parameters -- and then shared by that forward, its
+    backward and activation checkpointing's recomputation (which re-enters the blocks, not the wrappers)."""
+    if torch.is_grad_enabled():
+        invalidate_weight_cache()
+
+
+def _optimizer_stepped(optimizer, args, kwargs):
+    invalidate_weight_cache()
+
+
+try:        # every torch.optim.Optimizer (ZeroRedundancyOptimizer included) announces its step() here
+    from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_post_hook
+    _reg_post_hook(_optimizer_stepped)
+except ImportError:         # older torch: the per-forward trigger alone
+    pass
+
+
+def _cast_pair(src):
+    if src.dtype == torch.float32 and src.is_contiguous():
+        w = torch.empty_like(src, dtype=torch.bfloat16)
+        wt = torch.empty(src.shape[1], src.shape[0], dtype=torch.bfloat16, device=src.device)
+        C.check(C.lib().lvl_cast_transpose(C.ptr(src), C.ptr(w), C.ptr(wt), src.shape[0], src.shape[1], C.stream_ptr()),
+                'lvl_cast_transpose')
+    else:                   # fp16 parameters (model.half(), eval_zeroshot.py --use-half) and views
+        w = src.to(torch.bfloat16).contiguous()
+        wt = w.t().contiguous()
+    return w, wt
+
+
 def weight_copies(weight: torch.Tensor):
     """(w, wt): the bf16 copy [out,in] the forward GEMM reads and the transposed bf16 copy [in,out] the input-gradient
     GEMM reads (both operands of lvl_linear_tn are contraction-contiguous). One lvl_cast_transpose pass per optimizer
-    step: the pair is cached on the parameter and keyed by its version counter, so activation checkpointing's second
-    forward and every backward reuse it."""
+    step: the pair is cached per parameter and keyed by (version counter, storage pointer, cache generation), so
+    activation checkpointing's second forward and every backward reuse it; see invalidate_weight_cache for what bumps
+    the generation. Under hipGraph capture the cache is bypassed: the cast is recorded INTO the graph (into
+    graph-owned buffers), so a replay after a weight update reads the updated weights."""
+    src = weight.detach()
+    if src.is_cuda and torch.cuda.is_current_stream_capturing():
+        return _cast_pair(src)
     # keyed by the identity of the parameter (a 2-D view of one -- the Conv2d weight of the patch embedding -- keys on
     # its base); a weakref finaliser drops the entry with the parameter, nothing is attached to the parameter itself
     # (pickling / deepcopy of the model see no extra state)
     holder = weight._base if weight._base is not None else weight
     ver, key = weight._version, (id(holder), tuple(weight.shape))
     c = _copies.get(key)
-    if c is not None and c[0] == ver and c[3] == weight.data_ptr():      # same values, same storage
+    if c is not None and c[0] == ver and c[3] == weight.data_ptr() and c[4] == _generation:
         return c[1], c[2]
     if c is None:
         weakref.finalize(holder, _copies.pop, key, None)
-    src = weight.detach()
-    if src.dtype == torch.float32 and src.is_contiguous():
-        w = torch.empty_like(src, dtype=torch.bfloat16)
-        wt = torch.empty(src.shape[1], src.shape[0], dtype=torch.bfloat16, device=src.device)
-        C.check(C.lib().lvl_cast_transpose(C.ptr(src), C.ptr(w), C.ptr(wt), src.shape[0], src.shape[1], C.stream_ptr()),
-                'lvl_cast_transpose')
-    else:
-        w = src.to(torch.bfloat16).contiguous()
-        wt = w.t().contiguous()
-    _copies[key] = (ver, w, wt, weight.data_ptr())
+    w, wt = _cast_pair(src)
+    _copies[key] = (ver, w, wt, weight.data_ptr(), _generation)
     return w, wt
 
 
@@ -176,8 +241,7 @@ class _MlpFn(torch.autograd.Function):
 
 def mlp_quickgelu(x, w1, b1, w2):
     """fc2(QuickGELU(fc1(x))) minus fc2's bias; fused GEMM epilogues in bf16, composed kernels otherwise."""
-    if torch.is_autocast_enabled() and x.dtype == torch.float32:
-        x = x.to(torch.get_autocast_dtype('cuda'))
+    x = _act(x)
     rows = x.numel() // x.shape[-1]
     if (x.dtype == torch.bfloat16 and x.is_cuda and b1 is not None and _tn_ok(rows, w1.shape[0], w1.shape[1])
             and _tn_ok(rows, w1.shape[1], w1.shape[0]) and _tn_ok(rows, w2.shape[0], w2.shape[1])
@@ -203,6 +267,28 @@ def linear_wgrad_raw(dy, x, want_dbias: bool, ws_floats: int = -1):
     return dw, db
 
 
+# Tile-counter blocks of the persistent GEMM (lvl_linear_tn `sched`): 16 x uint32, zero on entry, zeroed again by the
+# kernel's last workgroup. One zero-filled pool per (device, stream), handed out round-robin: launches of one stream
+# run in order, so a block is long back to zero when its turn comes again (4096 launches later), and the two towers'
+# streams never share a block. Under hipGraph capture the block is allocated (and zeroed) inside the graph.
+_SCHED_BLOCKS = 4096
+_sched_pools = {}
+DYNAMIC_TILES = os.environ.get('LAVILA_DYNAMIC_TILES', '1') != '0'
+
+
+def sched_block(device):
+    if not DYNAMIC_TILES:
+        return None
+    if torch.cuda.is_current_stream_capturing():
+        return torch.zeros(16, dtype=torch.int32, device=device)
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    pool = _sched_pools.get(key)
+    if pool is None:
+        pool = _sched_pools[key] = [torch.zeros(_SCHED_BLOCKS, 16, dtype=torch.int32, device=device), 0]
+    pool[1] = (pool[1] + 1) % _SCHED_BLOCKS
+    return pool[0][pool[1]]
+
+
 def linear_tn_raw(x, w, bias=None, epilogue=C.EPI_BIAS, aux_in=None):
     """One lvl_linear_tn call on bf16 tensors: y[M,N] = epilogue(x[M,K] . w[N,K]^T).
     Returns y (EPI_BIAS), (y, u) (EPI_BIAS_QUICKGELU) or (y, colsum) (EPI_QUICKGELU_BWD)."""
@@ -217,8 +303,8 @@ def linear_tn_raw(x, w, bias=None, epilogue=C.EPI_BIAS, aux_in=None):
         colsum = torch.empty(N, dtype=torch.float32, device=x.device)
         ws = C.workspace('linear_tn', M, N, x.device)
     C.check(C.lib().lvl_linear_tn(C.ptr(x), C.ptr(w), C.ptr(bias), C.ptr(y), C.ptr(aux_out), C.ptr(aux_in),
-                                  C.ptr(colsum), C.ptr(ws), M, N, K, epilogue, C.LVL_BF16, C.stream_ptr()),
-            'lvl_linear_tn')
+                                  C.ptr(colsum), C.ptr(ws), C.ptr(sched_block(x.device)), M, N, K, epilogue, C.LVL_BF16,
+                                  C.stream_ptr()), 'lvl_linear_tn')
     if epilogue == C.EPI_BIAS_QUICKGELU:
         return y, aux_out
     if epilogue == C.EPI_QUICKGELU_BWD:
@@ -228,10 +314,8 @@ def linear_tn_raw(x, w, bias=None, epilogue=C.EPI_BIAS, aux_in=None):
 
 def linear(x, weight, bias=None):
     """nn.Linear forward with hand-written forward / input-gradient / weight-gradient GEMMs behind it.
-    Activation dtype = x.dtype (the autocast dtype when autocast is on); parameters stay f32 masters."""
-    if torch.is_autocast_enabled() and x.dtype == torch.float32:
-        x = x.to(torch.get_autocast_dtype('cuda'))
-    return _LinearFn.apply(x, weight, bias)
+    Activation dtype = x.dtype (the autocast dtype when autocast is on; fp16 -> bf16); parameters stay masters."""
+    return _LinearFn.apply(_act(x), weight, bias)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -299,7 +383,7 @@ RESIDUAL_F32 = os.environ.get('LAVILA_RESIDUAL_F32', '0') == '1'
 
 def _gemm_input_dtype():
     """dtype a LayerNorm output takes when it feeds GEMMs: the autocast dtype, or None (= leave as is)."""
-    return torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled() else None
+    return autocast_dtype()
 
 
 def _narrow(h):
@@ -309,7 +393,7 @@ def _narrow(h):
 
 def layer_norm(x, weight, bias, eps, stream=False):
     """stream=True: the output IS the residual stream (ln_pre): it keeps the dtype of x."""
-    y = _LayerNormFn.apply(x, weight, bias, eps)
+    y = _LayerNormFn.apply(lowp(x), weight, bias, eps)
     return y if stream else _narrow(y)
 
 
@@ -378,6 +462,7 @@ class _AddLayerNormPassFn(torch.autograd.Function):
 
 def add_layer_norm_pass(res, y, ybias, weight, bias, eps):
     """Returns (res_again, h) with h = LayerNorm(res + y (+ ybias)); use res_again for the next consumer of res."""
+    res = lowp(res)
     if y.dtype != res.dtype:
         y = y.to(res.dtype)
     r, h = _AddLayerNormPassFn.apply(res, y, ybias, weight, bias, eps)
@@ -386,6 +471,7 @@ def add_layer_norm_pass(res, y, ybias, weight, bias, eps):
 
 def add_layer_norm(res, y, ybias, weight, bias, eps, keep_sum=True):
     """Returns (s, h) with s = res + y (+ ybias) and h = LayerNorm(s). With keep_sum=False s is None."""
+    res = lowp(res)
     if y.dtype != res.dtype:
         y = y.to(res.dtype)
     s, h = _AddLayerNormFn.apply(res, y, ybias, weight, bias, eps, keep_sum)
@@ -425,24 +511,28 @@ class _BiasQuickGELUFn(torch.autograd.Function):
 
 def bias_quick_gelu(u, bias=None):
     """(u + bias) * sigmoid(1.702 (u + bias))"""
-    return _BiasQuickGELUFn.apply(u, bias)
+    return _BiasQuickGELUFn.apply(lowp(u), bias)
 
 
 # --------------------------------------------------------------------------------------------------
 # patch gather + token assembly
 # --------------------------------------------------------------------------------------------------
-def patchify(video: torch.Tensor, patch: int, dtype: torch.dtype) -> torch.Tensor:
-    """[B,C,F,H,W] f32 -> [B, F*N, C*P*P] (no gradient w.r.t. pixels: the reference never needs one)."""
+def patchify(video: torch.Tensor, patch: int, dtype: torch.dtype, frame_major: bool = False) -> torch.Tensor:
+    """[B,C,F,H,W] f32 (or, frame_major, [B,F,C,H,W]) -> [B, F*N, C*P*P]; both layouts are read in place (no gradient
+    w.r.t. pixels: the reference never needs one)."""
     video = video.detach()
     if video.dtype != torch.float32:
-        video = video.float()
+        video = video.float()          # fp16 clips of the --use-half eval recipes
     video = video.contiguous()
     C.require_device(video)
-    B, Ch, Fr, H, W = video.shape
+    if frame_major:
+        B, Fr, Ch, H, W = video.shape
+    else:
+        B, Ch, Fr, H, W = video.shape
     N = (H // patch) * (W // patch)
     out = torch.empty(B, Fr * N, Ch * patch * patch, dtype=dtype, device=video.device)
-    C.check(C.lib().lvl_patchify(C.ptr(video), C.ptr(out), B, Ch, Fr, H, W, patch, C.dtype_code(out),
-                                 C.stream_ptr()), 'lvl_patchify')
+    C.check(C.lib().lvl_patchify(C.ptr(video), C.ptr(out), B, Ch, Fr, H, W, patch, int(frame_major),
+                                 C.dtype_code(out), C.stream_ptr()), 'lvl_patchify')
     return out
 
 
@@ -474,7 +564,7 @@ class _EmbedTokensFn(torch.autograd.Function):
 
 
 def embed_tokens(pe, cls_token, pos_embed, temporal_embed, frames, n_per_frame):
-    return _EmbedTokensFn.apply(pe, cls_token, pos_embed, temporal_embed, frames, n_per_frame)
+    return _EmbedTokensFn.apply(lowp(pe), cls_token, pos_embed, temporal_embed, frames, n_per_frame)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -544,7 +634,7 @@ def divided_attention(qkv, frames, n_per_frame, heads, mode, bias=None):
     """mode: 'space' | 'time'. qkv [B,T,3D] -> [B,T,D] (timesformer.py:110-140 between the two Linears).
     bias: see _DividedAttnFn."""
     m = {'space': C.ATTN_SPACE, 'time': C.ATTN_TIME}[mode]
-    return _DividedAttnFn.apply(qkv, bias, frames, n_per_frame, heads, m)
+    return _DividedAttnFn.apply(lowp(qkv), bias, frames, n_per_frame, heads, m)
 
 
 class _CausalAttnFn(torch.autograd.Function):
@@ -581,7 +671,7 @@ class _CausalAttnFn(torch.autograd.Function):
 
 def causal_attention(qkv, heads, bias=None):
     """bias: the in_proj bias that produced qkv (see _DividedAttnFn)."""
-    return _CausalAttnFn.apply(qkv, bias, heads)
+    return _CausalAttnFn.apply(lowp(qkv), bias, heads)
 
 
 # --------------------------------------------------------------------------------------------------

@@ -4,9 +4,12 @@ Mirrors `lavila/models/timesformer.py` of facebookresearch/LaViLa (class names, 
 signatures, forward()/forward_features() signatures, parameter/state_dict names, error behaviour),
 but the execution plan is ours: no rearrange copies, no materialised attention scores, the
 BCTHW->BTCHW permute folded into the patch gather, every residual add fused into the LayerNorm
-that consumes it, bias+QuickGELU fused, and the divided space-time attention core run by
-hand-written HIP kernels through the C ABI (include/lavila_hip.h). Linear layers are plain GEMMs
-(torch -> hipBLASLt). There is no CPU path: forward() on a CPU tensor raises.
+that consumes it, and every Linear layer (qkv, proj, fc1 + bias + QuickGELU, fc2, patch embedding), the
+LayerNorms and the divided space-time attention core run by hand-written HIP kernels through the C ABI
+(include/lavila_hip.h: lvl_linear_tn / lvl_linear_wgrad / lvl_layernorm_* / lvl_divided_attn_*). No call of
+this file reaches a library GEMM in bf16 unless the shape does not tile (ops.warn_once says so). There is
+no CPU path: forward() on a CPU tensor raises. fp16 models / inputs (model.half(), eval_zeroshot.py
+--use-half) compute in bf16 and hand fp16 back.
 """
 from collections import OrderedDict
 from functools import partial
@@ -24,11 +27,20 @@ def to_2tuple(x):
 
 
 def _compute_dtype(weight: torch.Tensor) -> torch.dtype:
-    """Activation dtype of the tower: the autocast dtype when autocast is on (fp16 autocast is remapped to
-    bf16 by the CLIP wrapper), else the dtype of the weights."""
-    if torch.is_autocast_enabled():
-        return torch.get_autocast_dtype('cuda')
-    return weight.dtype
+    """Activation dtype of the tower: the autocast dtype when autocast is on, else the dtype of the weights;
+    fp16 (the reference's AMP dtype, or a model.half()) means bf16 (ops.autocast_dtype / ops.lowp)."""
+    lp = ops.autocast_dtype()
+    if lp is not None:
+        return lp
+    return torch.bfloat16 if weight.dtype == torch.float16 else weight.dtype
+
+
+def _like_caller(out, *given):
+    """fp16 in (parameters or input) -> fp16 out, as nn.Module.half() callers expect (eval_zeroshot.py:212-261)."""
+    if out.dtype == torch.bfloat16 and not torch.is_autocast_enabled() and \
+            any(g is not None and g.dtype == torch.float16 for g in given):
+        return out.to(torch.float16)
+    return out
 
 
 class LayerNorm(nn.Module):
@@ -88,10 +100,10 @@ class Mlp(nn.Module):
     def hidden(self, x):
         if self._fused_act:
             return self.drop(ops.bias_quick_gelu(ops.linear(x, self.fc1.weight), self.fc1.bias))
-        return self.drop(self.act(self.fc1(x)))
+        return self.drop(self.act(ops.linear(x, self.fc1.weight, self.fc1.bias)))
 
     def forward(self, x):
-        return self.drop(self.fc2(self.hidden(x)))
+        return _like_caller(self.drop(ops.linear(self.hidden(x), self.fc2.weight, self.fc2.bias)), x)
 
 
 class VideoPatchEmbed(nn.Module):
@@ -113,17 +125,26 @@ class VideoPatchEmbed(nn.Module):
     def tokens_from_bcthw(self, video):
         """[B,C,F,H,W] -> [B, F*N, D] without the BTCHW copy."""
         assert video.shape[2] <= self.num_frames
+        return self._tokens(video, frame_major=False)
+
+    def tokens_from_btchw(self, video):
+        """[B,F,C,H,W] (what forward_features / forward receive, timesformer.py:79-84,345-348) -> [B, F*N, D]: the
+        gather reads this layout in place as well (no permute().contiguous() round trip of the clip)."""
+        assert video.shape[1] <= self.num_frames
+        return self._tokens(video, frame_major=True)
+
+    def _tokens(self, video, frame_major):
         if self.patch_size[0] != self.patch_size[1]:
             raise NotImplementedError('non-square patches')
         w = self.proj.weight
-        patches = ops.patchify(video, self.patch_size[0], _compute_dtype(w))
+        patches = ops.patchify(video, self.patch_size[0], _compute_dtype(w), frame_major=frame_major)
         return ops.linear(patches, w.reshape(w.shape[0], -1), self.proj.bias)
 
     def forward(self, x):
         """Reference signature: x [B,F,C,H,W] -> [B*F, D, H/P, W/P] (timesformer.py:79-84)."""
         B, Fr, C, H, W = x.shape
         assert Fr <= self.num_frames
-        tok = self.tokens_from_bcthw(x.permute(0, 2, 1, 3, 4))
+        tok = _like_caller(self.tokens_from_btchw(x), x, self.proj.weight)
         gh, gw = H // self.patch_size[0], W // self.patch_size[1]
         return tok.reshape(B * Fr, gh, gw, -1).permute(0, 3, 1, 2)
 
@@ -175,7 +196,7 @@ class VarAttention(nn.Module):
         mode, k = self._mode(einops_to, einops_dims)
         patches = x.shape[1] - 1
         frames, n = (k, patches // k) if mode == 'space' else (patches // k, k)
-        return self.proj(self.core(x, mode, frames, n))
+        return _like_caller(ops.linear(self.core(x, mode, frames, n), self.proj.weight, self.proj.bias), x)
 
 
 class SpaceTimeBlock(nn.Module):
@@ -202,7 +223,10 @@ class SpaceTimeBlock(nn.Module):
         self.attention_style = attention_style
 
     def _dropping(self):
-        return self.training and isinstance(self.drop_path, DropPath) and self.drop_path.drop_prob > 0.
+        """Stochastic depth or MLP dropout live in this training forward: the branches are then materialised (own
+        GEMMs, separate bias / drop passes) instead of riding on the fused chain (timesformer.py:52-58,192-196)."""
+        return self.training and ((isinstance(self.drop_path, DropPath) and self.drop_path.drop_prob > 0.) or
+                                  self.mlp.drop.p > 0.)
 
     def chain(self, res, pend, pend_bias, frames, n_per_frame):
         """One block on the fused residual chain.
@@ -221,7 +245,7 @@ class SpaceTimeBlock(nn.Module):
         ta, sa = self.timeattn, self.attn
         o_t = ta.core(h3, 'time', frames, n_per_frame)
         if hasattr(self, 'alpha_timeattn'):
-            y_t, b_t = torch.tanh(self.alpha_timeattn).to(o_t.dtype) * ta.proj(o_t), None
+            y_t, b_t = torch.tanh(self.alpha_timeattn).to(o_t.dtype) * ops.linear(o_t, ta.proj.weight, ta.proj.bias), None
         else:
             y_t, b_t = ops.linear(o_t, ta.proj.weight), ta.proj.bias
         # t = x + time_out is never stored; x is handed through so that its second use below sends its gradient into
@@ -229,12 +253,12 @@ class SpaceTimeBlock(nn.Module):
         x, h1 = ops.add_layer_norm_pass(x, y_t, b_t, n1.weight, n1.bias, n1.eps)
         o_s = sa.core(h1, 'space', frames, n_per_frame)
         if self._dropping():
-            y_s, b_s = self.drop_path(sa.proj(o_s)), None
+            y_s, b_s = self.drop_path(ops.linear(o_s, sa.proj.weight, sa.proj.bias)), None
         else:
             y_s, b_s = ops.linear(o_s, sa.proj.weight), sa.proj.bias
         x1, h2 = ops.add_layer_norm(x, y_s, b_s, n2.weight, n2.bias, n2.eps, keep_sum=True)
         if self._dropping():
-            return x1, self.drop_path(self.mlp.drop(self.mlp.fc2(self.mlp.hidden(h2)))), None
+            return x1, self.drop_path(self.mlp(h2)), None
         if self.mlp._fused_act:
             return x1, ops.mlp_quickgelu(h2, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight), self.mlp.fc2.bias
         return x1, ops.linear(self.mlp.hidden(h2), self.mlp.fc2.weight), self.mlp.fc2.bias
@@ -247,7 +271,7 @@ class SpaceTimeBlock(nn.Module):
             x1, y, b = checkpoint.checkpoint(self.chain, x, None, None, frames, n, use_reentrant=False)
         else:
             x1, y, b = self.chain(x, None, None, frames, n)
-        return x1 + (y if b is None else y + b.to(y.dtype))
+        return _like_caller(x1 + (y if b is None else y + b.to(y.dtype)), x)
 
 
 class SpaceTimeTransformer(nn.Module):
@@ -280,7 +304,6 @@ class SpaceTimeTransformer(nn.Module):
         self.pos_drop = nn.Dropout(p=drop_rate)
 
         dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth)]
-        self._after_block = None      # transient (index, callable) hook of one forward call; never state
         self.blocks = nn.ModuleList([
             SpaceTimeBlock(dim=embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias,
                            qk_scale=qk_scale, drop=drop_rate, attn_drop=attn_drop_rate, drop_path=dpr[i],
@@ -343,8 +366,10 @@ class SpaceTimeTransformer(nn.Module):
         self._freeze(temporal=True)
 
     # ------------------------------------------------------------------------------------------------
-    def _features_from_tokens(self, tok, frames, use_checkpoint, cls_at_last):
-        """tok: [B, F*N, D] patch-embedded tokens (frame-major)."""
+    def _features_from_tokens(self, tok, frames, use_checkpoint, cls_at_last, after_block=None):
+        """tok: [B, F*N, D] patch-embedded tokens (frame-major). after_block: optional (index, callable), called once
+        after that block has been enqueued (CLIP.forward starts the text tower from there); an argument of this one
+        call, never module state, so concurrent forwards of one or several models cannot see each other's hook."""
         n = self.patches_per_frame
         if tok.shape[1] != frames * n:
             raise ValueError(f'got {tok.shape[1]} patch tokens for {frames} frames; this model was built for '
@@ -356,7 +381,7 @@ class SpaceTimeTransformer(nn.Module):
             x = ops.layer_norm(x, self.ln_pre.weight, self.ln_pre.bias, self.ln_pre.eps, stream=True)
         x = self.pos_drop(x)
         res, pend, pend_b = x, None, None
-        hook = self._after_block          # (index, callable) set by CLIP.forward for one call, see models.py
+        hook = after_block
         for i, blk in enumerate(self.blocks):
             if use_checkpoint:
                 res, pend, pend_b = checkpoint.checkpoint(blk.chain, res, pend, pend_b, frames, n,
@@ -380,13 +405,18 @@ class SpaceTimeTransformer(nn.Module):
         return ops.add_layer_norm(res, pend, pend_b, nm.weight, nm.bias, nm.eps, keep_sum=False)[1]
 
     def forward_features(self, x, use_checkpoint=False, cls_at_last=True):
-        """Reference signature: x is [B, F, C, H, W] (timesformer.py:345-382)."""
+        """Reference signature: x is [B, F, C, H, W] (timesformer.py:345-382; the narrator's entry with
+        cls_at_last=False, narrator.py:74). The gather reads this layout in place."""
+        ops.training_forward_begins()
         b, curr_frames, channels, _, _ = x.shape
-        tok = self.patch_embed.tokens_from_bcthw(x.permute(0, 2, 1, 3, 4))
-        return self._features_from_tokens(tok, curr_frames, use_checkpoint, cls_at_last)
+        tok = self.patch_embed.tokens_from_btchw(x)
+        out = self._features_from_tokens(tok, curr_frames, use_checkpoint, cls_at_last)
+        return _like_caller(out, x, self.cls_token)
 
-    def forward(self, x, use_checkpoint=False):
-        """x: [B, C, T, H, W] (timesformer.py:384-390); the BCTHW->BTCHW copy is folded into the gather."""
+    def forward(self, x, use_checkpoint=False, _after_block=None):
+        """x: [B, C, T, H, W] (timesformer.py:384-390); the BCTHW->BTCHW copy is folded into the gather.
+        `_after_block` is not part of the reference signature (see _features_from_tokens)."""
+        ops.training_forward_begins()
         tok = self.patch_embed.tokens_from_bcthw(x)
-        x = self._features_from_tokens(tok, x.shape[2], use_checkpoint, True)
-        return self.head(x)
+        out = self._features_from_tokens(tok, x.shape[2], use_checkpoint, True, _after_block)
+        return self.head(_like_caller(out, x, self.cls_token))

@@ -180,3 +180,90 @@ def test_drop_in_coexists_with_reference_tree():
         "print('ok')\n" % (ROOT, REFERENCE_ROOT, REFERENCE_ROOT, REFERENCE_ROOT, REFERENCE_ROOT))
     out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and 'ok' in out.stdout, out.stderr[-2000:]
+
+
+@pytest.mark.skipif(not reference_available(), reason='reference only exists in the build container')
+@pytest.mark.parametrize('embed,freeze', [(512, True), (256, False)])
+def test_pretrained_clip_import_matches_reference_constructor(tmp_path, monkeypatch, embed, freeze):
+    """models.py:329-370: the named constructor imports OpenAI-CLIP weights (vision tower through remap_keys with
+    strict=False, text tower / embeddings / ln_final verbatim, the two projections + logit_scale only when
+    project_embed_dim equals CLIP's 512) and optionally freezes what it imported. No network here: a seeded-random
+    `openai_model.CLIP` of the ViT-B/16 shape stands in for the download on BOTH sides -- the reference constructor
+    gets it through a monkey-patched `load_openai_clip`, ours reads the same state_dict from LAVILA_CLIP_WEIGHTS_DIR --
+    and every tensor of the two resulting models must be equal, requires_grad flags included."""
+    import contextlib
+    import io
+    from lavila.models import models
+    from oracle.ref_import import load_reference
+    ref = load_reference()
+    torch.manual_seed(11)
+    with contextlib.redirect_stdout(io.StringIO()):
+        clip = ref.openai_model.CLIP(embed_dim=512, image_resolution=224, vision_layers=12, vision_width=768,
+                                     vision_patch_size=16, context_length=77, vocab_size=49408, transformer_width=512,
+                                     transformer_heads=8, transformer_layers=12)
+    with torch.no_grad():       # make every imported tensor distinguishable from any default initialisation
+        g = torch.Generator().manual_seed(12)
+        for p in clip.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+    torch.save(clip.state_dict(), tmp_path / 'ViT-B-16.pt')
+    monkeypatch.setenv('LAVILA_CLIP_WEIGHTS_DIR', str(tmp_path))
+    monkeypatch.setattr(ref.models, 'load_openai_clip', lambda name, device='cpu': (clip, None))
+    kw = dict(num_frames=4, timesformer_freeze_space=freeze, project_embed_dim=embed, temperature_init=0.07)
+    with contextlib.redirect_stdout(io.StringIO()):
+        theirs = ref.models.CLIP_OPENAI_TIMESFORMER_BASE(**kw)
+        ours = models.CLIP_OPENAI_TIMESFORMER_BASE(**kw)
+    a, b = ours.state_dict(), theirs.state_dict()
+    assert list(a) == list(b)
+    random_init = set() if embed == 512 else {'image_projection', 'text_projection'}    # normal_() draws, not imports
+    for k in a:
+        if k in random_init:
+            assert a[k].shape == b[k].shape
+            continue
+        assert torch.equal(a[k], b[k]), k
+    if embed == 512:
+        assert torch.equal(a['logit_scale'], clip.logit_scale.data) and torch.equal(a['image_projection'], clip.visual.proj.data)
+    else:
+        assert abs(float(a['logit_scale']) - float(torch.log(torch.tensor(1 / 0.07)))) < 1e-6
+    assert torch.equal(a['visual.blocks.3.attn.qkv.weight'], clip.visual.transformer.resblocks[3].attn.in_proj_weight.data)
+    assert torch.equal(a['transformer.resblocks.5.mlp.c_fc.weight'], clip.transformer.resblocks[5].mlp.c_fc.weight.data)
+    flags_a = {k: p.requires_grad for k, p in ours.named_parameters()}
+    flags_b = {k: p.requires_grad for k, p in theirs.named_parameters()}
+    assert flags_a == flags_b
+    if freeze:
+        assert not flags_a['visual.blocks.0.attn.qkv.weight'] and flags_a['visual.blocks.0.timeattn.qkv.weight'] \
+            and flags_a['visual.cls_token'] and flags_a['visual.temporal_embed']
+    # a missing file is an error, as in the reference (openai_clip.py:128)
+    monkeypatch.setenv('LAVILA_CLIP_WEIGHTS_DIR', str(tmp_path / 'nowhere'))
+    with pytest.raises(RuntimeError):
+        with contextlib.redirect_stdout(io.StringIO()):
+            models.CLIP_OPENAI_TIMESFORMER_BASE(num_frames=4)
+
+
+def test_weight_cache_sees_out_of_band_parameter_writes():
+    """`param.data` writes (ZeroRedundancyOptimizer's shard broadcast, bucket views) do not bump the
+    version counter the bf16 weight-copy cache keys on. The cache generation -- bumped by every optimizer step (global
+    post-step hook) and by every grad-enabled model forward -- makes them visible. fp16 weights take the torch cast
+    path, so the cache logic itself runs without a GPU."""
+    from lavila_amd import ops
+    p = torch.nn.Parameter(torch.randn(8, 4).half())
+    w0, wt0 = ops.weight_copies(p)
+    assert ops.weight_copies(p)[0] is w0                          # cached
+    p.data.add_(1.0)                                              # out-of-band write: version unchanged
+    assert ops.weight_copies(p)[0] is w0                          # ... which is exactly the hazard
+    torch.optim.SGD([p], lr=0.0).step()                           # any optimizer step invalidates
+    w1, wt1 = ops.weight_copies(p)
+    assert w1 is not w0 and torch.equal(w1.float(), p.detach().to(torch.bfloat16).float())
+    assert torch.equal(wt1, w1.t())
+    p.data.add_(1.0)
+    with torch.no_grad():
+        ops.training_forward_begins()                             # inference forwards keep the cache
+    assert ops.weight_copies(p)[0] is w1
+    ops.training_forward_begins()                                 # a training forward re-casts
+    w2 = ops.weight_copies(p)[0]
+    assert w2 is not w1 and torch.equal(w2.float(), p.detach().to(torch.bfloat16).float())
+    p.data.add_(1.0)
+    ops.invalidate_weight_cache()                                 # the explicit entry point
+    assert torch.equal(ops.weight_copies(p)[0].float(), p.detach().to(torch.bfloat16).float())
+    with torch.no_grad():
+        p.add_(1.0)                                               # in-band write: the version counter alone suffices
+    assert torch.equal(ops.weight_copies(p)[0].float(), p.detach().to(torch.bfloat16).float())

@@ -121,3 +121,99 @@ def test_ddp_two_ranks_on_one_device_match_global_oracle_gradient():
             torch.testing.assert_close(g, wo[k].grad.reshape(g.shape), atol=2e-5, rtol=2e-3, msg=lambda m, k=k: f'{k}: {m}')
     for k in got[0][2]:                       # DDP: identical on both ranks
         assert got[0][2][k] == got[1][2][k], k
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# ZeroRedundancyOptimizer writes the parameters it does not own through `param.data` (broadcast of the
+# updated shards) -- invisible to the tensor version counter. The forward AFTER such a step must run on the new weights.
+CFG_MFMA = dict(img=32, patch=16, frames=2, dim=256, depth=2, heads=4, t_width=256, t_heads=4, t_layers=2, vocab=512,
+                embed=64, batch=3, gated=False)        # widths the MFMA GEMMs tile: the bf16 weight-copy cache is live
+
+
+def _zero_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    import torch.distributed as dist
+    from torch.distributed.optim import ZeroRedundancyOptimizer
+    from helpers import build_model
+    from lavila.models.loss import CLIPLoss
+    from lavila_amd import ops
+    from oracle import oracle as O
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    c = CFG_MFMA
+    model = build_model(c)
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict(O.procedural_weights(shapes, seed=3))
+    model.cuda().train()
+    ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], gradient_as_bucket_view=True)
+    crit = CLIPLoss(use_vissl=True, cache_labels=True, rank=rank, world_size=world)
+    video, tokens = O.synthetic_batch(world * c['batch'], c['frames'], c['img'], seed=21)
+    tokens = tokens.clone()
+    tokens[:, 1:31] = tokens[:, 1:31] % 510 + 1
+    tokens[:, 0], tokens[:, 31] = 510, 511
+    sl = slice(rank * c['batch'], (rank + 1) * c['batch'])
+    v, t = video[sl].cuda(), tokens[sl].cuda()
+    used = []
+    real = ops.linear_tn_raw
+    ops.linear_tn_raw = lambda *a, **k: (used.append(1), real(*a, **k))[1]
+
+    def fwd(train):
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            if train:
+                return crit(ddp(v, t, norm_embed=True))['loss']
+            with torch.no_grad():                        # the eval pass after each epoch (main_pretrain.py:365-384)
+                out = model(v, t, norm_embed=True)
+                return crit(out)['loss']
+    fwd(True).backward()
+    assert used, 'the MFMA GEMMs (and with them the weight-copy cache) must be on this path'
+    kw = dict(lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    before = {k: p.detach().clone() for k, p in model.named_parameters()}
+    grads = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    zero = ZeroRedundancyOptimizer(model.parameters(), optimizer_class=torch.optim.AdamW, **kw)
+    zero.step()
+    loss_zero_eval = fwd(False).item()                   # inference forward right after the sharded step
+    loss_zero = fwd(True).item()                         # next training forward
+    for k, p in model.named_parameters():                # rewind (out-of-band on purpose), plain AdamW on the same grads
+        p.data.copy_(before[k])
+        p.grad = grads[k]
+    torch.optim.AdamW(model.parameters(), **kw).step()
+    loss_plain_eval = fwd(False).item()
+    loss_plain = fwd(True).item()
+    for k, p in model.named_parameters():
+        p.data.copy_(before[k])
+    ops.invalidate_weight_cache()
+    loss_before = fwd(False).item()
+    q.put((rank, loss_zero, loss_plain, loss_zero_eval, loss_plain_eval, loss_before))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_zero_step_then_forward_runs_on_the_updated_weights():
+    import queue
+    import socket
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    procs = [ctx.Process(target=_zero_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got, deadline = [], time.time() + 600
+    while len(got) < world:
+        try:
+            got.append(q.get(timeout=2))
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            assert not dead, f'worker exited with {dead}'
+            assert time.time() < deadline, 'workers timed out'
+    for p in procs:
+        p.join(timeout=120)
+    for rank, lz, lp, lze, lpe, lb in got:
+        assert abs(lz - lp) < 1e-5 and abs(lze - lpe) < 1e-5, (rank, lz, lp, lze, lpe)   # ZeRO == AdamW, next forward
+        assert abs(lp - lb) > 1e-3, (lp, lb)              # ... and the step did move the loss (lr 1e-2): not vacuous
+    assert got[0][1] == got[1][1]                         # both ranks: the same global loss

@@ -9,7 +9,7 @@ import threading
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-so = os.path.join(ROOT, 'lavila_amd', 'lib', 'libspin_probe.so')
+so = os.path.join(ROOT, 'tools', 'probes', 'libspin_probe.so')      # probe code stays out of the product lib dir
 if '--build' in sys.argv:
     subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-fPIC', '-shared', '-w',
                            os.path.join(ROOT, 'tools', 'probes', 'spin.hip'), '-o', so])
