@@ -34,6 +34,11 @@ enum { LVL_EPI_BIAS = 0, LVL_EPI_BIAS_QUICKGELU = 1, LVL_EPI_QUICKGELU_BWD = 2 }
 
 /* library identification / diagnostics (host pointers) */
 const char* lvl_version(void);
+/* Test hook for the dynamic schedules of lvl_linear_tn / lvl_linear_wgrad (`sched` != NULL): from now on the workgroups
+ * with blockIdx % mod == 1 of every such launch behave as if their compute unit had been held by another kernel for
+ * the whole launch -- they start, find nothing left to do and sign off -- so that the take-over paths (tile queue /
+ * chunk stealing) can be exercised deterministically on an idle GPU. mod = 0 switches it off. Results must not change. */
+int lvl_debug_late_workgroups(int mod);
 /* Compute units the two persistent GEMM kernels (lvl_linear_tn, lvl_linear_wgrad: one workgroup per CU holding the
  * whole register file) size their grids for. 0 (default) = every CU of the device; a multiple of 8 below that leaves
  * the remaining CUs to whatever runs beside the step (e.g. the channel workgroups of an RCCL collective), which
@@ -196,9 +201,15 @@ int lvl_linear_tn(const void* x, const void* w, const float* bias, void* y, void
  * and bias of every nn.Linear on the path (qkv/proj: timesformer.py:96-99, Mlp fc1/fc2: timesformer.py:47-50) when
  * `loss.backward()` runs (main_pretrain.py:520). dy: [M,N], x: [M,K] bf16 row-major; dw: [N,K] f32; dbias: [N] f32.
  * Tiled for N, K multiples of 192/288/384 (TSF-B/L widths); other shapes return LVL_ENOSYS and the caller keeps
- * the library GEMM. Workspace: lvl_workspace_floats("linear_wgrad", N, K) floats (-1 = unsupported shape). */
-int lvl_linear_wgrad(const void* dy, const void* x, float* dw, float* dbias, float* ws, int64_t M, int N, int K,
-                     int dtype, void* stream);
+ * the library GEMM. Workspace: lvl_workspace_floats("linear_wgrad", N, K) floats (-1 = unsupported shape).
+ * sched (nullable): CHUNK-COUNTER block of the launch, 1024 x uint32 (64-byte aligned), ZERO on entry, zero again when
+ * the launch has drained (same reuse rule as lvl_linear_tn's block). With it every (tile, row split) unit is cut into
+ * row chunks handed out by device counters: a workgroup works through its own unit and then takes unclaimed chunks of
+ * the other splits of its tile, so a compute unit held by another kernel delays the launch by a fraction of a unit
+ * instead of a second round. With all CUs available nobody steals and the result is bit-identical to the static plan
+ * (NULL). */
+int lvl_linear_wgrad(const void* dy, const void* x, float* dw, float* dbias, float* ws, uint32_t* sched, int64_t M,
+                     int N, int K, int dtype, void* stream);
 
 /* ---- bias gradient of the qkv Linear that feeds an attention core ------------------------------------------------
  * dbias[3D] = column sums over all rows of the dqkv an attention backward produced (what autograd computes for

@@ -23,6 +23,7 @@ _P, _I, _L, _F = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float
 SIGNATURES = {
     'lvl_version': (_c.c_char_p, []),
     'lvl_set_compute_units': (_I, [_I]),
+    'lvl_debug_late_workgroups': (_I, [_I]),
     'lvl_last_error': (_c.c_char_p, []),
     'lvl_workspace_floats': (_L, [_c.c_char_p, _L, _L]),
     'lvl_layernorm_fwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P]),
@@ -41,7 +42,7 @@ SIGNATURES = {
     'lvl_ssl_clip_loss_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _P]),
     'lvl_ssl_clip_loss_bwd': (_I, [_P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _P, _P, _I, _P]),
     'lvl_linear_tn': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
-    'lvl_linear_wgrad': (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _P]),
+    'lvl_linear_wgrad': (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P]),
     'lvl_cast_transpose': (_I, [_P, _P, _P, _I, _I, _P]),
     'lvl_qkv_bias_grad': (_I, [_P, _P, _P, _P, _L, _I, _I, _P]),
 }

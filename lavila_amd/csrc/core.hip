@@ -42,6 +42,16 @@ extern "C" int lvl_set_compute_units(int n) {
   return LVL_OK;
 }
 
+// Test hook of the dynamic schedules: workgroups with blockIdx % mod == 1 act as if their compute unit had been held by
+// another kernel for the whole launch (0 = off).
+static std::atomic<int> g_late_mod{0};
+int lvl_debug_late_mod() { return g_late_mod.load(std::memory_order_relaxed); }
+extern "C" int lvl_debug_late_workgroups(int mod) {
+  if (mod < 0 || mod == 1) return lvl_fail(LVL_EINVAL, "debug_late_workgroups: mod must be 0 or >= 2");
+  g_late_mod.store(mod, std::memory_order_relaxed);
+  return LVL_OK;
+}
+
 extern "C" const char* lvl_version(void) { return "lavila_hip 0.1 (gfx950)"; }
 extern "C" const char* lvl_last_error(void) { return lvl_err_buf; }
 

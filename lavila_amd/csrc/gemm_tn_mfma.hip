@@ -53,6 +53,8 @@
 
 #include "common.h"
 
+int lvl_debug_late_mod();
+
 // the LDS-DMA fills set M0 inside inline asm and say so in the clobber list; this kernel has no other M0 user
 #pragma clang diagnostic ignored "-Winline-asm"
 
@@ -100,7 +102,8 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
                                                       uint16_t* __restrict__ aux_out,
                                                       const uint16_t* __restrict__ aux_in,
                                                       float* __restrict__ colpart, int64_t M, int N, int K,
-                                                      int tiles_n, int ntiles, unsigned* __restrict__ sched) {
+                                                      int tiles_n, int ntiles, unsigned* __restrict__ sched,
+                                                      int late_mod) {
   extern __shared__ __attribute__((aligned(1024))) uint8_t smem[];      // [NSLOT][128 rows][128 B]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -143,7 +146,9 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
   auto mailbox = [&]() -> int {
     return __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(smem + MBOX_OFF));
   };
-  if (dyn) {
+  if (dyn && late_mod > 0 && bid % late_mod == 1) {
+    my_tiles = 0;                               // test hook (lvl_debug_late_workgroups): as if the queues were drained
+  } else if (dyn) {
     // first tile: the one synchronous hand-out (nothing is in flight yet, ~1 us once per launch)
     pull();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -600,7 +605,7 @@ int launch_tn(const void* x, const void* w, const float* bias, void* y, void* au
   if (K / BK < DYN_MIN_NB) sched = nullptr; // too few K blocks per tile for the counter hand-off: static schedule
   hipLaunchKernelGGL((gemm_tn_kernel<EPI>), dim3((unsigned)grid), dim3(512), shmem, st, (const uint16_t*)x,
                      (const uint16_t*)w, bias, (uint16_t*)y, (uint16_t*)aux_out, (const uint16_t*)aux_in, colpart, M,
-                     N, K, tiles_n, (int)ntiles, sched);
+                     N, K, tiles_n, (int)ntiles, sched, sched ? lvl_debug_late_mod() : 0);
   LVL_CHECK_LAUNCH("linear_tn");
   return LVL_OK;
 }

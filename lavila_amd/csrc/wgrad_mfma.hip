@@ -20,7 +20,19 @@
 //     v_mfma_f32_16x16x32_bf16 operand. A and B use the same row permutation, so no data is ever transposed;
 //   * dbias rides along: v_dot2_f32_bf16 of the A fragments with (1,1).
 // Partial tiles [S,N,K] f32 are reduced by wgrad_reduce_kernel (deterministic, no atomics).
+//
+// Robustness against a taken compute unit (`sched`, optional): every (tile, split) unit is cut into C row CHUNKS that
+// are handed out by a per-unit device counter. A workgroup claims the chunks of ITS OWN unit first -- one returning
+// atomic per chunk boundary; while the replies are consecutive the row stream and the fragment pipeline run on across
+// the boundary -- and when its unit is exhausted it takes unclaimed chunks of the other splits of the SAME tile into its own accumulators
+// (its partial slab then simply holds more rows; the slab sum is unchanged). A workgroup whose CU is held by another
+// kernel (an RCCL channel) therefore delays the launch by its tile-mates' share of its rows, not by a second round of
+// the whole kernel; when it finally starts it finds its chunks gone and writes a zero slab. With every CU available
+// nobody steals: each slab holds exactly the rows of the static plan, in the same order -- results are bit-identical
+// to the static schedule and run-to-run deterministic.
 #include "common.h"
+
+int lvl_debug_late_mod();
 
 // the LDS-DMA fills set M0 inside inline asm and say so in the clobber list; this kernel has no other M0 user
 #pragma clang diagnostic ignored "-Winline-asm"
@@ -43,6 +55,11 @@ __device__ __forceinline__ wg_f32x4 mfma16(uint4 a, uint4 b, wg_f32x4 c) {
                                                  c, 0, 0, 0);
 }
 
+// Row plan of a launch (host-computed, no divisions in the kernel): the M/32 full row blocks are dealt to the S splits
+// as `base` blocks each, the first `rem` splits one more; the dynamic schedule cuts a unit into chunks of L blocks
+// (L even), nch0 / nch1 of them for a unit of base / base + 1 blocks.
+struct RowPlan { int base, rem, L, nch0, nch1, late_mod; };
+
 template <int WN, int WK, int TA, int TB>
 struct Geo {
   static constexpr int NW = WN * WK, NT = 64 * NW;
@@ -61,7 +78,8 @@ template <int WN, int WK, int TA, int TB, bool BIAS>
 __global__ __launch_bounds__(64 * WN * WK) void wgrad_kernel(const uint16_t* __restrict__ dy,
                                                              const uint16_t* __restrict__ x, float* __restrict__ part,
                                                              float* __restrict__ bpart, int64_t M, int N, int K,
-                                                             int tiles_k, int ntiles, int S) {
+                                                             int tiles_k, int ntiles, int S, RowPlan rp,
+                                                             unsigned* __restrict__ sched) {
   using G = Geo<WN, WK, TA, TB>;
   static_assert(TA % 2 == 0, "the mid-step barrier splits the A tiles in two halves");
   extern __shared__ __attribute__((aligned(16))) uint16_t smem[];     // [NSTAGE][A image | B image | dump]
@@ -75,8 +93,9 @@ __global__ __launch_bounds__(64 * WN * WK) void wgrad_kernel(const uint16_t* __r
   const int split = pair / ntiles, tile = pair % ntiles;
   const int n0 = (tile / tiles_k) * G::TN, k0 = (tile % tiles_k) * G::TK;
   const int64_t steps_total = M / MS;      // full row blocks; the < 32 tail rows are added by wgrad_reduce_kernel
-  const int64_t s_begin = steps_total * split / S, s_end = steps_total * (split + 1) / S;
-  const int nsteps = (int)(s_end - s_begin);
+  // (the dbias instantiations keep the static plan: they are not on the training path -- the bias gradients come from
+  // the LayerNorm / GEMM epilogues -- and their register budget leaves no room for the claim state)
+  const bool dyn = !BIAS && sched != nullptr;
 
   // ---- staging plan (LDS-DMA, no VGPR round trip) ---------------------------------------------------------------
   // Fill f (0 .. NI*NW-1) of a step is issued by wave f % NW; lane l of the fill lands at stage byte f*1024 + l*16.
@@ -86,27 +105,30 @@ __global__ __launch_bounds__(64 * WN * WK) void wgrad_kernel(const uint16_t* __r
   const uint16_t* src[G::NI];
   int64_t src_step[G::NI];
   int dst_off[G::NI];             // element offset of the fill inside a stage (wave-uniform)
+  // point the fill sources at row block `rb` (the first step of a stream)
+  auto set_sources = [&](int64_t rb) {
 #pragma unroll
-  for (int q = 0; q < G::NI; ++q) {
-    const int f = wave + q * G::NW;
-    dst_off[q] = f * 512;
-    const int chunk = f * 64 + lane;
-    if (f < G::IA) {
-      const int row = chunk / (G::SA / 8), c8 = chunk % (G::SA / 8);
-      src[q] = dy + (s_begin * MS + row) * (int64_t)N + n0 + (c8 < G::TN / 8 ? c8 : 0) * 8;
-      src_step[q] = (int64_t)MS * N;
-    } else {
-      const int cb = f < G::IA + G::IB ? chunk - G::IA * 64 : lane;
-      const int row = cb / (G::SB / 8), c8 = cb % (G::SB / 8);
-      src[q] = x + (s_begin * MS + row) * (int64_t)K + k0 + (c8 < G::TK / 8 ? c8 : 0) * 8;
-      src_step[q] = (int64_t)MS * K;
+    for (int q = 0; q < G::NI; ++q) {
+      const int f = wave + q * G::NW;
+      dst_off[q] = f * 512;
+      const int chunk = f * 64 + lane;
+      if (f < G::IA) {
+        const int row = chunk / (G::SA / 8), c8 = chunk % (G::SA / 8);
+        src[q] = dy + (rb * MS + row) * (int64_t)N + n0 + (c8 < G::TN / 8 ? c8 : 0) * 8;
+        src_step[q] = (int64_t)MS * N;
+      } else {
+        const int cb = f < G::IA + G::IB ? chunk - G::IA * 64 : lane;
+        const int row = cb / (G::SB / 8), c8 = cb % (G::SB / 8);
+        src[q] = x + (rb * MS + row) * (int64_t)K + k0 + (c8 < G::TK / 8 ? c8 : 0) * 8;
+        src_step[q] = (int64_t)MS * K;
+      }
     }
-  }
+  };
   // Fills are issued through inline asm: the compiler's LDS-DMA alias tracking would otherwise put s_waitcnt
   // vmcnt(0) in front of every LDS read and drain the run-ahead fills. Steps at or beyond `last_step` (run-ahead
   // past the end of the matrix) re-read the last full row block.
-  const int last_step = (int)(steps_total - 1 - s_begin);
-  int issued = 0;                 // steps issued so far; src[] points at step min(issued, last_step)
+  int last_step = 0;              // steps_total - 1 - (first row block of the stream)
+  int issued = 0;                 // steps issued so far in this stream; src[] points at step min(issued, last_step)
   auto issue_loads = [&](int stage) {
     const uint32_t lds_base = (uint32_t)(uintptr_t)(smem + stage * G::STAGE) ;
 #pragma unroll
@@ -116,6 +138,41 @@ __global__ __launch_bounds__(64 * WN * WK) void wgrad_kernel(const uint16_t* __r
       if (issued < last_step) src[q] += src_step[q];
     }
     ++issued;
+  };
+
+  // ---- chunk claims (dynamic schedule only) ---------------------------------------------------------------------
+  // A claim is ONE asm block on wave 0, lane 0 (EXEC narrowed inside it): returning atomic add -> s_waitcnt vmcnt(0) ->
+  // ds_write of the reply into the mailbox. The reply never lives in a compiler-visible register across the wait (a
+  // parked reply would be at the mercy of live-range splitting). The wait also drains this wave's run-ahead fills,
+  // about 1 us once per chunk of >= 24 steps: < 1 % of the kernel. The mailbox is the 32 pad bytes behind row 0 of a
+  // stage's dY image: never read by a fragment load, rewritten (with don't-care data) only by that stage's next fill.
+  auto mbox_addr = [&](int stage) { return (uint32_t)(uintptr_t)(smem + stage * G::STAGE + G::TN); };
+  uint64_t exec_save;
+  uint32_t reply;
+  auto claim = [&](unsigned* ctr, int stage) {          // mailbox <- old value of *ctr; *ctr += 1
+    if (wave == 0)
+      asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add %0, %2, %3, %4 sc0\n\t"
+                   "s_waitcnt vmcnt(0)\n\tds_write_b32 %5, %0\n\ts_mov_b64 exec, %1"
+                   : "=&v"(reply), "=&s"(exec_save) : "v"(0u), "v"(1u), "s"(ctr), "v"(mbox_addr(stage)) : "memory");
+  };
+  auto peek = [&](unsigned* ctr, int stage) {           // mailbox <- *ctr (agent-scope load)
+    if (wave == 0)
+      asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tglobal_load_dword %0, %2, %3 sc1\n\t"
+                   "s_waitcnt vmcnt(0)\n\tds_write_b32 %4, %0\n\ts_mov_b64 exec, %1"
+                   : "=&v"(reply), "=&s"(exec_save) : "v"(0u), "s"(ctr), "v"(mbox_addr(stage)) : "memory");
+  };
+  auto count_one = [&](unsigned* ctr) {                 // fire-and-forget atomic add of 1
+    if (wave == 0)
+      asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add %1, %2, %3\n\ts_mov_b64 exec, %0"
+                   : "=&s"(exec_save) : "v"(0u), "v"(1u), "s"(ctr) : "memory");
+  };
+  // mailbox -> every wave; two barriers: write -> read, read -> anything that may overwrite the mailbox
+  auto collect = [&](int stage) -> int {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const int v = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(smem + stage * G::STAGE + G::TN));
+    __builtin_amdgcn_s_barrier();
+    return v;
   };
 
   // ---- per-lane fragment offsets -----------------------------------------------------------------------------
@@ -165,16 +222,6 @@ __global__ __launch_bounds__(64 * WN * WK) void wgrad_kernel(const uint16_t* __r
     }
   };
   uint4 bf[TB], bf_next[TB], af_next;
-  if (nsteps > 0) {
-    issue_loads(0);
-    issue_loads(1);
-    issue_loads(2);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G::NI) : "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    read_b(smem, bf);
-    af_next = read_a(smem, 0);
-  }
   int stage = 0;
   // one step; `cur` holds this step's B fragments, `nxt` receives the next step's (ping-pong: no register copies)
   auto do_step = [&](uint4 (&cur)[TB], uint4 (&nxt)[TB]) {
@@ -204,14 +251,74 @@ __global__ __launch_bounds__(64 * WN * WK) void wgrad_kernel(const uint16_t* __r
     }
     stage = nstage;
   };
-  int step = 0;
-  for (; step + 1 < nsteps; step += 2) {
-    do_step(bf, bf_next);
-    do_step(bf_next, bf);
-  }
-  if (step < nsteps) do_step(bf, bf_next);
 
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the run-ahead fills before this workgroup's LDS is freed
+  // Units visited: the own (tile, split) first, then -- dynamic schedule only -- the other splits of the same tile.
+  unsigned* const taken = dyn ? sched + ntiles * S + tile : nullptr;      // chunks of this tile consumed so far
+  // (test hook, lvl_debug_late_workgroups: a "late" workgroup visits nothing and writes a zero slab)
+  const int visits = dyn ? ((rp.late_mod > 0 && bid % rp.late_mod == 1) ? 0 : S) : 1;
+  for (int d = 0; d < visits; ++d) {
+    int sp = split + d;
+    if (sp >= S) sp -= S;
+    const int ulen = rp.base + (sp < rp.rem ? 1 : 0);                               // row blocks of the unit
+    const int64_t ub = (int64_t)sp * rp.base + (sp < rp.rem ? sp : rp.rem), ue = ub + ulen;
+    int L = ulen, nchunks = ulen > 0 ? 1 : 0, cur = 0;
+    unsigned* uctr = nullptr;
+    if (dyn) {
+      L = rp.L;      // even: the fragment ping-pong is back in phase at every boundary the stream may run across
+      nchunks = sp < rp.rem ? rp.nch1 : rp.nch0;
+      uctr = sched + sp * ntiles + tile;
+      if (d > 0) {
+        // steal only if the tile still has unconsumed chunks (one load; stale by at most the claims in flight)
+        const int total = rp.rem * rp.nch1 + (S - rp.rem) * rp.nch0;
+        peek(taken, 0);
+        if (collect(0) >= total) break;
+      }
+      claim(uctr, 0);
+      cur = collect(0);
+    }
+    while (cur < nchunks) {
+      // ---- one stream: chunk `cur` and, while the claims keep returning the next index, the chunks behind it ----
+      if (dyn) count_one(taken);
+      int64_t pos = ub + (int64_t)cur * L;
+      set_sources(pos);
+      last_step = (int)(steps_total - 1 - pos);
+      issued = 0;
+      stage = 0;
+      issue_loads(0);
+      issue_loads(1);
+      issue_loads(2);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * G::NI) : "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      read_b(smem, bf);
+      af_next = read_a(smem, 0);
+      int next = nchunks;            // where the next stream of this unit starts (>= nchunks: none)
+      for (;;) {
+        const int len = (int)(ue - pos < L ? ue - pos : L);
+        const bool more = dyn && cur + 1 < nchunks;
+        int step = 0;
+        for (; step + 1 < len; step += 2) {
+          do_step(bf, bf_next);
+          do_step(bf_next, bf);
+        }
+        if (step < len) do_step(bf, bf_next);          // odd length: only a unit's last chunk
+        if (!more) break;
+        // every wave has finished the step that used stage `done`: its pad is free until the next step refills it
+        const int done = stage == 0 ? G::NSTAGE - 1 : stage - 1;
+        claim(uctr, done);
+        next = collect(done);
+        if (next != cur + 1 || (len & 1)) break;       // a tile-mate took chunks of this unit: stop, restart at `next`
+        count_one(taken);
+        cur = next;
+        next = nchunks;
+        pos += L;
+      }
+      // the run-ahead fills must have landed (and everybody must be done reading) before the stages are reused
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      cur = next;
+    }
+  }
 
   // ---- epilogue: partial tile of this split -------------------------------------------------------------------
   float* out = part + ((size_t)split * N + n0 + wn * (16 * TA)) * K + k0 + wk * (16 * TB);
@@ -231,6 +338,16 @@ __global__ __launch_bounds__(64 * WN * WK) void wgrad_kernel(const uint16_t* __r
         if (g == 0) bpart[(size_t)split * N + n0 + wn * (16 * TA) + i * 16 + mm] = b;
       }
     }
+  }
+  if (dyn && wave == 0) {
+    // sign-off: this workgroup's counter traffic is complete (every stream ended with vmcnt(0)); the last workgroup
+    // out leaves the counter block zeroed for the next launch that is handed the same block
+    const int nctr = ntiles * S + ntiles;          // unit counters | per-tile consumed counts | [nctr] = sign-offs
+    unsigned gone = 0;
+    if (lane == 0) gone = __hip_atomic_fetch_add(sched + nctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    gone = __builtin_amdgcn_readfirstlane(gone);
+    if (gone == gridDim.x - 1)
+      for (int q = lane; q <= nctr; q += 64) __hip_atomic_store(sched + q, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -313,20 +430,37 @@ Plan make_plan(int N, int K) {
   return best;
 }
 
+// chunks per (tile, split) unit of the dynamic schedule: at least ~48 steps (1536 rows, ~30 us) each, at most 4
+RowPlan row_plan(int64_t M, int S) {
+  const int64_t steps = M / MS;
+  RowPlan rp;
+  rp.base = (int)(steps / S);
+  rp.rem = (int)(steps % S);
+  int c = rp.base / 48;
+  c = c < 1 ? 1 : (c > 4 ? 4 : c);
+  rp.L = ((rp.base + 1 + c - 1) / c + 1) & ~1;
+  if (rp.L < 2) rp.L = 2;
+  rp.nch0 = (rp.base + rp.L - 1) / rp.L;
+  rp.nch1 = (rp.base + 1 + rp.L - 1) / rp.L;
+  rp.late_mod = lvl_debug_late_mod();
+  return rp;
+}
+
 template <int WN, int WK, int TA, int TB>
 int launch(const Plan& p, const void* dy, const void* x, float* part, float* bpart, int64_t M, int N, int K,
-           hipStream_t st) {
+           unsigned* sched, hipStream_t st) {
+  const RowPlan rp = row_plan(M, p.S);
   using G = Geo<WN, WK, TA, TB>;
   const size_t shmem = (size_t)G::NSTAGE * G::STAGE * sizeof(uint16_t);
   const dim3 grid((unsigned)(p.ntiles * p.S)), block(G::NT);
   if (bpart != nullptr) {
     if (int rc = lvl_allow_lds<wgrad_kernel<WN, WK, TA, TB, true>>()) return rc;
     hipLaunchKernelGGL((wgrad_kernel<WN, WK, TA, TB, true>), grid, block, shmem, st, (const uint16_t*)dy,
-                       (const uint16_t*)x, part, bpart, M, N, K, p.tiles_k, p.ntiles, p.S);
+                       (const uint16_t*)x, part, bpart, M, N, K, p.tiles_k, p.ntiles, p.S, rp, sched);
   } else {
     if (int rc = lvl_allow_lds<wgrad_kernel<WN, WK, TA, TB, false>>()) return rc;
     hipLaunchKernelGGL((wgrad_kernel<WN, WK, TA, TB, false>), grid, block, shmem, st, (const uint16_t*)dy,
-                       (const uint16_t*)x, part, bpart, M, N, K, p.tiles_k, p.ntiles, p.S);
+                       (const uint16_t*)x, part, bpart, M, N, K, p.tiles_k, p.ntiles, p.S, rp, sched);
   }
   LVL_CHECK_LAUNCH("linear_wgrad");
   return LVL_OK;
@@ -340,8 +474,8 @@ int64_t lvl_wgrad_workspace_floats(int64_t N, int64_t K) {
   return (int64_t)p.S * N * K + (int64_t)p.S * N;
 }
 
-extern "C" int lvl_linear_wgrad(const void* dy, const void* x, float* dw, float* dbias, float* ws, int64_t M, int N,
-                                int K, int dtype, void* stream) {
+extern "C" int lvl_linear_wgrad(const void* dy, const void* x, float* dw, float* dbias, float* ws, uint32_t* sched,
+                                int64_t M, int N, int K, int dtype, void* stream) {
   LVL_REQUIRE(dy && x && dw && ws, "linear_wgrad: null pointer");
   LVL_REQUIRE(dtype == LVL_BF16, "linear_wgrad: bf16 operands only (dtype=%d)", dtype);
   LVL_REQUIRE(M > 0 && N > 0 && K > 0, "linear_wgrad: empty problem");
@@ -354,14 +488,14 @@ extern "C" int lvl_linear_wgrad(const void* dy, const void* x, float* dw, float*
   float* bpart = dbias ? ws + (size_t)p.S * N * K : nullptr;
   int rc = LVL_OK;
   switch (p.cfg) {
-    case 0: rc = launch<4, 2, 6, 6>(p, dy, x, part, bpart, M, N, K, st); break;
-    case 1: rc = launch<2, 4, 6, 6>(p, dy, x, part, bpart, M, N, K, st); break;
-    case 2: rc = launch<3, 2, 6, 6>(p, dy, x, part, bpart, M, N, K, st); break;
-    case 3: rc = launch<2, 3, 6, 6>(p, dy, x, part, bpart, M, N, K, st); break;
-    case 4: rc = launch<2, 2, 6, 6>(p, dy, x, part, bpart, M, N, K, st); break;
-    case 5: rc = launch<2, 4, 8, 4>(p, dy, x, part, bpart, M, N, K, st); break;
-    case 6: rc = launch<2, 2, 8, 4>(p, dy, x, part, bpart, M, N, K, st); break;
-    default: rc = launch<1, 4, 8, 4>(p, dy, x, part, bpart, M, N, K, st); break;
+    case 0: rc = launch<4, 2, 6, 6>(p, dy, x, part, bpart, M, N, K, sched, st); break;
+    case 1: rc = launch<2, 4, 6, 6>(p, dy, x, part, bpart, M, N, K, sched, st); break;
+    case 2: rc = launch<3, 2, 6, 6>(p, dy, x, part, bpart, M, N, K, sched, st); break;
+    case 3: rc = launch<2, 3, 6, 6>(p, dy, x, part, bpart, M, N, K, sched, st); break;
+    case 4: rc = launch<2, 2, 6, 6>(p, dy, x, part, bpart, M, N, K, sched, st); break;
+    case 5: rc = launch<2, 4, 8, 4>(p, dy, x, part, bpart, M, N, K, sched, st); break;
+    case 6: rc = launch<2, 2, 8, 4>(p, dy, x, part, bpart, M, N, K, sched, st); break;
+    default: rc = launch<1, 4, 8, 4>(p, dy, x, part, bpart, M, N, K, sched, st); break;
   }
   if (rc != LVL_OK) return rc;
   const int64_t NK = (int64_t)N * K;

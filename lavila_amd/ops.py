@@ -262,8 +262,9 @@ def linear_wgrad_raw(dy, x, want_dbias: bool, ws_floats: int = -1):
     ws = torch.empty(int(ws_floats), dtype=torch.float32, device=dy.device)
     dw = torch.empty(N, K, dtype=torch.float32, device=dy.device)
     db = torch.empty(N, dtype=torch.float32, device=dy.device) if want_dbias else None
-    C.check(C.lib().lvl_linear_wgrad(C.ptr(dy), C.ptr(x), C.ptr(dw), C.ptr(db), C.ptr(ws), M, N, K, C.dtype_code(dy),
-                                     C.stream_ptr()), 'lvl_linear_wgrad')
+    C.check(C.lib().lvl_linear_wgrad(C.ptr(dy), C.ptr(x), C.ptr(dw), C.ptr(db), C.ptr(ws),
+                                     C.ptr(sched_block(dy.device, 1024)), M, N, K, C.dtype_code(dy), C.stream_ptr()),
+            'lvl_linear_wgrad')
     return dw, db
 
 
@@ -271,21 +272,22 @@ def linear_wgrad_raw(dy, x, want_dbias: bool, ws_floats: int = -1):
 # kernel's last workgroup. One zero-filled pool per (device, stream), handed out round-robin: launches of one stream
 # run in order, so a block is long back to zero when its turn comes again (4096 launches later), and the two towers'
 # streams never share a block. Under hipGraph capture the block is allocated (and zeroed) inside the graph.
-_SCHED_BLOCKS = 4096
+# lvl_linear_wgrad's chunk-counter blocks (1024 words) come from a second pool of the same kind.
+_SCHED_BLOCKS = {16: 4096, 1024: 512}
 _sched_pools = {}
 DYNAMIC_TILES = os.environ.get('LAVILA_DYNAMIC_TILES', '1') != '0'
 
 
-def sched_block(device):
+def sched_block(device, words=16):
     if not DYNAMIC_TILES:
         return None
     if torch.cuda.is_current_stream_capturing():
-        return torch.zeros(16, dtype=torch.int32, device=device)
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
+        return torch.zeros(words, dtype=torch.int32, device=device)
+    key = (device, torch.cuda.current_stream(device).cuda_stream, words)
     pool = _sched_pools.get(key)
     if pool is None:
-        pool = _sched_pools[key] = [torch.zeros(_SCHED_BLOCKS, 16, dtype=torch.int32, device=device), 0]
-    pool[1] = (pool[1] + 1) % _SCHED_BLOCKS
+        pool = _sched_pools[key] = [torch.zeros(_SCHED_BLOCKS[words], words, dtype=torch.int32, device=device), 0]
+    pool[1] = (pool[1] + 1) % _SCHED_BLOCKS[words]
     return pool[0][pool[1]]
 
 

@@ -267,3 +267,88 @@ def test_weight_cache_sees_out_of_band_parameter_writes():
     with torch.no_grad():
         p.add_(1.0)                                               # in-band write: the version counter alone suffices
     assert torch.equal(ops.weight_copies(p)[0].float(), p.detach().to(torch.bfloat16).float())
+
+
+def _isa(tmp_path, name):
+    import shutil
+    import subprocess
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('hipcc not available')
+    src = os.path.join(ROOT, 'lavila_amd', 'csrc', name + '.hip')
+    out = tmp_path / (name + '.s')
+    subprocess.run([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-S',
+                    '--cuda-device-only', src, '-o', str(out)], check=True, capture_output=True, timeout=900)
+    return open(out).read().split('\n')
+
+
+def _kernel_bodies(lines, stem):
+    starts = [i for i, l in enumerate(lines) if l.startswith('_ZN') and stem in l and l.split(':')[0].isidentifier()]
+    for a in starts:
+        b = next(i for i in range(a, len(lines)) if 's_endpgm' in lines[i])
+        yield lines[a], [l.strip() for l in lines[a:b]]
+
+
+def _check_parked_reply_registers(name, body, n_defs):
+    """Registers that receive a memory reply LATER than the instruction naming them (`pend` in the kernels): destinations
+    of returning atomics (`sc0`) / agent-scope loads (`sc1`) issued from the exec-narrowed asm blocks. Each such register
+    may be touched only by (a) `v_mov vN, 0`, (b) such a definition, (c) the mailbox `ds_write_b32 vX, vN`; and in
+    layout order every definition is followed by its publish before anything else touches the register."""
+    defs = [(i, re.search(r' (v\d+),', l).group(1)) for i, l in enumerate(body)
+            if i > 0 and body[i - 1] == 's_mov_b64 exec, 1'               # the exec-narrowed asm blocks only
+            and (re.match(r'global_atomic_add v\d+, v\d+, v\d+, s\[\d+:\d+\] sc0$', l)
+                 or re.match(r'global_load_dword v\d+, v\d+, s\[\d+:\d+\] sc1$', l))]
+    assert len(defs) == n_defs, (name, defs)
+    if not defs:
+        return
+    for reg in {r for _, r in defs}:
+        n = int(reg[1:])
+        kinds = []
+        for l in body:
+            hit = re.search(r'\b' + reg + r'\b', l) is not None
+            hit = hit or any(int(m.group(1)) <= n <= int(m.group(2)) for m in re.finditer(r'v\[(\d+):(\d+)\]', l))
+            if not hit:
+                continue
+            if re.fullmatch(r'v_mov_b32_e32 ' + reg + r', (0|v\d+)', l):       # overwritten (pend = 0), never read
+                kinds.append('init')
+            elif (l.startswith('global_atomic_add ' + reg + ',') or l.startswith('global_load_dword ' + reg + ',')) \
+                    and l.endswith((' sc0', ' sc1')):
+                kinds.append('def')
+            elif re.fullmatch(r'ds_write_b32 v\d+, ' + reg, l):
+                kinds.append('publish')
+            else:
+                raise AssertionError(f'{name[:70]}: {reg} touched by `{l}`')
+        assert 'def' in kinds, (name, kinds)
+        for i, k in enumerate(kinds):          # layout order: a request is followed by its publish, nothing between
+            if k == 'def':
+                assert i + 1 < len(kinds) and kinds[i + 1] == 'publish', (name, kinds)
+            if k == 'publish':
+                assert i > 0 and kinds[i - 1] == 'def', (name, kinds)
+
+
+def test_gemm_tile_counter_reply_register_is_untouched_in_isa(tmp_path):
+    """lvl_linear_tn's dynamic tile scheduler and lvl_linear_wgrad's chunk claims park the reply of a returning atomic in
+    a VGPR that the memory system writes LATER than the instruction that names it (`pend` in csrc/gemm_tn_mfma.hip and
+    csrc/wgrad_mfma.hip). That is only sound if the compiler never copies, spills or reuses that register between the
+    request and the LDS publish behind the covering vmcnt wait. Checked where it can be checked without a GPU: in the
+    gfx950 ISA of every instantiation (see _check_parked_reply_registers); the kernels of the benched configuration must
+    also be free of scratch spills (a spill reload is a vector-memory operation inside the counted vmcnt schedule)."""
+    lines = _isa(tmp_path, 'gemm_tn_mfma')
+    bodies = list(_kernel_bodies(lines, 'gemm_tn_kernel'))
+    assert len(bodies) == 3
+    for name, body in bodies:
+        assert 'ILi2E' in name or not any('scratch_' in l for l in body), 'VGPR spills in the bias / fc1 GEMM kernels'
+        _check_parked_reply_registers(name, body, 2)           # first hand-out + the per-tile pull
+    lines = _isa(tmp_path, 'wgrad_mfma')
+    bodies = list(_kernel_bodies(lines, 'wgrad_kernel'))
+    assert len(bodies) == 16
+    for name, body in bodies:
+        if 'Lb0E' in name and ('ILi4ELi2ELi6ELi6E' in name or 'ILi2ELi4ELi6ELi6E' in name or 'ILi2ELi4ELi8ELi4E' in name):
+            assert not any('scratch_' in l for l in body), name      # the TSF-B / TSF-L / text shapes of the towers
+        # the chunk claims are synchronous: request, full wait and mailbox write sit in ONE asm block (nothing parked);
+        # the dbias instantiations keep the static plan and contain no claim code at all
+        reqs = [i for i, l in enumerate(body) if i > 0 and body[i - 1] == 's_mov_b64 exec, 1' and l.endswith((' sc0', ' sc1'))]
+        assert len(reqs) == (3 if 'Lb0E' in name else 0), (name, reqs)
+        for i in reqs:
+            reg = re.search(r' (v\d+),', body[i]).group(1)
+            assert body[i + 1] == 's_waitcnt vmcnt(0)' and re.fullmatch(r'ds_write_b32 v\d+, ' + reg, body[i + 2]), body[i:i + 3]

@@ -152,6 +152,152 @@ def test_persistent_gemms_exact_with_fewer_compute_units(cus):
         assert lib.lvl_set_compute_units(0) == 0
 
 
+def _tn_call(x, w, bias, epi, sched, aux_in=None):
+    """lvl_linear_tn through the raw C ABI with an explicit tile-counter block (None = static tile ranges)."""
+    from lavila_amd import _cabi as C
+    M, K = x.shape
+    N = w.shape[0]
+    y = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    aux_out = torch.empty_like(y) if epi == C.EPI_BIAS_QUICKGELU else None
+    colsum = torch.empty(N, dtype=torch.float32, device=DEV) if epi == C.EPI_QUICKGELU_BWD else None
+    ws = C.workspace('linear_tn', M, N, DEV) if epi == C.EPI_QUICKGELU_BWD else None
+    C.check(C.lib().lvl_linear_tn(C.ptr(x), C.ptr(w), C.ptr(bias), C.ptr(y), C.ptr(aux_out), C.ptr(aux_in), C.ptr(colsum),
+                                  C.ptr(ws), C.ptr(sched), M, N, K, epi, C.LVL_BF16, C.stream_ptr()), 'lvl_linear_tn')
+    return y, aux_out, colsum
+
+
+@pytest.mark.parametrize('M,N,K', [(70001, 768, 768), (9000, 2304, 768), (5000, 768, 3072), (200, 256, 320), (3000, 512, 256)])
+def test_dynamic_tile_schedule_equals_static_and_resets_its_counters(M, N, K):
+    """include/lavila_hip.h, lvl_linear_tn `sched`: with a tile-counter block the persistent workgroups take their
+    tiles from per-XCD device counters; every tile's arithmetic is unchanged (bit-equal outputs for all three
+    epilogues, column sums included), the block is zero again when the launch has drained (so the next launch can
+    reuse it), and K < 5 blocks of 64 silently keeps the static ranges."""
+    from lavila_amd import _cabi as C
+    g = torch.Generator(device=DEV).manual_seed(M)
+    x = torch.randn(M, K, device=DEV, generator=g).bfloat16()
+    w = (torch.randn(N, K, device=DEV, generator=g) * K ** -0.5).bfloat16()
+    b = torch.randn(N, device=DEV, generator=g)
+    u = torch.randn(M, N, device=DEV, generator=g).bfloat16()
+    sched = torch.zeros(16, dtype=torch.int32, device=DEV)
+    for epi, bias, aux in ((C.EPI_BIAS, b, None), (C.EPI_BIAS, None, None), (C.EPI_BIAS_QUICKGELU, b, None),
+                           (C.EPI_QUICKGELU_BWD, None, u)):
+        want = _tn_call(x, w, bias, epi, None, aux)
+        for rep in range(3):                       # the same block, back to back: it must come back zeroed
+            got = _tn_call(x, w, bias, epi, sched, aux)
+            for a, c in zip(got, want):
+                assert (a is None) == (c is None)
+                if a is not None:
+                    assert torch.equal(a, c), (epi, rep)
+        torch.cuda.synchronize()
+        assert int(sched.abs().sum()) == 0, sched.tolist()
+    # small-integer operands through the dynamic schedule: exact against the CPU
+    gi = torch.Generator().manual_seed(K)
+    xi = torch.randint(-2, 3, (M, K), generator=gi).float()
+    wi = torch.randint(-1, 2, (N, K), generator=gi).float() * (torch.rand(N, K, generator=gi) < 0.08)
+    bi = torch.randint(-8, 9, (N,), generator=gi).float()
+    y, _, _ = _tn_call(xi.to(DEV).bfloat16(), wi.to(DEV).bfloat16(), bi.to(DEV), C.EPI_BIAS, sched)
+    assert torch.equal(y.float().cpu(), xi @ wi.t() + bi)
+
+
+def _wgrad_call(dy, x, want_dbias, sched):
+    from lavila_amd import _cabi as C
+    M, N = dy.shape
+    K = x.shape[1]
+    ws = torch.empty(int(C.lib().lvl_workspace_floats(b'linear_wgrad', N, K)), dtype=torch.float32, device=DEV)
+    dw = torch.empty(N, K, dtype=torch.float32, device=DEV)
+    db = torch.empty(N, dtype=torch.float32, device=DEV) if want_dbias else None
+    C.check(C.lib().lvl_linear_wgrad(C.ptr(dy), C.ptr(x), C.ptr(dw), C.ptr(db), C.ptr(ws), C.ptr(sched), M, N, K,
+                                     C.LVL_BF16, C.stream_ptr()), 'lvl_linear_wgrad')
+    return dw, db
+
+
+@pytest.mark.parametrize('M,N,K', [(200960, 768, 768), (50000, 2304, 768), (30011, 768, 3072), (8192, 1536, 512), (2000, 1024, 1024)])
+def test_wgrad_chunk_schedule_equals_static_and_resets_its_counters(M, N, K):
+    """lvl_linear_wgrad `sched`: row chunks handed out by device counters. On an idle GPU nobody steals: every slab
+    holds the rows of the static plan in the same order, so dW (and dbias) are BIT-identical to the static schedule;
+    the counter block comes back zeroed."""
+    g = torch.Generator(device=DEV).manual_seed(N + K)
+    dy = torch.randn(M, N, device=DEV, generator=g).bfloat16()
+    x = torch.randn(M, K, device=DEV, generator=g).bfloat16()
+    sched = torch.zeros(1024, dtype=torch.int32, device=DEV)
+    for want_db in (False, True):          # (with dbias the kernel keeps the static plan and leaves the block alone)
+        want = _wgrad_call(dy, x, want_db, None)
+        for rep in range(2):
+            got = _wgrad_call(dy, x, want_db, sched)
+            assert torch.equal(got[0], want[0]), rep
+            if want_db:
+                assert torch.equal(got[1], want[1])
+        torch.cuda.synchronize()
+        assert int(sched.abs().sum()) == 0
+
+
+@pytest.mark.parametrize('mod', [2, 3, 7])
+def test_take_over_paths_with_late_workgroups(mod):
+    """lvl_debug_late_workgroups: every mod-th workgroup of the persistent GEMMs acts as if its compute unit had been
+    held by another kernel (an RCCL channel) for the whole launch. The tile queue (lvl_linear_tn) and the chunk stealing
+    among the splits of a tile (lvl_linear_wgrad) must still produce every output: exact on small-integer operands,
+    within float32 summation-order noise of the static schedule on random data, counters zeroed."""
+    from lavila_amd import _cabi as C
+    lib = C.lib()
+    assert lib.lvl_debug_late_workgroups(1) != 0
+    g = torch.Generator().manual_seed(mod)
+    M, N, K = 60000, 768, 768
+    xi = torch.randint(-2, 3, (M, K), generator=g).float()
+    wi = torch.randint(-1, 2, (N, K), generator=g).float() * (torch.rand(N, K, generator=g) < 0.08)
+    bi = torch.randint(-8, 9, (N,), generator=g).float()
+    dyi = torch.randint(-2, 3, (M, N), generator=g).float() * (torch.rand(M, N, generator=g) < 0.05)
+    x, w, b, dy = xi.to(DEV).bfloat16(), wi.to(DEV).bfloat16(), bi.to(DEV), dyi.to(DEV).bfloat16()
+    gr = torch.Generator(device=DEV).manual_seed(mod)
+    xr = torch.randn(M, K, device=DEV, generator=gr).bfloat16()
+    dyr = torch.randn(M, N, device=DEV, generator=gr).bfloat16()
+    want_r, wantb_r = _wgrad_call(dyr, xr, True, None)
+    s16 = torch.zeros(16, dtype=torch.int32, device=DEV)
+    s1k = torch.zeros(1024, dtype=torch.int32, device=DEV)
+    assert lib.lvl_debug_late_workgroups(mod) == 0
+    try:
+        for rep in range(2):
+            y, _, _ = _tn_call(x, w, b, C.EPI_BIAS, s16)
+            assert torch.equal(y.float().cpu(), xi @ wi.t() + bi)
+            dw, db = _wgrad_call(dy, x, True, s1k)
+            assert torch.equal(dw.cpu(), dyi.t() @ xi) and torch.equal(db.cpu(), dyi.sum(0))
+            dwr, dbr = _wgrad_call(dyr, xr, True, s1k)
+            torch.testing.assert_close(dwr, want_r, atol=2e-2, rtol=1e-4)      # |dW| ~ sqrt(M) = 245: 1e-4 relative
+            torch.testing.assert_close(dbr, wantb_r, atol=2e-2, rtol=1e-4)
+        torch.cuda.synchronize()
+        assert int(s16.abs().sum()) == 0 and int(s1k.abs().sum()) == 0
+    finally:
+        assert lib.lvl_debug_late_workgroups(0) == 0
+
+
+def test_dynamic_tile_schedule_on_concurrent_streams():
+    """The two towers launch lvl_linear_tn on two streams at once (models.py: text tower on the side stream): each
+    stream draws its counter blocks from its own pool (ops.sched_block), results stay exact while the launches overlap."""
+    from lavila_amd import _cabi as C
+    from lavila_amd import ops
+    g = torch.Generator().manual_seed(7)
+    M, N, K = 40000, 768, 768
+    xi = torch.randint(-2, 3, (M, K), generator=g).float()
+    wi = torch.randint(-1, 2, (N, K), generator=g).float() * (torch.rand(N, K, generator=g) < 0.08)
+    want = (xi @ wi.t()).to(DEV)
+    x, w = xi.to(DEV).bfloat16(), wi.to(DEV).bfloat16()
+    x2, w2 = x[:8192].contiguous(), w[:512].contiguous()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    outs, outs2 = [], []
+    for _ in range(6):
+        outs.append(ops.linear_tn_raw(x, w, None, C.EPI_BIAS))
+        with torch.cuda.stream(side):
+            outs2.append(ops.linear_tn_raw(x2, w2, None, C.EPI_BIAS))
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    for y in outs:
+        assert torch.equal(y.float(), want)
+    for y in outs2:
+        assert torch.equal(y.float(), want[:8192, :512])
+    pools = [p for key, p in ops._sched_pools.items() if key[2] == 16]
+    assert len(pools) >= 2 and all(int(p[0].abs().sum()) == 0 for p in pools)
+
+
 # --------------------------------------------------------------------------------------------------------------------
 # contrastive slabs at the global batch of BASELINE.json configs[2] (G = 2048 = 8 ranks x 256)
 # --------------------------------------------------------------------------------------------------------------------
