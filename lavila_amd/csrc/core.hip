@@ -16,6 +16,7 @@ int lvl_fail(int code, const char* fmt, ...) {
 int lvl_ln_bwd_parts();
 int lvl_gelu_bwd_row_blocks();
 int lvl_qkv_bias_row_blocks();
+int lvl_colsum_mid_rows();
 int64_t lvl_wgrad_workspace_floats(int64_t N, int64_t K);
 int64_t lvl_linear_tn_workspace_floats(int64_t M, int64_t N);
 
@@ -57,12 +58,13 @@ extern "C" const char* lvl_last_error(void) { return lvl_err_buf; }
 
 extern "C" int64_t lvl_workspace_floats(const char* op, int64_t rows, int64_t cols) {
   if (!op) return -1;
-  if (!strcmp(op, "layernorm_bwd")) return (int64_t)lvl_ln_bwd_parts() * 3 * cols;
-  if (!strcmp(op, "bias_quickgelu_bwd")) return (int64_t)lvl_gelu_bwd_row_blocks() * cols;
+  // partial slabs + the kColsumMid intermediate rows of the two-stage column reduction behind them
+  if (!strcmp(op, "layernorm_bwd")) return (int64_t)(lvl_ln_bwd_parts() + lvl_colsum_mid_rows()) * 3 * cols;
+  if (!strcmp(op, "bias_quickgelu_bwd")) return (int64_t)(lvl_gelu_bwd_row_blocks() + lvl_colsum_mid_rows()) * cols;
   if (!strcmp(op, "divided_attn_fwd")) return rows * 64 * 66;   // <= 64 CLS-row partial records per (b,h)
   if (!strcmp(op, "divided_attn_bwd")) return rows * cols + rows * 192;   // delta [B*H, T] + cls-grad atomics
   if (!strcmp(op, "causal_attn_bwd")) return rows * cols;    // delta [B*H, L]
-  if (!strcmp(op, "qkv_bias_grad")) return (int64_t)lvl_qkv_bias_row_blocks() * 2 * cols;   // cols = D
+  if (!strcmp(op, "qkv_bias_grad")) return (int64_t)(lvl_qkv_bias_row_blocks() + lvl_colsum_mid_rows()) * 2 * cols;   // cols = D
   if (!strcmp(op, "linear_wgrad")) return lvl_wgrad_workspace_floats(rows, cols);   // rows = N (out), cols = K (in); -1: no tiling
   if (!strcmp(op, "linear_tn")) return lvl_linear_tn_workspace_floats(rows, cols);   // rows = M, cols = N
   return -1;

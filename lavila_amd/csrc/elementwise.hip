@@ -2,7 +2,7 @@
 // All HBM-bound single-pass kernels: 16 B per lane, consecutive lanes on consecutive vectors.
 #include "common.h"
 
-int lvl_launch_column_reduce(const float* part, int nparts, int width, int seg, float* out0, float* out1,
+int lvl_launch_column_reduce(const float* part, int nparts, int width, int seg, float* mid, float* out0, float* out1,
                              float* out2, hipStream_t st);
 
 namespace {
@@ -290,7 +290,9 @@ extern "C" int lvl_bias_quickgelu_bwd(const void* da, const void* u, const float
                                                (const T*)da, (const T*)u, bias, (T*)du, dbias ? ws : nullptr, rows,
                                                cols));
   LVL_CHECK_LAUNCH("bias_quickgelu_bwd");
-  if (dbias) return lvl_launch_column_reduce(ws, (int)gy, cols, cols, dbias, nullptr, nullptr, st);
+  if (dbias)
+    return lvl_launch_column_reduce(ws, (int)gy, cols, cols, ws + (size_t)kGeluBwdRowBlocks * cols, dbias, nullptr, nullptr,
+                                    st);
   return LVL_OK;
 }
 
@@ -361,5 +363,6 @@ extern "C" int lvl_qkv_bias_grad(const void* dqkv, const void* dout, float* dbia
   LVL_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((qkv_bias_partial_kernel<T>), grid, dim3(128), 0, st, (const T*)dqkv,
                                                (const T*)dout, ws, rows, D));
   LVL_CHECK_LAUNCH("qkv_bias_grad");
-  return lvl_launch_column_reduce(ws, (int)gy, 2 * D, D, dbias, dbias + 2 * (size_t)D, nullptr, st);
+  return lvl_launch_column_reduce(ws, (int)gy, 2 * D, D, ws + (size_t)kBiasGradRowBlocks * 2 * D, dbias,
+                                  dbias + 2 * (size_t)D, nullptr, st);
 }

@@ -42,8 +42,8 @@
 //     N-fastest tile order, so the N/256 tiles that read the same 256 rows of X sit behind one L2 and X comes from
 //     HBM once; W (<= 4.7 MB) lives in L2 / Infinity Cache;
 //   * inside an XCD's range the tiles are handed out by a DEVICE TILE COUNTER (one word per XCD, `sched`): a
-//     workgroup takes the next tile of its XCD's queue with one returning atomic add, issued at the top of the tile
-//     before, so that its latency never shows (the reply is parked in a register, published to the other waves
+//     workgroup takes the next tile of its XCD's queue with one returning atomic add, issued in front of the
+//     result stores of the tile before the tile before, so that its latency never shows (the reply is parked in a register, published to the other waves
 //     through an LDS mailbox two K blocks later -- by then the counted vmcnt waits of the K loop have covered it --
 //     and read by the fetch cursor when it wraps to the next tile, three K blocks before the end).
 //     A compute unit that another kernel holds (an RCCL channel during the gradient all-reduce) therefore costs
@@ -54,6 +54,9 @@
 #include "common.h"
 
 int lvl_debug_late_mod();
+int lvl_colsum_mid_rows();
+int lvl_launch_column_reduce(const float* part, int nparts, int width, int seg, float* mid, float* out0, float* out1,
+                             float* out2, hipStream_t st);
 
 // the LDS-DMA fills set M0 inside inline asm and say so in the clobber list; this kernel has no other M0 user
 #pragma clang diagnostic ignored "-Winline-asm"
@@ -120,6 +123,7 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
   const int cnt = tq + (xcd < tr ? 1 : 0);
   const int xstart = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
   const bool dyn = sched != nullptr;            // the host passes a counter block only when nb >= DYN_MIN_NB
+  if (dyn) __builtin_assume(nb >= DYN_MIN_NB);
   if (!dyn && bid / nx >= cnt) return;
   int my_tiles = dyn ? 0x7fffffff : (cnt - bid / nx + wpx - 1) / wpx;
   int pair_even = xstart + bid / nx, pair_odd = pair_even;    // tile index (N-fastest order) of tile ordinal i, by i & 1
@@ -159,6 +163,7 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
     if (v >= cnt) my_tiles = 0;                 // queue already drained (this workgroup got its CU late)
     pair_even = xstart + v;
     __builtin_amdgcn_s_barrier();               // everyone has read the mailbox before it is written again
+    if (my_tiles) pull();                       // tile 1: the reply lands during the prologue fills and tile 0's first blocks
   }
 
   // Tile order: all N/256 column tiles of a row block are neighbours (N-fastest). (Panels of 3-6 column tiles, to keep
@@ -520,10 +525,6 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
   using IS = std::integral_constant<int, NS>;
   for (int i = 0; i < my_tiles; ++i) {
     int j = 0;
-    // ask for the NEXT tile now: the reply lands during K blocks 0-1, is published at block 2 and read by the fetch
-    // cursor at block nb-3 (the register that receives it is live only across these first blocks, not across the
-    // epilogue, where the accumulators, the packed results and the next tile's first fragments fill the file)
-    if (dyn) pull();
     if (i > 0) {                     // the slots read here were filled before the previous tile's epilogue
       k_block(IS{}, IS{});
       if (nb > 1) k_block(IS{}, I0{});
@@ -531,8 +532,8 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
     }
     for (; j < nb; ++j) {
       if (dyn && j == 2) {
-        // K block 2: the counter reply asked for at the top of this tile is 16 fills old; "all but the 10 newest" --
-        // the wait the next barrier performs anyway -- has it in its register
+        // K block 2: the counter reply asked for before the previous tile's epilogue is an epilogue and 16 fills old;
+        // "all but the 10 newest" -- the wait the next barrier performs anyway -- has it in its register
         if (wave == 0) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
         publish();
       }
@@ -541,6 +542,12 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
     // the fills of the next tile's first blocks are in flight and its first X0 / W0 fragments already in registers
     // while this tile's results leave
     GM_STAMP();
+    // Ask for the tile after the next one NOW, in front of this tile's result stores: vector-memory replies come back
+    // in issue order, so a slow device-scope atomic holds up the completion count of every fill issued behind it --
+    // here the fills in front of it are the ones the next barriers wait for (the next tile's blocks 0 and 1 were
+    // fetched before this point), and the epilogue (~3 us) plus two K blocks pass before anything behind it is awaited.
+    // (Issued at the top of a tile the reply delayed that tile's first fills: +3 % on the K = 768 shapes.)
+    if (dyn && my_tiles == 0x7fffffff) pull();
     const int pair = get_pair(i);
     int tm, tn;
     decode_tile(pair, tm, tn);
@@ -553,6 +560,8 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
 #undef GM_BAR
 #undef GM_PHASE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the run-ahead fills before this workgroup's LDS is freed
+  // the last pull's reply is never consumed: keep its register reserved until the drain above has delivered it
+  asm volatile("" ::"v"(pend));
   if (dyn && wave == 0 && lane == 0) {
     // every workgroup of the launch signs off once (its counter atomics are complete: vmcnt(0) above); the last one
     // out leaves the counter block zeroed for the next launch that is handed the same block
@@ -562,30 +571,6 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
       for (int q = 0; q < 9; ++q) __hip_atomic_store(sched + q, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-}
-
-// out[g][n] = sum over the rows p = g, g + G, g + 2G, ... of part[p][n] (deterministic, no atomics). Launched twice:
-// P rows -> 32 rows, 32 rows -> 1. 64 columns x 4 row lanes per workgroup, grid (N/64, G).
-__global__ __launch_bounds__(256) void colpart_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
-                                                             int P, int N) {
-  __shared__ float red[4][64];
-  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-  const int n = blockIdx.x * 64 + cx;
-  const int G = gridDim.y, g = blockIdx.y;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  if (n < N) {                          // 4 loads in flight: a latency chain otherwise
-    int p = g + ry * G;
-    for (; p + 12 * G < P; p += 16 * G) {
-      a0 += part[(size_t)p * N + n];
-      a1 += part[(size_t)(p + 4 * G) * N + n];
-      a2 += part[(size_t)(p + 8 * G) * N + n];
-      a3 += part[(size_t)(p + 12 * G) * N + n];
-    }
-    for (; p < P; p += 4 * G) a0 += part[(size_t)p * N + n];
-  }
-  red[ry][cx] = (a0 + a1) + (a2 + a3);
-  __syncthreads();
-  if (ry == 0 && n < N) out[(size_t)g * N + n] = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
 }
 
 int num_cus() { return lvl_persistent_cus(); }      // one persistent workgroup per compute unit
@@ -612,7 +597,9 @@ int launch_tn(const void* x, const void* w, const float* bias, void* y, void* au
 
 }  // namespace
 
-int64_t lvl_linear_tn_workspace_floats(int64_t M, int64_t N) { return (2 * ((M + TM - 1) / TM) + 32) * N; }
+int64_t lvl_linear_tn_workspace_floats(int64_t M, int64_t N) {
+  return (2 * ((M + TM - 1) / TM) + lvl_colsum_mid_rows()) * N;      // column partials + the reducer's intermediate rows
+}
 
 #ifdef GM_TRACE
 extern "C" int lvl_linear_tn_trace(const void* x, const void* w, const float* bias, void* y, void* trace, int64_t M,
@@ -647,12 +634,7 @@ extern "C" int lvl_linear_tn(const void* x, const void* w, const float* bias, vo
       const int rc = launch_tn<2>(x, w, nullptr, y, nullptr, aux_in, ws, M, N, K, sched, st);
       if (rc != LVL_OK) return rc;
       const int P = (int)(2 * ((M + TM - 1) / TM));
-      float* mid = ws + (size_t)P * N;          // [32][N]
-      hipLaunchKernelGGL(colpart_reduce_kernel, dim3((unsigned)((N + 63) / 64), 32), dim3(256), 0, st, ws, mid, P, N);
-      hipLaunchKernelGGL(colpart_reduce_kernel, dim3((unsigned)((N + 63) / 64), 1), dim3(256), 0, st, mid, colsum, 32,
-                         N);
-      LVL_CHECK_LAUNCH("linear_tn_colsum");
-      return LVL_OK;
+      return lvl_launch_column_reduce(ws, P, N, N, ws + (size_t)P * N, colsum, nullptr, nullptr, st);
     }
     default:
       return lvl_fail(LVL_EINVAL, "linear_tn: unknown epilogue %d", epilogue);

@@ -294,36 +294,84 @@ __global__ __launch_bounds__(256, (VPL * W <= 12 ? (sizeof(T) == 2 ? 3 : 2) : 1)
   }
 }
 
-// out_s[k - s*seg] = sum_p part[p][k] for k in segment s of width seg.
-// 16 columns per workgroup, 16 thread groups each summing one sixteenth of the partial slabs (64-B row segments),
-// merged through LDS: width/16 workgroups (144 for 3 x 768) instead of width/64 spread this latency-bound tail of
-// the backward over more CUs and shorten each thread's dependent load chain 4x.
-__global__ __launch_bounds__(256) void column_reduce_kernel(const float* __restrict__ part, int nparts, int width,
-                                                            int seg, float* __restrict__ out0,
-                                                            float* __restrict__ out1, float* __restrict__ out2) {
-  __shared__ float red[16][16];
-  const int col = threadIdx.x & 15, pg = threadIdx.x >> 4;
-  const int k = blockIdx.x * 16 + col;
-  float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (k < width) {
-    // 8 independent loads in flight per thread: the kernel is a latency chain (7 MB behind 144 workgroups), the
-    // slab rows a thread walks are 16 apart
-    int p = pg;
-    for (; p + 112 < nparts; p += 128) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) a[i] += part[(size_t)(p + 16 * i) * width + k];
+// Column sums of a partial slab part[nparts][width] (f32), deterministic, in two coalesced stages:
+//   stage 1: grid (width/256, kColsumMid): a workgroup owns 256 columns (one 16-byte vector per lane = 1 KiB per row
+//            per wave) and one of kColsumMid row chunks; its 4 waves take the chunk's rows round-robin with every load
+//            issued before the first add, merge through LDS and write one row of mid[kColsumMid][width];
+//   stage 2: 64 columns x 16 row groups per workgroup sum the kColsumMid rows of mid and scatter the result into up to
+//            three `seg`-wide outputs.
+// The whole slab (7-19 MB) is in flight at once in stage 1: two short launches (~4 + 3 us) instead of one
+// latency chain of 8 dependent round trips per thread behind 144 workgroups (50 us, 99 calls per step in round 2).
+constexpr int kColsumMid = 64;
+
+__global__ __launch_bounds__(256) void colsum_stage1_kernel(const float* __restrict__ part, int nparts, int width,
+                                                            float* __restrict__ mid) {
+  __shared__ float4 red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 256 + lane * 4;
+  const int rpc = (nparts + kColsumMid - 1) / kColsumMid;
+  const int r0 = blockIdx.y * rpc, r1 = min(r0 + rpc, nparts);
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < width) {
+    int p = r0 + wave;
+    for (; p + 12 < r1; p += 16) {          // 4 rows in flight per wave
+      const float4 v0 = *reinterpret_cast<const float4*>(part + (size_t)p * width + c);
+      const float4 v1 = *reinterpret_cast<const float4*>(part + (size_t)(p + 4) * width + c);
+      const float4 v2 = *reinterpret_cast<const float4*>(part + (size_t)(p + 8) * width + c);
+      const float4 v3 = *reinterpret_cast<const float4*>(part + (size_t)(p + 12) * width + c);
+      a.x += (v0.x + v1.x) + (v2.x + v3.x);
+      a.y += (v0.y + v1.y) + (v2.y + v3.y);
+      a.z += (v0.z + v1.z) + (v2.z + v3.z);
+      a.w += (v0.w + v1.w) + (v2.w + v3.w);
     }
-    for (; p < nparts; p += 16) a[0] += part[(size_t)p * width + k];
+    for (; p < r1; p += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(part + (size_t)p * width + c);
+      a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
   }
-  red[pg][col] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  red[wave][lane] = a;
   __syncthreads();
-  if (pg == 0 && k < width) {
-    float acc = 0.f;
+  if (wave == 0 && c < width) {
+    const float4 b = red[1][lane], d = red[2][lane], e = red[3][lane];
+    float4 o;
+    o.x = (a.x + b.x) + (d.x + e.x);
+    o.y = (a.y + b.y) + (d.y + e.y);
+    o.z = (a.z + b.z) + (d.z + e.z);
+    o.w = (a.w + b.w) + (d.w + e.w);
+    *reinterpret_cast<float4*>(mid + (size_t)blockIdx.y * width + c) = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void colsum_stage2_kernel(const float* __restrict__ mid, int width, int seg,
+                                                            float* __restrict__ out0, float* __restrict__ out1,
+                                                            float* __restrict__ out2) {
+  __shared__ float4 red[16][16];
+  const int cg = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + cg * 4;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < width) {
+    float4 v[kColsumMid / 16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc += red[i][col];
-    const int sg = k / seg;
-    float* o = sg == 0 ? out0 : (sg == 1 ? out1 : out2);
-    if (o) o[k - sg * seg] = acc;
+    for (int i = 0; i < kColsumMid / 16; ++i) v[i] = *reinterpret_cast<const float4*>(mid + (size_t)(rg + 16 * i) * width + c);
+#pragma unroll
+    for (int i = 0; i < kColsumMid / 16; ++i) { a.x += v[i].x; a.y += v[i].y; a.z += v[i].z; a.w += v[i].w; }
+  }
+  red[rg][cg] = a;
+  __syncthreads();
+  if (rg == 0 && c < width) {
+    float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const float4 b = red[i][cg];
+      o[0] += b.x; o[1] += b.y; o[2] += b.z; o[3] += b.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = c + e;
+      const int sg = k / seg;
+      float* dst = sg == 0 ? out0 : (sg == 1 ? out1 : out2);
+      if (dst && k < width) dst[k - sg * seg] = o[e];
+    }
   }
 }
 
@@ -346,11 +394,15 @@ __global__ __launch_bounds__(256) void column_reduce_kernel(const float* __restr
 
 int lvl_ln_bwd_parts() { return kLnBwdParts; }
 
-// out0/out1/out2 receive consecutive `seg`-wide segments of the column sums of part[nparts][width]
-int lvl_launch_column_reduce(const float* part, int nparts, int width, int seg, float* out0, float* out1,
+int lvl_colsum_mid_rows() { return kColsumMid; }
+
+// out0/out1/out2 receive consecutive `seg`-wide segments of the column sums of part[nparts][width] (width % 4 == 0);
+// mid: kColsumMid * width floats of scratch (the callers place it behind their partial slab)
+int lvl_launch_column_reduce(const float* part, int nparts, int width, int seg, float* mid, float* out0, float* out1,
                              float* out2, hipStream_t st) {
-  hipLaunchKernelGGL(column_reduce_kernel, dim3((width + 15) / 16), dim3(256), 0, st, part, nparts, width, seg,
-                     out0, out1, out2);
+  hipLaunchKernelGGL(colsum_stage1_kernel, dim3((width + 255) / 256, kColsumMid), dim3(256), 0, st, part, nparts, width,
+                     mid);
+  hipLaunchKernelGGL(colsum_stage2_kernel, dim3((width + 63) / 64), dim3(256), 0, st, mid, width, seg, out0, out1, out2);
   LVL_CHECK_LAUNCH("column_reduce");
   return LVL_OK;
 }
@@ -407,5 +459,6 @@ extern "C" int lvl_layernorm_bwd(const void* dy, const void* x, const void* x2, 
 #undef LN_BWD
 #undef LN_BWD_T
   LVL_CHECK_LAUNCH("layernorm_bwd");
-  return lvl_launch_column_reduce(ws, (int)blocks, 3 * cols, cols, dgamma, dbeta, dxsum, st);
+  return lvl_launch_column_reduce(ws, (int)blocks, 3 * cols, cols, ws + (size_t)kLnBwdParts * 3 * cols, dgamma, dbeta,
+                                  dxsum, st);
 }

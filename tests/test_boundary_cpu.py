@@ -285,45 +285,62 @@ def _isa(tmp_path, name):
 def _kernel_bodies(lines, stem):
     starts = [i for i, l in enumerate(lines) if l.startswith('_ZN') and stem in l and l.split(':')[0].isidentifier()]
     for a in starts:
-        b = next(i for i in range(a, len(lines)) if 's_endpgm' in lines[i])
+        b = next(i for i in range(a, len(lines)) if lines[i].startswith('.Lfunc_end'))      # (s_endpgm may occur early)
         yield lines[a], [l.strip() for l in lines[a:b]]
 
 
 def _check_parked_reply_registers(name, body, n_defs):
-    """Registers that receive a memory reply LATER than the instruction naming them (`pend` in the kernels): destinations
-    of returning atomics (`sc0`) / agent-scope loads (`sc1`) issued from the exec-narrowed asm blocks. Each such register
-    may be touched only by (a) `v_mov vN, 0`, (b) such a definition, (c) the mailbox `ds_write_b32 vX, vN`; and in
-    layout order every definition is followed by its publish before anything else touches the register."""
-    defs = [(i, re.search(r' (v\d+),', l).group(1)) for i, l in enumerate(body)
-            if i > 0 and body[i - 1] == 's_mov_b64 exec, 1'               # the exec-narrowed asm blocks only
-            and (re.match(r'global_atomic_add v\d+, v\d+, v\d+, s\[\d+:\d+\] sc0$', l)
-                 or re.match(r'global_load_dword v\d+, v\d+, s\[\d+:\d+\] sc1$', l))]
+    """Registers that receive a memory reply LATER than the instruction naming them (`pend` in the GEMM): destinations of
+    the returning atomics issued from the exec-narrowed asm blocks. Static check on the control-flow graph of the ISA:
+    on every path from such a request to (a) the mailbox `ds_write_b32 vX, vN` that consumes it or (b) a full
+    `s_waitcnt vmcnt(0)`, no other instruction may touch the register -- no copy, spill, reload or reuse while the
+    reply can still be in flight."""
+    body = [l.split(';')[0].strip() for l in body]
+    ins = [l for l in body if l and (not l.startswith('.') or re.fullmatch(r'\.LBB\d+_\d+:', l))]
+    labels = {l[:-1]: i for i, l in enumerate(ins) if l.endswith(':')}
+    defs = [(i, re.search(r' (v\d+),', l).group(1)) for i, l in enumerate(ins)
+            if i > 0 and ins[i - 1] == 's_mov_b64 exec, 1' and re.match(r'global_atomic_add v\d+, v\d+, v\d+, s\[\d+:\d+\] sc0$', l)]
     assert len(defs) == n_defs, (name, defs)
-    if not defs:
-        return
-    for reg in {r for _, r in defs}:
+
+    def touches(l, reg):
         n = int(reg[1:])
-        kinds = []
-        for l in body:
-            hit = re.search(r'\b' + reg + r'\b', l) is not None
-            hit = hit or any(int(m.group(1)) <= n <= int(m.group(2)) for m in re.finditer(r'v\[(\d+):(\d+)\]', l))
-            if not hit:
+        return re.search(r'\b' + reg + r'\b', l) is not None or \
+            any(int(m.group(1)) <= n <= int(m.group(2)) for m in re.finditer(r'v\[(\d+):(\d+)\]', l))
+
+    def succ(i):
+        l = ins[i]
+        if l.startswith('s_endpgm'):
+            return []
+        if l.startswith('s_branch'):
+            return [labels[l.split()[-1]]]
+        out = [i + 1] if i + 1 < len(ins) else []
+        if l.startswith('s_cbranch'):
+            out.append(labels[l.split()[-1]])
+        return out
+    for d, reg in defs:
+        seen, todo, published = set(), succ(d), 0
+        while todo:
+            i = todo.pop()
+            if i in seen:
                 continue
-            if re.fullmatch(r'v_mov_b32_e32 ' + reg + r', (0|v\d+)', l):       # overwritten (pend = 0), never read
-                kinds.append('init')
-            elif (l.startswith('global_atomic_add ' + reg + ',') or l.startswith('global_load_dword ' + reg + ',')) \
-                    and l.endswith((' sc0', ' sc1')):
-                kinds.append('def')
-            elif re.fullmatch(r'ds_write_b32 v\d+, ' + reg, l):
-                kinds.append('publish')
-            else:
-                raise AssertionError(f'{name[:70]}: {reg} touched by `{l}`')
-        assert 'def' in kinds, (name, kinds)
-        for i, k in enumerate(kinds):          # layout order: a request is followed by its publish, nothing between
-            if k == 'def':
-                assert i + 1 < len(kinds) and kinds[i + 1] == 'publish', (name, kinds)
-            if k == 'publish':
-                assert i > 0 and kinds[i - 1] == 'def', (name, kinds)
+            seen.add(i)
+            l = ins[i]
+            if re.fullmatch(r'ds_write_b32 v\d+, ' + reg, l):
+                published += 1
+                continue                                   # consumed: the window ends here
+            if l == 's_waitcnt vmcnt(0)':
+                published += 1
+                continue                                   # every reply has been delivered
+            nxt = [k for k in range(i, min(i + 8, len(ins))) if ins[k].startswith('global_atomic_add ' + reg + ',')
+                   and ins[k - 1] == 's_mov_b64 exec, 1']
+            if nxt and (nxt[0] == i or re.fullmatch(r'v_mov_b32_e32 ' + reg + r', [01]', l)):
+                # the next request into the same register (replies return in issue order; the compiler may load the
+                # request's constant operand into the very register that will receive the reply); its own window is
+                # checked separately. (The walk is path-insensitive: it also follows the nb < 3 exit of the K loop.)
+                continue
+            assert not touches(l, reg), f'{name[:70]}: {reg} (reply in flight since instruction {d}) touched by `{l}`'
+            todo.extend(succ(i))
+        assert published >= 1, (name, d, reg)
 
 
 def test_gemm_tile_counter_reply_register_is_untouched_in_isa(tmp_path):
@@ -338,7 +355,7 @@ def test_gemm_tile_counter_reply_register_is_untouched_in_isa(tmp_path):
     assert len(bodies) == 3
     for name, body in bodies:
         assert 'ILi2E' in name or not any('scratch_' in l for l in body), 'VGPR spills in the bias / fc1 GEMM kernels'
-        _check_parked_reply_registers(name, body, 2)           # first hand-out + the per-tile pull
+        _check_parked_reply_registers(name, body, 3)           # first hand-out, tile 1, the per-tile pull
     lines = _isa(tmp_path, 'wgrad_mfma')
     bodies = list(_kernel_bodies(lines, 'wgrad_kernel'))
     assert len(bodies) == 16

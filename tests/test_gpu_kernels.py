@@ -401,5 +401,10 @@ def test_kernel_argument_errors_are_loud():
     with pytest.raises(HipExtensionError):
         ops.divided_attention(torch.randn(2, 11, 3 * 96, device=DEV), 2, 5, 3, 'space')   # head dim 32
     with pytest.raises(HipExtensionError):
-        ops.layer_norm(torch.randn(4, 128, device=DEV, dtype=torch.float16), torch.ones(128, device=DEV),
+        ops.layer_norm(torch.randn(4, 128, device=DEV, dtype=torch.float64), torch.ones(128, device=DEV),
                        torch.zeros(128, device=DEV), 1e-5)
+    # fp16 activations (model.half() callers) are computed in bf16, not rejected (tests/test_gpu_boundary.py)
+    xh = torch.randn(4, 128, device=DEV, dtype=torch.float16)
+    yh = ops.layer_norm(xh, torch.ones(128, device=DEV), torch.zeros(128, device=DEV), 1e-5)
+    assert yh.dtype == torch.bfloat16
+    torch.testing.assert_close(yh.float(), torch.nn.functional.layer_norm(xh.float(), (128,)), atol=3e-2, rtol=3e-2)
