@@ -37,7 +37,9 @@ const char* lvl_version(void);
 /* Test hook for the dynamic schedules of lvl_linear_tn / lvl_linear_wgrad (`sched` != NULL): from now on the workgroups
  * with blockIdx % mod == 1 of every such launch behave as if their compute unit had been held by another kernel for
  * the whole launch -- they start, find nothing left to do and sign off -- so that the take-over paths (tile queue /
- * chunk stealing) can be exercised deterministically on an idle GPU. mod = 0 switches it off. Results must not change. */
+ * chunk stealing) can be exercised deterministically on an idle GPU. mod = 0 switches it off. Results must not change
+ * as long as mod does not divide 8 (blockIdx % 8 selects the XCD tile queue: an XCD whose workgroups ALL never work has
+ * nobody to serve its queue -- a workgroup that is merely late serves it when it starts). */
 int lvl_debug_late_workgroups(int mod);
 /* Compute units the two persistent GEMM kernels (lvl_linear_tn, lvl_linear_wgrad: one workgroup per CU holding the
  * whole register file) size their grids for. 0 (default) = every CU of the device; a multiple of 8 below that leaves
@@ -171,6 +173,16 @@ int lvl_ssl_clip_loss_bwd(const void* img_all, const void* txt_all, const int32_
                           const float* lse_all, const float* scales3, const float* upstream, float coef,
                           int B, int G, int E, int row0, float* dimg, float* dtxt, int dtype,
                           void* stream);
+
+/* ---- narrator seam: multi-query cross-attention pooling (inference) ------------------------------------------
+ * The core of coca.py's CrossAttention (lavila/models/coca.py:93-123) between to_q / to_kv and to_out, as
+ * VCLM_HF.encode_image runs it on the tower's token features (narrator.py:44-49,88-90): NQ x H query rows of 64
+ * channels attend to the Tk context tokens through ONE shared key/value head:
+ *   out[b,n,h,:] = softmax_j(0.125 * q[b,n,h,:] . k[b,j,:]) v[b,j,:]   (q * dim_head^-0.5, max-subtracted softmax)
+ * q: [B or 1, NQ, H*64] with batch stride q_batch_stride elements (0 = the same queries for every clip: the narrator
+ * repeats its learned img_queries); kv: [B, Tk, 128] = k | v as to_kv writes them; out: [B, NQ, H*64]. Forward only. */
+int lvl_mq_cross_attn_fwd(const void* q, int64_t q_batch_stride, const void* kv, void* out, int B, int NQ, int H,
+                          int Tk, int dtype, void* stream);
 
 /* ---- Linear layers: forward and input-gradient GEMMs with fused epilogues -------------------------------------
  * y[M,N] = epilogue(x[M,K] . w[N,K]^T): both operands bf16, row-major, contraction-contiguous; f32 accumulation.

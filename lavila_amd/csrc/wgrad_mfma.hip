@@ -404,7 +404,10 @@ constexpr int kCfg[][4] = {{4, 2, 6, 6}, {2, 4, 6, 6}, {3, 2, 6, 6}, {2, 3, 6, 6
                            {2, 4, 8, 4}, {2, 2, 8, 4}, {1, 4, 8, 4}};
 constexpr int kNumCfg = sizeof(kCfg) / sizeof(kCfg[0]);
 
-Plan make_plan(int N, int K) {
+// M > 0: the row count of the launch -- a unit keeps at least ~48 steps (1536 rows) so that a short problem (the text
+// tower: 8192 rows) is not cut into 250 units whose 256-KiB partial slabs cost more than their MFMAs and which would
+// hold every CU while the other tower's kernels wait. M = 0: the largest plan (workspace sizing).
+Plan make_plan(int N, int K, int64_t M = 0) {
   Plan best{};
   int64_t best_score = 0;
   for (int ci = 0; ci < kNumCfg; ++ci) {
@@ -415,9 +418,19 @@ Plan make_plan(int N, int K) {
     const int cus = lvl_persistent_cus();
     if (ntiles > cus) continue;
     // one resident workgroup per CU: S * ntiles <= CUs and a multiple of 8 (XCD mapping)
-    int S = cus / ntiles;
+    const int smax = cus / ntiles;
+    int S = smax;
+    if (M > 0) {
+      const int64_t cap = (M / MS) / 48;
+      if (S > cap) S = cap < 1 ? 1 : (int)cap;
+    }
+    const int want = S;
     while (S > 1 && (ntiles * S) % 8) --S;
-    if ((ntiles * S) % 8) continue;
+    if ((ntiles * S) % 8) {                  // nothing at or below the cap maps onto whole XCD rounds: go up instead
+      S = want;
+      while (S <= smax && (ntiles * S) % 8) ++S;
+      if (S > smax) continue;
+    }
     // score = busy SIMD slots x tile area: 6 waves load the 4 SIMDs 2:2:1:1, 4 waves leave every SIMD one wave
     const int waves = c[0] * c[1];
     const int64_t eff = waves % 4 == 0 ? (waves >= 8 ? 4 : 3) : 3;
@@ -481,7 +494,7 @@ extern "C" int lvl_linear_wgrad(const void* dy, const void* x, float* dw, float*
   LVL_REQUIRE(M > 0 && N > 0 && K > 0, "linear_wgrad: empty problem");
   LVL_REQUIRE(lvl_aligned16(dy) && lvl_aligned16(x) && lvl_aligned16(dw) && lvl_aligned16(ws),
               "linear_wgrad: pointers must be 16-byte aligned");
-  const Plan p = make_plan(N, K);
+  const Plan p = make_plan(N, K, M);
   if (!p.ok) return lvl_fail(LVL_ENOSYS, "linear_wgrad: no tiling for N=%d K=%d (multiples of 192/288/384 or 128/256 needed)", N, K);
   hipStream_t st = (hipStream_t)stream;
   float* part = ws;

@@ -313,6 +313,63 @@ def run_ssl_loss_golden(ref):
     print(f"[golden] ssl_clip_loss: single loss={single['out']['loss']:.6f} multi loss={multi['out'][0]['loss']:.6f}")
 
 
+NARRATOR = dict(img=32, patch=16, frames=2, dim=128, depth=2, heads=2, text_width=192, queries=24, pool_heads=3, batch=3)
+
+
+def run_narrator_pool_golden(ref):
+    """Tower-side seam of the narrator, from the reference's own modules: SpaceTimeTransformer.forward_features(
+    cls_at_last=False) -> coca.CrossAttention(norm_context=True) on the repeated img_queries -> coca.LayerNorm, glued
+    exactly as VCLM_HF.encode_image does (narrator.py:63-90; narrator.py itself does not import on this container's
+    transformers, its 12 glue lines are restated here around the reference's modules)."""
+    c = NARRATOR
+    torch.manual_seed(0)
+    vis = ref.timesformer.SpaceTimeTransformer(
+        img_size=c['img'], patch_size=c['patch'], embed_dim=c['dim'], depth=c['depth'], num_heads=c['heads'],
+        num_frames=c['frames'], time_init='zeros', attention_style='frozen-in-time', ln_pre=True,
+        act_layer=ref.openai_model.QuickGELU, is_tanh_gating=False)
+    vis.head = nn.Identity()
+    vis.pre_logits = nn.Identity()
+    vis.fc = nn.Identity()
+
+    class Seam(nn.Module):                       # attribute names of VCLM_HF (narrator.py:44-49)
+        def __init__(self):
+            super().__init__()
+            self.visual = vis
+            self.img_queries = nn.Parameter(torch.empty(c['queries'], c['text_width']))
+            self.img_attn_pool = ref.coca.CrossAttention(dim=c['text_width'], context_dim=c['dim'], dim_head=64,
+                                                         heads=c['pool_heads'], norm_context=True)
+            self.img_attn_pool_norm = ref.coca.LayerNorm(c['text_width'])
+
+        def encode_image(self, image):           # narrator.py:73-90, SpaceTimeTransformer branch
+            image = image.permute(0, 2, 1, 3, 4).contiguous()
+            x = self.visual.forward_features(image, use_checkpoint=False, cls_at_last=False)
+            x = x.permute(0, 2, 1)
+            x = x.flatten(start_dim=2)
+            x = x.permute(0, 2, 1)
+            q = self.img_queries[None].expand(x.shape[0], -1, -1)
+            q = self.img_attn_pool(q, x)
+            return self.img_attn_pool_norm(q), x
+    seam = Seam()
+    shapes = {k: tuple(v.shape) for k, v in seam.state_dict().items()}
+    weights = O.procedural_weights(shapes, seed=13)
+    for k in shapes:
+        if k.endswith('.beta'):                  # the zero buffers stay zero (coca.py:31)
+            weights[k] = torch.zeros(shapes[k])
+    seam.load_state_dict(weights, strict=True)
+    seam.eval()
+    video, _ = O.synthetic_batch(c['batch'], c['frames'], c['img'], seed=77)
+    with torch.no_grad():
+        tokens, feats = seam.encode_image(video)
+        g = torch.Generator().manual_seed(5)
+        xq = torch.randn(2, 10, c['text_width'], generator=g)          # per-sample queries: the general module call
+        ctx = torch.randn(2, 37, c['dim'], generator=g)
+        pool_general = seam.img_attn_pool(xq, ctx)
+    torch.save({'config': c, 'shapes': shapes, 'weight_seed': 13, 'input_seed': 77, 'state_dict_keys': list(shapes),
+                'image_tokens': tokens, 'features': feats, 'pool_general': pool_general, 'pool_general_seed': 5},
+               os.path.join(GOLDEN, 'narrator_pool.pt'))
+    print('narrator_pool', tuple(tokens.shape), float(tokens.abs().mean()))
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     torch.set_num_threads(8)
@@ -329,6 +386,8 @@ def main():
         run_multirank_loss_golden()
     if not only or 'ssl' in only:
         run_ssl_loss_golden(ref)
+    if not only or 'narrator' in only:
+        run_narrator_pool_golden(ref)
 
 
 if __name__ == '__main__':

@@ -171,6 +171,42 @@ def vision_tower(video_bcthw: Tensor, w: Dict[str, Tensor], heads: int, prefix: 
 # --------------------------------------------------------------------------------------
 # text tower (OpenAI-CLIP Transformer)
 # --------------------------------------------------------------------------------------
+def coca_layer_norm(x: Tensor, gamma: Tensor) -> Tensor:
+    """coca.py:27-34: F.layer_norm with a learned gamma and a zero beta buffer (eps 1e-5)."""
+    return F.layer_norm(x, x.shape[-1:], gamma, torch.zeros_like(gamma), 1e-5)
+
+
+def mq_cross_attention_core(q: Tensor, kv: Tensor, heads: int) -> Tensor:
+    """coca.py:104-120 between to_q / to_kv and to_out: q [B,n,heads*64] (times dim_head^-0.5), ONE key/value head
+    kv [B,j,128] = k | v shared by all query heads, max-subtracted softmax over j."""
+    B, n, _ = q.shape
+    qh = q.reshape(B, n, heads, 64).permute(0, 2, 1, 3) * (64 ** -0.5)
+    k, v = kv.chunk(2, dim=-1)
+    sim = torch.einsum('bhid,bjd->bhij', qh, k)
+    attn = (sim - sim.amax(dim=-1, keepdim=True)).softmax(dim=-1)
+    out = torch.einsum('bhij,bjd->bhid', attn, v)
+    return out.permute(0, 2, 1, 3).reshape(B, n, heads * 64)
+
+
+def cross_attention_pool(x: Tensor, context: Tensor, w: Dict[str, Tensor], prefix: str, heads: int) -> Tensor:
+    """coca.CrossAttention.forward with norm_context=True, parallel_ff=False (coca.py:93-131)."""
+    xq = coca_layer_norm(x, w[prefix + 'norm.gamma'])
+    ctx = coca_layer_norm(context, w[prefix + 'context_norm.gamma'])
+    q = F.linear(xq, w[prefix + 'to_q.weight'])
+    kv = F.linear(ctx, w[prefix + 'to_kv.weight'])
+    return F.linear(mq_cross_attention_core(q, kv, heads), w[prefix + 'to_out.weight'])
+
+
+def narrator_encode_image(video_bcthw: Tensor, w: Dict[str, Tensor], vis_heads: int, pool_heads: int) -> Tensor:
+    """VCLM_HF.encode_image (narrator.py:63-90): all-token tower features -> attention pooling onto img_queries ->
+    img_attn_pool_norm."""
+    feats = vision_tower(video_bcthw, w, vis_heads, cls_at_last=False)
+    B = feats.shape[0]
+    q = w['img_queries'][None].expand(B, -1, -1)
+    pooled = cross_attention_pool(q, feats, w, 'img_attn_pool.', pool_heads)
+    return coca_layer_norm(pooled, w['img_attn_pool_norm.gamma'])
+
+
 def causal_attention_core(qkv: Tensor, heads: int) -> Tensor:
     """nn.MultiheadAttention core with the additive causal mask of CLIP.build_attention_mask
     (models.py:131-137; openai_model.py:196-198): softmax((q dh^-0.5) k^T + mask) v, packed

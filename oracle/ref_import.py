@@ -112,6 +112,7 @@ def load_reference():
         ns.loss = importlib.import_module("lavila.models.loss")
         ns.distributed_utils = importlib.import_module("lavila.models.distributed_utils")
         ns.utils = importlib.import_module("lavila.models.utils")
+        ns.coca = importlib.import_module("lavila.models.coca")          # narrator pooling (imports as is)
         ns.models = importlib.import_module("lavila.models.models")
         assert ns.models.__file__.startswith(REFERENCE_ROOT), ns.models.__file__
     finally:

@@ -369,3 +369,34 @@ def test_gemm_tile_counter_reply_register_is_untouched_in_isa(tmp_path):
         for i in reqs:
             reg = re.search(r' (v\d+),', body[i]).group(1)
             assert body[i + 1] == 's_waitcnt vmcnt(0)' and re.fullmatch(r'ds_write_b32 v\d+, ' + reg, body[i + 2]), body[i:i + 3]
+
+
+def test_narrator_seam_state_dict_matches_reference_names():
+    """lavila_amd.narrator.VCLM_HF owns `visual.*`, `img_queries`, `img_attn_pool.*`, `img_attn_pool_norm.*` under the
+    reference's names (narrator.py:44-49, coca.py:27-31,76-82), beta buffers included, so those entries of a VCLM_*
+    checkpoint load unchanged; decoding stays out of scope and says so."""
+    import contextlib
+    import io
+    from lavila.models.openai_model import QuickGELU
+    from lavila.models.timesformer import SpaceTimeTransformer
+    from lavila_amd.narrator import VCLM_HF, CrossAttention
+    fx = load_golden('narrator_pool.pt')
+    c = fx['config']
+    with contextlib.redirect_stdout(io.StringIO()):
+        vis = SpaceTimeTransformer(img_size=c['img'], patch_size=c['patch'], embed_dim=c['dim'], depth=c['depth'],
+                                   num_heads=c['heads'], num_frames=c['frames'], time_init='zeros',
+                                   attention_style='frozen-in-time', ln_pre=True, act_layer=QuickGELU)
+    vis.head = vis.pre_logits = vis.fc = torch.nn.Identity()
+    m = VCLM_HF(vision_width=c['dim'], vision_model=vis, text_width=c['text_width'], text_decoder=None,
+                num_img_queries=c['queries'], dim_head=64, heads=c['pool_heads'])
+    sd = m.state_dict()
+    assert list(sd.keys()) == fx['state_dict_keys']
+    assert {k: tuple(v.shape) for k, v in sd.items()} == fx['shapes']
+    assert [k for k, _ in m.named_buffers()] == ['img_attn_pool.norm.beta', 'img_attn_pool.context_norm.beta',
+                                                 'img_attn_pool_norm.beta']
+    with pytest.raises(NotImplementedError):
+        m.generate(None, None)
+    with pytest.raises(NotImplementedError):
+        m(torch.zeros(1, 3, 2, 32, 32), torch.zeros(1, 8, dtype=torch.long))
+    with pytest.raises(NotImplementedError):
+        CrossAttention(64, parallel_ff=True)

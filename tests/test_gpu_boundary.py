@@ -246,3 +246,95 @@ def test_hip_graph_replay_after_weight_update():
     torch.cuda.synchronize()
     assert not torch.equal(before, after)
     assert torch.equal(after, eager)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# narrator, tower-side seam: VCLM_HF.encode_image on the HIP path
+# ----------------------------------------------------------------------------------------------------------------------
+def _narrator(fx):
+    from lavila.models.openai_model import QuickGELU
+    from lavila.models.timesformer import SpaceTimeTransformer
+    from lavila_amd.narrator import VCLM_HF
+    c = fx['config']
+    with contextlib.redirect_stdout(io.StringIO()):
+        vis = SpaceTimeTransformer(img_size=c['img'], patch_size=c['patch'], embed_dim=c['dim'], depth=c['depth'],
+                                   num_heads=c['heads'], num_frames=c['frames'], time_init='zeros',
+                                   attention_style='frozen-in-time', ln_pre=True, act_layer=QuickGELU)
+    vis.head = vis.pre_logits = vis.fc = torch.nn.Identity()
+    m = VCLM_HF(vision_width=c['dim'], vision_model=vis, text_width=c['text_width'], text_decoder=None,
+                num_img_queries=c['queries'], dim_head=64, heads=c['pool_heads'])
+    w = O.procedural_weights(fx['shapes'], seed=fx['weight_seed'])
+    for k in fx['shapes']:
+        if k.endswith('.beta'):
+            w[k] = torch.zeros(fx['shapes'][k])
+    m.load_state_dict(w, strict=True)
+    return m.to(DEV).eval(), c
+
+
+@pytest.mark.parametrize('mode', ['f32', 'bf16', 'half'])
+def test_narrator_encode_image_matches_reference(mode):
+    """narrator.py:63-90 on the reference's own outputs (tests/golden/narrator_pool.pt): float32 within 1e-3, bf16
+    autocast and the --use-half recipe of main_infer_narrator.py (docs/PRETRAIN.md:85-91) within the 2-block bf16 bound."""
+    fx = load_golden('narrator_pool.pt')
+    m, c = _narrator(fx)
+    video, _ = O.synthetic_batch(c['batch'], c['frames'], c['img'], seed=fx['input_seed'])
+    v = video.to(DEV)
+    with torch.no_grad():
+        if mode == 'f32':
+            got = m.encode_image(v)
+            assert got.dtype == torch.float32
+            torch.testing.assert_close(got.cpu(), fx['image_tokens'], atol=1e-3, rtol=1e-3)
+        elif mode == 'bf16':
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                got = m.encode_image(v)
+            torch.testing.assert_close(got.float().cpu(), fx['image_tokens'], atol=4e-2, rtol=4e-2)
+        else:
+            got = m.half().encode_image(v.half())
+            assert got.dtype == torch.float16
+            torch.testing.assert_close(got.float().cpu(), fx['image_tokens'], atol=4e-2, rtol=4e-2)
+    assert got.shape == (c['batch'], c['queries'], c['text_width'])
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('B,NQ,H,T', [(2, 10, 3, 37), (3, 256, 12, 785), (1, 5, 1, 1), (2, 33, 2, 130)])
+def test_mq_cross_attention_core(dt, B, NQ, H, T):
+    """lvl_mq_cross_attn_fwd against oracle.mq_cross_attention_core (coca.py:104-120): per-sample and batch-shared
+    queries, key counts that are not multiples of the 8-key blocks / 64-key chunks, one key."""
+    from lavila_amd.narrator import mq_cross_attention
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    q = torch.randn(B, NQ, H * 64, generator=g)
+    kv = torch.randn(B, T, 128, generator=g)
+    qd, kvd = q.to(DEV).to(dt), kv.to(DEV).to(dt)
+    want = O.mq_cross_attention_core(qd.float().cpu(), kvd.float().cpu(), H)
+    got = mq_cross_attention(qd, kvd, H)
+    tol = dict(atol=2e-5, rtol=1e-4) if dt == torch.float32 else dict(atol=2e-2, rtol=2e-2)
+    torch.testing.assert_close(got.float().cpu(), want, **tol)
+    shared = mq_cross_attention(qd[0], kvd, H)                       # [NQ, H*64]: the same queries for every sample
+    want_s = O.mq_cross_attention_core(qd[:1].float().cpu().expand(B, -1, -1), kvd.float().cpu(), H)
+    torch.testing.assert_close(shared.float().cpu(), want_s, **tol)
+
+
+def test_narrator_general_cross_attention_and_inference_only():
+    from lavila_amd._cabi import HipExtensionError
+    fx = load_golden('narrator_pool.pt')
+    m, c = _narrator(fx)
+    g = torch.Generator().manual_seed(fx['pool_general_seed'])
+    xq = torch.randn(2, 10, c['text_width'], generator=g)
+    ctx = torch.randn(2, 37, c['dim'], generator=g)
+    with torch.no_grad():
+        got = m.img_attn_pool(xq.to(DEV), ctx.to(DEV))
+    torch.testing.assert_close(got.cpu(), fx['pool_general'], atol=1e-3, rtol=1e-3)
+    out = m.img_attn_pool(xq.to(DEV).requires_grad_(True), ctx.to(DEV))
+    with pytest.raises(HipExtensionError):
+        out.sum().backward()
+
+
+@pytest.mark.parametrize('N,K', [(768, 768), (2304, 768), (100, 72), (65, 130), (512, 2048)])
+def test_cast_transpose(N, K):
+    """lvl_cast_transpose: f32 master [N,K] -> bf16 copy and bf16 transposed copy, bit-equal to torch's rounding."""
+    from lavila_amd import _cabi as C
+    src = torch.randn(N, K, device=DEV, generator=torch.Generator(device=DEV).manual_seed(N + K))
+    w = torch.empty(N, K, dtype=torch.bfloat16, device=DEV)
+    wt = torch.empty(K, N, dtype=torch.bfloat16, device=DEV)
+    C.check(C.lib().lvl_cast_transpose(C.ptr(src), C.ptr(w), C.ptr(wt), N, K, C.stream_ptr()), 'lvl_cast_transpose')
+    assert torch.equal(w, src.bfloat16()) and torch.equal(wt, src.bfloat16().t().contiguous())

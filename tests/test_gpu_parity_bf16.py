@@ -231,12 +231,14 @@ def test_wgrad_chunk_schedule_equals_static_and_resets_its_counters(M, N, K):
         assert int(sched.abs().sum()) == 0
 
 
-@pytest.mark.parametrize('mod', [2, 3, 7])
+@pytest.mark.parametrize('mod', [3, 5, 7])
 def test_take_over_paths_with_late_workgroups(mod):
     """lvl_debug_late_workgroups: every mod-th workgroup of the persistent GEMMs acts as if its compute unit had been
     held by another kernel (an RCCL channel) for the whole launch. The tile queue (lvl_linear_tn) and the chunk stealing
     among the splits of a tile (lvl_linear_wgrad) must still produce every output: exact on small-integer operands,
-    within float32 summation-order noise of the static schedule on random data, counters zeroed."""
+    within float32 summation-order noise of the static schedule on random data, counters zeroed.
+    (mod must not divide 8: the hook makes workgroups NEVER work, and the tile queues are per XCD = blockIdx % 8 -- a
+    whole XCD that never runs has nobody to serve its queue, whereas a really late workgroup serves it when it starts.)"""
     from lavila_amd import _cabi as C
     lib = C.lib()
     assert lib.lvl_debug_late_workgroups(1) != 0

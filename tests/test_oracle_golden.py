@@ -150,3 +150,25 @@ def test_ssl_clip_loss_matches_reference():
             assert abs(a - scale.grad.item()) < 1e-6
         for a in dp:
             assert abs(a - pparam.grad.item()) < 1e-6
+
+
+def test_narrator_pool_oracle_matches_reference():
+    """oracle.narrator_encode_image / cross_attention_pool against the reference's own coca.CrossAttention + LayerNorm on
+    top of its SpaceTimeTransformer.forward_features(cls_at_last=False) (tests/golden/narrator_pool.pt)."""
+    fx = load_golden('narrator_pool.pt')
+    c = fx['config']
+    w = O.procedural_weights(fx['shapes'], seed=fx['weight_seed'])
+    for k in fx['shapes']:
+        if k.endswith('.beta'):
+            w[k] = torch.zeros(fx['shapes'][k])
+    video, _ = O.synthetic_batch(c['batch'], c['frames'], c['img'], seed=fx['input_seed'])
+    with torch.no_grad():
+        feats = O.vision_tower(video, w, c['heads'], cls_at_last=False)
+        tokens = O.narrator_encode_image(video, w, c['heads'], c['pool_heads'])
+        g = torch.Generator().manual_seed(fx['pool_general_seed'])
+        xq = torch.randn(2, 10, c['text_width'], generator=g)
+        ctx = torch.randn(2, 37, c['dim'], generator=g)
+        general = O.cross_attention_pool(xq, ctx, w, 'img_attn_pool.', c['pool_heads'])
+    torch.testing.assert_close(feats, fx['features'], atol=1e-5, rtol=1e-4)
+    torch.testing.assert_close(tokens, fx['image_tokens'], atol=1e-5, rtol=1e-4)
+    torch.testing.assert_close(general, fx['pool_general'], atol=1e-5, rtol=1e-4)
