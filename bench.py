@@ -100,6 +100,15 @@ class KernelTimer:
         return sum(s.elapsed_time(e) for s, e in self.pairs) / len(self.pairs)
 
 
+def _traffic_file(stem):
+    """Newest committed PMC traffic summary of a kernel family (profiles/rNN_<stem>, tools/pmc_bench_traffic.sh)."""
+    for rnd in ('r03', 'r02'):
+        path = os.path.join(ROOT, 'profiles', f'{rnd}_{stem}')
+        if os.path.isfile(path):
+            return path
+    return os.path.join(ROOT, 'profiles', 'r03_' + stem)
+
+
 def build_model(args, device):
     import contextlib
     import io
@@ -298,7 +307,7 @@ def main():
         kms = timer.mean_ms()
         roofline_hbm = None
         traffic = None
-        tfile = os.path.join(ROOT, 'profiles', 'r02_traffic_space_fwd.json')   # PMC pass of the same kernel/shape
+        tfile = _traffic_file('traffic_space_fwd.json')   # PMC pass of the same kernel/shape
         if os.path.isfile(tfile) and (B, Fr, N, D) == (256, 4, 196, 768) and amp is not None:
             traffic = json.load(open(tfile))['traffic_bytes_per_launch']
         if kms:
@@ -311,7 +320,7 @@ def main():
             if not tm.pairs:
                 return None
             traffic = note = None
-            path = os.path.join(ROOT, 'profiles', tfile)
+            path = _traffic_file(tfile)
             if os.path.isfile(path) and (B, Fr, N, D) == (256, 4, 196, 768):
                 tj = json.load(open(path))
                 traffic, note = tj['traffic_bytes_per_launch'], tj.get('note')
@@ -328,10 +337,10 @@ def main():
                                               'source': 'profiles/r02_mfma_ceiling_microbench.txt'}}
         # dominant kernel: the forward / input-gradient GEMM, aggregated over all its launches in the timed region
         roofline = mfma_roofline(gtimer, 'lvl_linear_tn (gemm_tn_kernel<0|1|2>, all video-tower forward and '
-                                 'input-gradient GEMMs incl. their fused epilogues)', 'r02_traffic_gemm_tn.json') \
+                                 'input-gradient GEMMs incl. their fused epilogues)', 'traffic_gemm_tn.json') \
             or roofline_hbm
         roofline_wgrad = mfma_roofline(wtimer, 'lvl_linear_wgrad (wgrad_kernel<4,2,6,6,false> + its partial-tile '
-                                       'reduction, all video-tower weight gradients)', 'r02_traffic_wgrad.json')
+                                       'reduction, all video-tower weight gradients)', 'traffic_wgrad.json')
         tower = 'TSF-L/14' if 'LARGE' in args.model else 'TSF-B/16'
         line = {
             'metric': f'clip-text pairs/s (whole node), {tower} {Fr}x{img}^2 + CLIP text tower, fwd+loss+bwd+AdamW',
@@ -347,6 +356,8 @@ def main():
                        # (models._longest_caption), which returns only when the previous step has drained
                        'host_enqueue_ms_per_step': round(1e3 * host_s / args.steps, 1),
                        'text_trim_off': no_trim,
+                       'tile_schedule': 'dynamic (device tile / chunk counters)' if ops.dynamic_tiles()
+                                        else 'static (single GPU; the counters switch on inside a process group)',
                        'parity_note': 'benched path = bf16 MFMA kernels: bit-exact on integer / one-hot operands '
                                       '(tests/test_gpu_parity_bf16.py); TSF-B step vs the f32 oracle: max |d logit| 0.015, '
                                       'embeddings 1.0e-2, aggregate gradient 3.7e-2 relative L2 (bf16-inherent; 0.6e-2 / '

@@ -49,7 +49,6 @@
 //     A compute unit that another kernel holds (an RCCL channel during the gradient all-reduce) therefore costs
 //     the launch one tile's worth of throughput, not a static range of tiles: its workgroup starts late, finds
 //     the queues drained and leaves. The last workgroup out zeroes the counters again.
-#include <stdlib.h>
 #include <type_traits>
 
 #include "common.h"
@@ -587,14 +586,6 @@ int launch_tn(const void* x, const void* w, const float* bias, void* y, void* au
   const int64_t ntiles = tiles_m * tiles_n;
   if (ntiles > 0x7fffffff) return lvl_fail(LVL_EINVAL, "linear_tn: too many tiles");
   int grid = (int)(ntiles < num_cus() ? ntiles : num_cus());
-  // A SHORT problem (the text tower: 8192 rows, 64-256 tiles) does not take every compute unit for one tile each: its
-  // persistent workgroups walk ~4 tiles on a quarter of the chip, so that the other tower's kernels, which run beside
-  // it on their own stream, are not held up behind a chip-wide launch (LAVILA_SMALL_GRID=0: one tile per CU as before).
-  static const bool small_grid = [] { const char* e = getenv("LAVILA_SMALL_GRID"); return e && e[0] == '1'; }();
-  if (small_grid && ntiles <= 2 * num_cus() && grid > 32) {
-    grid = (int)(ntiles / 4);
-    if (grid < 32) grid = 32;
-  }
   if (grid >= 8) grid -= grid % 8;          // whole XCD rounds (the kernel maps workgroup b to XCD b % 8)
   if (K / BK < DYN_MIN_NB) sched = nullptr; // too few K blocks per tile for the counter hand-off: static schedule
   hipLaunchKernelGGL((gemm_tn_kernel<EPI>), dim3((unsigned)grid), dim3(512), shmem, st, (const uint16_t*)x,

@@ -275,11 +275,23 @@ def linear_wgrad_raw(dy, x, want_dbias: bool, ws_floats: int = -1):
 # lvl_linear_wgrad's chunk-counter blocks (1024 words) come from a second pool of the same kind.
 _SCHED_BLOCKS = {16: 4096, 1024: 512}
 _sched_pools = {}
-DYNAMIC_TILES = os.environ.get('LAVILA_DYNAMIC_TILES', '1') != '0'
+# LAVILA_DYNAMIC_TILES: '1' always, '0' never, unset = when this process is one rank of a multi-GPU job (an initialised
+# torch.distributed group of more than one rank: RCCL's channel kernels then share the GPU with the step -- that is
+# the situation the counters are for; measured with 16 CUs held by another kernel: -5..8 % instead of -26..30 %,
+# profiles/r03_cu_contention.txt). A single-GPU run keeps the static ranges: the counters cost 0.8 % of the step
+# (the one synchronous hand-out per launch and the claims' round trips).
+DYNAMIC_TILES = {'1': True, '0': False}.get(os.environ.get('LAVILA_DYNAMIC_TILES', ''), None)
+
+
+def dynamic_tiles() -> bool:
+    if DYNAMIC_TILES is not None:
+        return DYNAMIC_TILES
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
 def sched_block(device, words=16):
-    if not DYNAMIC_TILES:
+    if not dynamic_tiles():
         return None
     if torch.cuda.is_current_stream_capturing():
         return torch.zeros(words, dtype=torch.int32, device=device)

@@ -271,11 +271,13 @@ def test_take_over_paths_with_late_workgroups(mod):
         assert lib.lvl_debug_late_workgroups(0) == 0
 
 
-def test_dynamic_tile_schedule_on_concurrent_streams():
+def test_dynamic_tile_schedule_on_concurrent_streams(monkeypatch):
     """The two towers launch lvl_linear_tn on two streams at once (models.py: text tower on the side stream): each
     stream draws its counter blocks from its own pool (ops.sched_block), results stay exact while the launches overlap."""
     from lavila_amd import _cabi as C
     from lavila_amd import ops
+    monkeypatch.setattr(ops, 'DYNAMIC_TILES', True)       # (default: only inside a multi-rank process group)
+    assert ops.sched_block(torch.device(DEV, 0)) is not None
     g = torch.Generator().manual_seed(7)
     M, N, K = 40000, 768, 768
     xi = torch.randint(-2, 3, (M, K), generator=g).float()

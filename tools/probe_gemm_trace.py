@@ -7,7 +7,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-SO = os.path.join(ROOT, 'lavila_amd', 'lib', 'libgemm_trace%s.so' % os.environ.get('GM_VARIANT', ''))
+SO = os.path.join(ROOT, 'tools', 'probes', 'libgemm_trace%s.so' % os.environ.get('GM_VARIANT', ''))   # probe builds stay out of the product lib dir
 if '--build' in sys.argv:
     src = os.path.join(ROOT, 'lavila_amd', 'csrc')
     subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
