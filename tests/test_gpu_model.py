@@ -226,5 +226,17 @@ def test_block_forward_backward_is_hip_graph_capturable():
     got = (out_static.clone(), gx_static.clone(), gw_static.clone())
     out_e = step()
     torch.cuda.synchronize()
-    assert torch.equal(got[0], out_e) and torch.equal(got[1], x_static.grad)
-    assert torch.equal(got[2], blk.mlp.fc1.weight.grad)
+    assert torch.equal(got[0], out_e)
+    # input gradient: the cls token's d(q / k / v) of the space attention are summed over the frames with float32
+    # atomics (attn_space_bwd.hip), whose order is not fixed. A last-bit difference there reaches the cls row directly
+    # and -- through the cls query of the TIME attention, which attends to every token (timesformer.py:116-119) -- the
+    # dK / dV of any token, where it occasionally flips one bf16 rounding. So: every row within one bf16 ulp-scale
+    # tolerance, and all but a handful of patch rows bit-equal (observed: 0 rows in five runs out of six, 4 of 1570 in
+    # the sixth; demanding bit equality made this test fail about one run in five).
+    bad = (got[1] != x_static.grad).any(-1).nonzero().tolist()
+    patch_bad = [bt for bt in bad if bt[1] != 0]
+    assert len(patch_bad) <= 16, f'input gradient differs on {len(patch_bad)} patch rows: {patch_bad[:8]}'
+    torch.testing.assert_close(got[1].float(), x_static.grad.float(), atol=2e-2, rtol=2e-2)
+    nbad = int((got[2] != blk.mlp.fc1.weight.grad).sum())
+    assert nbad == 0, f'fc1 weight gradient differs in {nbad} elements'
+
