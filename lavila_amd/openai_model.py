@@ -77,6 +77,25 @@ class ResidualAttentionBlock(nn.Module):
         return x1, ops.mlp_quickgelu(h2, self.mlp.c_fc.weight, self.mlp.c_fc.bias, self.mlp.c_proj.weight), \
             self.mlp.c_proj.bias
 
+    def chain_rows(self, res, pend, pend_bias, rows):
+        """The LAST block when only one position per caption is read afterwards (the EOT row, models.py:158-160): the
+        attention runs on every position (row `rows[b]` attends to all positions before it), the output projection, ln_2
+        and the MLP on the B selected rows only -- exact, see SpaceTimeBlock.chain_cls. Returns [B, W] tensors."""
+        l1, l2, at = self.ln_1, self.ln_2, self.attn
+        if pend is None:
+            x = res
+            h = ops.layer_norm(x, l1.weight, l1.bias, l1.eps)
+        else:
+            x, h = ops.add_layer_norm(res, pend, pend_bias, l1.weight, l1.bias, l1.eps, keep_sum=True)
+        o = ops.causal_attention(ops.linear(h, at.in_proj_weight, at.in_proj_bias.detach()), at.num_heads,
+                                 bias=at.in_proj_bias)
+        idx = torch.arange(x.shape[0], device=x.device)
+        y = ops.linear(o[idx, rows].contiguous(), at.out_proj.weight)
+        x1, h2 = ops.add_layer_norm(x[idx, rows].contiguous(), y, at.out_proj.bias, l2.weight, l2.bias, l2.eps,
+                                    keep_sum=True)
+        return x1, ops.mlp_quickgelu(h2, self.mlp.c_fc.weight, self.mlp.c_fc.bias, self.mlp.c_proj.weight), \
+            self.mlp.c_proj.bias
+
     def forward(self, x: torch.Tensor, use_checkpoint=False):
         """Reference signature: x is [L, N, D] (openai_model.py:206-216)."""
         xb = x.permute(1, 0, 2).contiguous()
@@ -94,19 +113,26 @@ class Transformer(nn.Module):
     def forward_batch_major(self, x, final_ln, use_checkpoint=False, rows=None):
         """x: [B, L, W]. Runs all blocks on the fused chain and applies `final_ln` (CLIP.ln_final). If `rows`
         ([B] int64) is given only those token rows are normalised and returned ([B, W])."""
+        from .timesformer import CLS_ONLY_LAST_BLOCK
         res, pend, pb = x.contiguous(), None, None
-        for blk in self.resblocks:
-            if use_checkpoint:
+        last = len(self.resblocks) - 1
+        for i, blk in enumerate(self.resblocks):
+            if rows is not None and i == last and CLS_ONLY_LAST_BLOCK:      # only the selected rows leave the tower
+                if use_checkpoint:
+                    res, pend, pb = checkpoint.checkpoint(blk.chain_rows, res, pend, pb, rows, use_reentrant=False)
+                else:
+                    res, pend, pb = blk.chain_rows(res, pend, pb, rows)
+            elif use_checkpoint:
                 res, pend, pb = checkpoint.checkpoint(blk.chain, res, pend, pb, use_reentrant=False)
             else:
                 res, pend, pb = blk.chain(res, pend, pb)
         if rows is not None:
             idx = torch.arange(res.shape[0], device=res.device)
-            r = res[idx, rows].contiguous()
+            r = res if res.dim() == 2 else res[idx, rows].contiguous()
             if pend is None:
                 return ops.layer_norm(r, final_ln.weight, final_ln.bias, final_ln.eps)
-            return ops.add_layer_norm(r, pend[idx, rows].contiguous(), pb, final_ln.weight, final_ln.bias,
-                                      final_ln.eps, keep_sum=False)[1]
+            p = pend if pend.dim() == 2 else pend[idx, rows].contiguous()
+            return ops.add_layer_norm(r, p, pb, final_ln.weight, final_ln.bias, final_ln.eps, keep_sum=False)[1]
         if pend is None:
             return ops.layer_norm(res, final_ln.weight, final_ln.bias, final_ln.eps)
         return ops.add_layer_norm(res, pend, pb, final_ln.weight, final_ln.bias, final_ln.eps, keep_sum=False)[1]

@@ -22,6 +22,10 @@ import torch.utils.checkpoint as checkpoint
 from . import ops
 
 
+# LAVILA_CLS_LAST=0 computes the whole last block as the reference does (A/B and debugging)
+CLS_ONLY_LAST_BLOCK = __import__('os').environ.get('LAVILA_CLS_LAST', '1') != '0'
+
+
 def to_2tuple(x):
     return tuple(x) if isinstance(x, (tuple, list)) else (x, x)
 
@@ -263,6 +267,33 @@ class SpaceTimeBlock(nn.Module):
             return x1, ops.mlp_quickgelu(h2, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight), self.mlp.fc2.bias
         return x1, ops.linear(self.mlp.hidden(h2), self.mlp.fc2.weight), self.mlp.fc2.bias
 
+    def chain_cls(self, res, pend, pend_bias, frames, n_per_frame):
+        """The LAST block when only the cls row of its output is read (`norm(x)[:, 0]`, timesformer.py:377): same
+        arithmetic as `chain`, restricted to what reaches that row. Time attention, norm1 and the space qkv run on every
+        token (the cls query of the space attention reads the keys / values of all of them); the space attention's
+        output projection, norm2 and the whole MLP -- 2/3 of a block's flops -- run on the B cls rows only. Exact, like
+        the caption trim of the text tower: the skipped rows feed nothing (their gradient is exactly zero in the
+        reference, too). Returns (x1, y, y_bias) of the cls rows, [B, D] each."""
+        n3, n1, n2 = self.norm3, self.norm1, self.norm2
+        if pend is None:
+            x = res
+            h3 = ops.layer_norm(x, n3.weight, n3.bias, n3.eps)
+        else:
+            x, h3 = ops.add_layer_norm(res, pend, pend_bias, n3.weight, n3.bias, n3.eps, keep_sum=True)
+        ta, sa = self.timeattn, self.attn
+        o_t = ta.core(h3, 'time', frames, n_per_frame)
+        if hasattr(self, 'alpha_timeattn'):
+            y_t, b_t = torch.tanh(self.alpha_timeattn).to(o_t.dtype) * ops.linear(o_t, ta.proj.weight, ta.proj.bias), None
+        else:
+            y_t, b_t = ops.linear(o_t, ta.proj.weight), ta.proj.bias
+        x, h1 = ops.add_layer_norm_pass(x, y_t, b_t, n1.weight, n1.bias, n1.eps)
+        o_s = sa.core(h1, 'space', frames, n_per_frame)
+        y_s = ops.linear(o_s[:, 0].contiguous(), sa.proj.weight)                 # [B, D]
+        x1, h2 = ops.add_layer_norm(x[:, 0].contiguous(), y_s, sa.proj.bias, n2.weight, n2.bias, n2.eps, keep_sum=True)
+        if self.mlp._fused_act:
+            return x1, ops.mlp_quickgelu(h2, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight), self.mlp.fc2.bias
+        return x1, ops.linear(self.mlp.hidden(h2), self.mlp.fc2.weight), self.mlp.fc2.bias
+
     def forward(self, x, einops_from_space, einops_to_space, einops_from_time, einops_to_time,
                 time_n, space_f, use_checkpoint=False):
         """Reference signature (timesformer.py:173-174); materialises the block output."""
@@ -382,23 +413,26 @@ class SpaceTimeTransformer(nn.Module):
         x = self.pos_drop(x)
         res, pend, pend_b = x, None, None
         hook = after_block
+        last = len(self.blocks) - 1
         for i, blk in enumerate(self.blocks):
+            # the last block of a cls-pooled forward only has to produce its cls rows (SpaceTimeBlock.chain_cls)
+            fn = blk.chain_cls if (cls_at_last and i == last and CLS_ONLY_LAST_BLOCK and not blk._dropping()
+                                   and blk.attention_style == 'frozen-in-time') else blk.chain
             if use_checkpoint:
-                res, pend, pend_b = checkpoint.checkpoint(blk.chain, res, pend, pend_b, frames, n,
-                                                          use_reentrant=False)
+                res, pend, pend_b = checkpoint.checkpoint(fn, res, pend, pend_b, frames, n, use_reentrant=False)
             else:
-                res, pend, pend_b = blk.chain(res, pend, pend_b, frames, n)
+                res, pend, pend_b = fn(res, pend, pend_b, frames, n)
             if hook is not None and i == hook[0]:
                 hook[1]()
         nm = self.norm
         if cls_at_last:
             # only row 0 of every sample feeds the output: final residual add + LayerNorm on [B, D]
-            r0 = res[:, 0].contiguous()
+            r0 = res if res.dim() == 2 else res[:, 0].contiguous()
             if pend is None:
                 out = ops.layer_norm(r0, nm.weight, nm.bias, nm.eps)
             else:
-                _, out = ops.add_layer_norm(r0, pend[:, 0].contiguous(), pend_b, nm.weight, nm.bias, nm.eps,
-                                            keep_sum=False)
+                p0 = pend if pend.dim() == 2 else pend[:, 0].contiguous()
+                _, out = ops.add_layer_norm(r0, p0, pend_b, nm.weight, nm.bias, nm.eps, keep_sum=False)
             return self.pre_logits(out)
         if pend is None:
             return ops.layer_norm(res, nm.weight, nm.bias, nm.eps)
