@@ -174,6 +174,17 @@ int lvl_ssl_clip_loss_bwd(const void* img_all, const void* txt_all, const int32_
                           int B, int G, int E, int row0, float* dimg, float* dtxt, int dtype,
                           void* stream);
 
+/* ---- cls-only attention (last block of a cls-pooled forward) ---------------------------------------------------
+ * When only `norm(x)[:, 0]` leaves the tower (SpaceTimeTransformer.forward, timesformer.py:377,384-390) the last
+ * block's space attention is needed for its cls query alone, which attends to all T tokens (timesformer.py:116-119):
+ *   out[b,h,:] = softmax_j(0.125 * q[b,h,:] . k[b,j,h,:]) v[b,j,h,:]
+ * q: [B, H*64] (the q third of the qkv Linear applied to the cls rows), kv: [B, T, 2*H*64] (its k and v thirds applied
+ * to all rows), out: [B, H*64], lse: [B, H] f32 (natural log of the softmax denominator of the scaled scores).
+ * Backward: dq [B, H*64] f32, dkv [B, T, 2*H*64] dtype, from dout [B, H*64]. */
+int lvl_cls_attn_fwd(const void* q, const void* kv, void* out, float* lse, int B, int T, int H, int dtype, void* stream);
+int lvl_cls_attn_bwd(const void* q, const void* kv, const void* out, const void* dout, const float* lse, float* dq,
+                     void* dkv, int B, int T, int H, int dtype, void* stream);
+
 /* ---- narrator seam: multi-query cross-attention pooling (inference) ------------------------------------------
  * The core of coca.py's CrossAttention (lavila/models/coca.py:93-123) between to_q / to_kv and to_out, as
  * VCLM_HF.encode_image runs it on the tower's token features (narrator.py:44-49,88-90): NQ x H query rows of 64

@@ -44,6 +44,8 @@ SIGNATURES = {
     'lvl_linear_tn': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
     'lvl_linear_wgrad': (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P]),
     'lvl_cast_transpose': (_I, [_P, _P, _P, _I, _I, _P]),
+    'lvl_cls_attn_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    'lvl_cls_attn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'lvl_mq_cross_attn_fwd': (_I, [_P, _L, _P, _P, _I, _I, _I, _I, _I, _P]),
     'lvl_qkv_bias_grad': (_I, [_P, _P, _P, _P, _L, _I, _I, _P]),
 }

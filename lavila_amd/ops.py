@@ -651,6 +651,53 @@ def divided_attention(qkv, frames, n_per_frame, heads, mode, bias=None):
     return _DividedAttnFn.apply(lowp(qkv), bias, frames, n_per_frame, heads, m)
 
 
+class _ClsAttnFn(torch.autograd.Function):
+    """out[b] = attention of the cls query over all tokens (lvl_cls_attn_fwd / _bwd). `bias`: the qkv Linear's bias
+    (its q third was added to `q`, its k | v thirds to `kv` by the caller's Linears on detached slices); its gradient
+    follows from the softmax identities of _qkv_bias_grad: sum_j dk_j = 0, sum_j dv_j = dout, plus sum_b dq."""
+
+    @staticmethod
+    def forward(ctx, q, kv, bias, heads):
+        q, kv = q.contiguous(), kv.contiguous()
+        C.require_device(q, kv)
+        B, T, D2 = kv.shape
+        D = D2 // 2
+        if D != heads * 64 or tuple(q.shape) != (B, D):
+            raise C.HipExtensionError(f'cls attention: q {tuple(q.shape)} / kv {tuple(kv.shape)} inconsistent with '
+                                      f'heads={heads} (head dim must be 64)')
+        out = torch.empty(B, D, dtype=kv.dtype, device=kv.device)
+        lse = torch.empty(B, heads, dtype=torch.float32, device=kv.device)
+        C.check(C.lib().lvl_cls_attn_fwd(C.ptr(q), C.ptr(kv), C.ptr(out), C.ptr(lse), B, T, heads, C.dtype_code(kv),
+                                         C.stream_ptr()), 'lvl_cls_attn_fwd')
+        ctx.save_for_backward(q, kv, out, lse)
+        ctx.cfg = (heads, q.dtype, None if bias is None else bias.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, kv, out, lse = ctx.saved_tensors
+        heads, qdt, bdt = ctx.cfg
+        B, T, D2 = kv.shape
+        dout = dout.contiguous()
+        dq = torch.empty(B, D2 // 2, dtype=torch.float32, device=kv.device)
+        dkv = torch.empty_like(kv)
+        C.check(C.lib().lvl_cls_attn_bwd(C.ptr(q), C.ptr(kv), C.ptr(out), C.ptr(dout), C.ptr(lse), C.ptr(dq), C.ptr(dkv),
+                                         B, T, heads, C.dtype_code(kv), C.stream_ptr()), 'lvl_cls_attn_bwd')
+        db = None
+        if bdt is not None and ctx.needs_input_grad[2]:
+            zero = dq.new_zeros(D2 // 2)
+            db = torch.cat([dq.sum(0), zero, dout.sum(0, dtype=torch.float32)]).to(bdt)
+        return dq.to(qdt), dkv, db, None
+
+
+def cls_attention(q, kv, heads, bias=None):
+    """q [B, D] (cls rows), kv [B, T, 2D] -> [B, D]; see _ClsAttnFn."""
+    q, kv = lowp(q), lowp(kv)
+    if q.dtype != kv.dtype:
+        q = q.to(kv.dtype)
+    return _ClsAttnFn.apply(q, kv, bias, heads)
+
+
 class _CausalAttnFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, qkv, bias, heads):

@@ -269,9 +269,10 @@ class SpaceTimeBlock(nn.Module):
 
     def chain_cls(self, res, pend, pend_bias, frames, n_per_frame):
         """The LAST block when only the cls row of its output is read (`norm(x)[:, 0]`, timesformer.py:377): same
-        arithmetic as `chain`, restricted to what reaches that row. Time attention, norm1 and the space qkv run on every
-        token (the cls query of the space attention reads the keys / values of all of them); the space attention's
-        output projection, norm2 and the whole MLP -- 2/3 of a block's flops -- run on the B cls rows only. Exact, like
+        arithmetic as `chain`, restricted to what reaches that row. Time attention, norm1 and the k | v thirds of the space
+        qkv run on every token (the cls query of the space attention reads the keys / values of all of them); the q
+        third, the attention itself (lvl_cls_attn_*: one query per head), its output projection, norm2 and the whole MLP
+        -- 2/3 of a block's flops -- run on the B cls rows only. Exact, like
         the caption trim of the text tower: the skipped rows feed nothing (their gradient is exactly zero in the
         reference, too). Returns (x1, y, y_bias) of the cls rows, [B, D] each."""
         n3, n1, n2 = self.norm3, self.norm1, self.norm2
@@ -287,8 +288,14 @@ class SpaceTimeBlock(nn.Module):
         else:
             y_t, b_t = ops.linear(o_t, ta.proj.weight), ta.proj.bias
         x, h1 = ops.add_layer_norm_pass(x, y_t, b_t, n1.weight, n1.bias, n1.eps)
-        o_s = sa.core(h1, 'space', frames, n_per_frame)
-        y_s = ops.linear(o_s[:, 0].contiguous(), sa.proj.weight)                 # [B, D]
+        # space attention, cls query only: k | v of every token (the last two thirds of the qkv Linear), q of the cls rows
+        D = h1.shape[-1]
+        w, bias = sa.qkv.weight, sa.qkv.bias
+        bq, bkv = (None, None) if bias is None else (bias.detach()[:D], bias.detach()[D:])
+        kv = ops.linear(h1, w[D:], bkv)                                          # [B, T, 2D]
+        q = ops.linear(h1[:, 0].contiguous(), w[:D], bq)                         # [B, D]
+        o_cls = ops.cls_attention(q, kv, sa.num_heads, bias=bias)                # [B, D]
+        y_s = ops.linear(o_cls, sa.proj.weight)                                  # [B, D]
         x1, h2 = ops.add_layer_norm(x[:, 0].contiguous(), y_s, sa.proj.bias, n2.weight, n2.bias, n2.eps, keep_sum=True)
         if self.mlp._fused_act:
             return x1, ops.mlp_quickgelu(h2, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight), self.mlp.fc2.bias

@@ -171,6 +171,17 @@ def vision_tower(video_bcthw: Tensor, w: Dict[str, Tensor], heads: int, prefix: 
 # --------------------------------------------------------------------------------------
 # text tower (OpenAI-CLIP Transformer)
 # --------------------------------------------------------------------------------------
+def cls_attention_core(q: Tensor, kv: Tensor, heads: int) -> Tensor:
+    """The cls row of VarAttention's attention (timesformer.py:113-119): q [B, D] of the cls token (times dh^-0.5) against
+    the keys / values kv [B, T, 2D] of ALL tokens, per head."""
+    B, T, D2 = kv.shape
+    D = D2 // 2
+    qh = q.reshape(B, heads, 1, 64) * (64 ** -0.5)
+    k = kv[..., :D].reshape(B, T, heads, 64).permute(0, 2, 1, 3)
+    v = kv[..., D:].reshape(B, T, heads, 64).permute(0, 2, 1, 3)
+    return _softmax_av(qh, k, v).reshape(B, D)
+
+
 def coca_layer_norm(x: Tensor, gamma: Tensor) -> Tensor:
     """coca.py:27-34: F.layer_norm with a learned gamma and a zero beta buffer (eps 1e-5)."""
     return F.layer_norm(x, x.shape[-1:], gamma, torch.zeros_like(gamma), 1e-5)

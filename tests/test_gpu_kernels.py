@@ -233,6 +233,34 @@ def test_causal_attention_core(dt, B, L, H):
     _check_qkv_bias_grad(bias.grad, qo.grad, dt)
 
 
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('B,T,H', [(2, 99, 3), (3, 785, 12), (1, 1, 1), (2, 33, 2), (2, 3137, 12)])
+def test_cls_attention_core(dt, B, T, H):
+    """lvl_cls_attn_fwd / _bwd (the cls query of the last block's space attention over all T tokens) against
+    oracle.cls_attention_core and its autograd gradients; the qkv bias gradient from the softmax identities."""
+    from lavila_amd import ops
+    D = 64 * H
+    g = torch.Generator().manual_seed(B * 7 + T)
+    q = _r(torch.randn(B, D, generator=g), dt)
+    kv = _r(torch.randn(B, T, 2 * D, generator=g), dt)
+    dout = _r(torch.randn(B, D, generator=g), dt)
+    bias = torch.zeros(3 * D, device=DEV, requires_grad=True)
+    qo, kvo = q.clone().requires_grad_(True), kv.clone().requires_grad_(True)
+    want = O.cls_attention_core(qo, kvo, H)
+    want.backward(dout)
+    qd, kvd = q.to(DEV).to(dt).requires_grad_(True), kv.to(DEV).to(dt).requires_grad_(True)
+    got = ops.cls_attention(qd, kvd, H, bias=bias)
+    got.backward(dout.to(DEV).to(dt))
+    _close(got.detach().float().cpu(), want.detach(), dt, msg='out')
+    _close(qd.grad.float().cpu(), qo.grad, dt, scale=max(1.0, qo.grad.abs().max().item()), msg='dq')
+    _close(kvd.grad.float().cpu(), kvo.grad, dt, scale=max(1.0, kvo.grad.abs().max().item()), msg='dkv')
+    # d bias = (sum_b dq | sum_{b,j} dk = 0 | sum_{b,j} dv): what adding the bias to q / k / v implies
+    wantb = torch.cat([qo.grad.sum(0), kvo.grad[..., :D].sum((0, 1)), kvo.grad[..., D:].sum((0, 1))])
+    tolb = (1e-3 if dt == torch.float32 else 5e-2) * max(1.0, wantb.abs().max().item())
+    assert (bias.grad.cpu() - wantb).abs().max() < tolb
+    assert float(bias.grad[D:2 * D].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize('case', range(4))
 @pytest.mark.parametrize('mode', ['space', 'time'])
 def test_var_attention_module_vs_reference_golden(case, mode):
