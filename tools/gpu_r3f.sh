@@ -4,7 +4,7 @@ set -u
 O=gpurun_out/r3f
 mkdir -p $O
 export TMPDIR=/tmp
-(timeout 1200 python -m pytest tests -m gpu -q 2>&1 | tail -15) > $O/pytest.log
+(timeout 1200 python -m pytest tests -m gpu -q 2>&1 | grep -E "^E  |passed|failed|^FAILED" | cut -c1-300 | head -30) > $O/pytest.log
 timeout 200 python __graft_entry__.py smoke > $O/smoke.log 2>&1
 timeout 300 python bench.py > $O/bench_final.json 2> $O/bench.err
 LAVILA_DYNAMIC_TILES=1 timeout 300 python bench.py --no-cpu-baseline > $O/bench_counters.json 2>/dev/null
