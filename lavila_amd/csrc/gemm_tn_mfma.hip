@@ -150,21 +150,10 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
   auto mailbox = [&]() -> int {
     return __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(smem + MBOX_OFF));
   };
-  if (dyn && late_mod > 0 && bid % late_mod == 1) {
-    my_tiles = 0;                               // test hook (lvl_debug_late_workgroups): as if the queues were drained
-  } else if (dyn) {
-    // first tile: the one synchronous hand-out (nothing is in flight yet, ~1 us once per launch)
-    pull();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    publish();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    const int v = mailbox();
-    if (v >= cnt) my_tiles = 0;                 // queue already drained (this workgroup got its CU late)
-    pair_even = xstart + v;
-    __builtin_amdgcn_s_barrier();               // everyone has read the mailbox before it is written again
-    if (my_tiles) pull();                       // tile 1: the reply lands during the prologue fills and tile 0's first blocks
-  }
+  const bool late = dyn && late_mod > 0 && bid % late_mod == 1;      // test hook (lvl_debug_late_workgroups)
+  // first tile: the one synchronous hand-out of a launch. Requested here, consumed behind the address set-up below
+  // (nothing else is in flight yet, so the round trip overlaps ~1 us of scalar / vector arithmetic).
+  if (dyn && !late) pull();
 
   // Tile order: all N/256 column tiles of a row block are neighbours (N-fastest). (Panels of 3-6 column tiles, to keep
   // a weight panel L2-resident, measured no faster: the weight re-reads are served by the Infinity Cache.)
@@ -427,6 +416,19 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
 #else
 #define GM_STAMP() do { } while (0)
 #endif
+  if (late) {
+    my_tiles = 0;                               // as if the queues were drained
+  } else if (dyn) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    publish();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const int v = mailbox();
+    if (v >= cnt) my_tiles = 0;                 // queue already drained (this workgroup got its CU late)
+    pair_even = xstart + v;
+    __builtin_amdgcn_s_barrier();               // everyone has read the mailbox before it is written again
+    if (my_tiles) pull();                       // tile 1: the reply lands during the prologue fills and tile 0's first blocks
+  }
   GM_STAMP();
   uint4 xA[8], xB[8], wA[4], wB[4];
   if (my_tiles > 0) {
