@@ -146,8 +146,7 @@ class CLIP(nn.Module):
         return rows, (rows.max() if trim else None)
 
     def encode_text(self, text, use_checkpoint=False, _eot=None):
-        ops.training_forward_begins()
-        with _amp_region():
+        with ops.model_forward(), _amp_region():
             # Only the EOT row (highest token id, models.py:158-160) of the last layer feeds the output, and under
             # the causal mask a row never sees later positions: everything behind the longest caption of the batch
             # is dead work in every layer (and receives exactly zero gradient in the reference too). The tower runs
@@ -168,7 +167,10 @@ class CLIP(nn.Module):
             return _half_out(x @ self.text_projection, self.text_projection)
 
     def forward(self, image, text, use_checkpoint=False, norm_embed=False):
-        ops.training_forward_begins()
+        with ops.model_forward():
+            return self._forward(image, text, use_checkpoint, norm_embed)
+
+    def _forward(self, image, text, use_checkpoint, norm_embed):
         if _TEXT_STREAM and image.is_cuda:
             # The two towers are independent until the loss: the (small) text tower runs on a second HIP stream so that
             # its short kernels fill the tails of the video tower's launches. Autograd replays each tower's backward on

@@ -118,11 +118,11 @@ class VCLM_HF(nn.Module):
         BTCHW with a copy and the features to BDN and back; here the tower reads BCTHW in place and hands [B, T, D] on."""
         if not isinstance(self.visual, SpaceTimeTransformer):
             raise NotImplementedError('VCLM_HF.encode_image: only the SpaceTimeTransformer tower is built (narrator.py:73-76)')
-        ops.training_forward_begins()
-        tok = self.visual.patch_embed.tokens_from_bcthw(image)
-        x = self.visual._features_from_tokens(tok, image.shape[2], use_checkpoint, False)       # [B, 1 + F*N, D]
-        pooled = self.img_attn_pool(self.img_queries, x)              # queries shared by the batch: projected once
-        return _like_caller(self.img_attn_pool_norm(pooled), image, self.img_queries)
+        with ops.model_forward():
+            tok = self.visual.patch_embed.tokens_from_bcthw(image)
+            x = self.visual._features_from_tokens(tok, image.shape[2], use_checkpoint, False)   # [B, 1 + F*N, D]
+            pooled = self.img_attn_pool(self.img_queries, x)          # queries shared by the batch: projected once
+            return _like_caller(self.img_attn_pool_norm(pooled), image, self.img_queries)
 
     def forward(self, image, text, mask=None, use_checkpoint=False, norm_embed=False):
         """narrator.py:92-110 around whatever decoder the constructor was given."""

@@ -90,6 +90,27 @@ def training_forward_begins():
         invalidate_weight_cache()
 
 
+_forward_depth = __import__('threading').local()
+
+
+class model_forward:
+    """`with ops.model_forward():` around a model-level forward (CLIP.forward / encode_*, SpaceTimeTransformer.forward*,
+    VCLM_HF.encode_image): the OUTERMOST one of a grad-enabled forward bumps the weight-copy generation; nested ones
+    (CLIP.forward -> encode_image -> visual.forward, the text tower started from inside the video forward) do not, so
+    every weight is cast exactly once per training forward and activation checkpointing's recomputation finds the
+    copies of its own forward."""
+
+    def __enter__(self):
+        d = getattr(_forward_depth, 'd', 0)
+        if d == 0:
+            training_forward_begins()
+        _forward_depth.d = d + 1
+
+    def __exit__(self, *exc):
+        _forward_depth.d -= 1
+        return False
+
+
 def _optimizer_stepped(optimizer, args, kwargs):
     invalidate_weight_cache()
 

@@ -448,16 +448,16 @@ class SpaceTimeTransformer(nn.Module):
     def forward_features(self, x, use_checkpoint=False, cls_at_last=True):
         """Reference signature: x is [B, F, C, H, W] (timesformer.py:345-382; the narrator's entry with
         cls_at_last=False, narrator.py:74). The gather reads this layout in place."""
-        ops.training_forward_begins()
-        b, curr_frames, channels, _, _ = x.shape
-        tok = self.patch_embed.tokens_from_btchw(x)
-        out = self._features_from_tokens(tok, curr_frames, use_checkpoint, cls_at_last)
-        return _like_caller(out, x, self.cls_token)
+        with ops.model_forward():
+            b, curr_frames, channels, _, _ = x.shape
+            tok = self.patch_embed.tokens_from_btchw(x)
+            out = self._features_from_tokens(tok, curr_frames, use_checkpoint, cls_at_last)
+            return _like_caller(out, x, self.cls_token)
 
     def forward(self, x, use_checkpoint=False, _after_block=None):
         """x: [B, C, T, H, W] (timesformer.py:384-390); the BCTHW->BTCHW copy is folded into the gather.
         `_after_block` is not part of the reference signature (see _features_from_tokens)."""
-        ops.training_forward_begins()
-        tok = self.patch_embed.tokens_from_bcthw(x)
-        out = self._features_from_tokens(tok, x.shape[2], use_checkpoint, True, _after_block)
-        return self.head(_like_caller(out, x, self.cls_token))
+        with ops.model_forward():
+            tok = self.patch_embed.tokens_from_bcthw(x)
+            out = self._features_from_tokens(tok, x.shape[2], use_checkpoint, True, _after_block)
+            return self.head(_like_caller(out, x, self.cls_token))
