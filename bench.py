@@ -297,6 +297,21 @@ def main():
                    'host_enqueue_ms_per_step': round(1e3 * h2 / n2, 1), 'steps': n2}
         _m._TEXT_TRIM = True
 
+    # the same step with the LAST block of both towers computed on every row, as the reference does (the default computes
+    # only the rows that reach the output -- cls / EOT -- which is exact: DESIGN.md section 4, "Last block")
+    full_last = None
+    if os.environ.get('LAVILA_CLS_LAST', '1') != '0' and not args.no_events:
+        from lavila_amd import timesformer as _t
+        _t.CLS_ONLY_LAST_BLOCK = False
+        step()
+        fence()
+        n3, t3 = max(2, min(4, args.steps)), time.perf_counter()
+        for _ in range(n3):
+            step()
+        fence()
+        full_last = {'ms_per_step': round(1e3 * (time.perf_counter() - t3) / n3, 3), 'steps': n3}
+        _t.CLS_ONLY_LAST_BLOCK = True
+
     if rank == 0:
         B, Fr = args.batch, args.frames
         N = model.visual.patches_per_frame
@@ -356,6 +371,12 @@ def main():
                        # (models._longest_caption), which returns only when the previous step has drained
                        'host_enqueue_ms_per_step': round(1e3 * host_s / args.steps, 1),
                        'text_trim_off': no_trim,
+                       'full_last_block': full_last,
+                       'exact_work_elimination': 'text positions behind the longest caption (causal: unread) and, in the LAST '
+                                                 'block of each tower, the projection / LayerNorm / MLP rows that do not reach '
+                                                 'the output (only norm(x)[:,0] / the EOT row leave the towers) are not computed; '
+                                                 'outputs and every parameter gradient equal the reference (tests/golden/model_*.pt). '
+                                                 'text_trim_off / full_last_block give the step time without each',
                        'tile_schedule': 'dynamic (device tile / chunk counters)' if ops.dynamic_tiles()
                                         else 'static (single GPU; the counters switch on inside a process group)',
                        'parity_note': 'benched path = bf16 MFMA kernels: bit-exact on integer / one-hot operands '
