@@ -11,6 +11,7 @@ batch 4).
 """
 import os
 import sys
+import types
 
 import torch
 import torch.nn as nn
@@ -370,6 +371,87 @@ def run_narrator_pool_golden(ref):
     print('narrator_pool', tuple(tokens.shape), float(tokens.abs().mean()))
 
 
+DECODER = dict(vocab=331, positions=40, layers=3, text_len=13, max_text_length=15,
+               variants={'freq1_gated': dict(cross_attn_freq=1, gated_xattn=True),
+                         'freq2_plain': dict(cross_attn_freq=2, gated_xattn=False)})
+
+
+def decoder_weights(model, seed):
+    """Procedural weights for every learnable tensor of a VCLM_HF; the causal-mask buffers (`attn.bias`,
+    `attn.masked_bias`, gpt2_gated.py:154-160) and the coca `beta` zeros keep their constructed values and lm_head
+    stays tied to wte (transformers 4.27 ties them in post_init; `tie_word_embeddings` is GPT-2's default)."""
+    sd = model.state_dict()
+    keep = [k for k in sd if k.endswith('.attn.bias') or k.endswith('.crossattention.bias') or k.endswith('masked_bias')
+            or k.endswith('.beta')]
+    shapes = {k: tuple(v.shape) for k, v in sd.items() if k not in keep and k != 'text_decoder.lm_head.weight'}
+    weights = O.procedural_weights(shapes, seed=seed)
+    weights['text_decoder.lm_head.weight'] = weights['text_decoder.transformer.wte.weight']
+    for k in keep:
+        weights[k] = sd[k].clone()
+    return shapes, keep, weights
+
+
+def run_narrator_decoder_golden():
+    """The narrator end to end from the reference's own, unmodified narrator.py / gpt2_gated.py / coca.py /
+    timesformer.py (imported under transformers-4.27 name stand-ins, oracle/ref_import.py): VCLM_HF.forward (teacher-forced
+    logits), VCLM_HF.generate with top_k=1 (free-running, early-stopping, and teacher-forced with a target)."""
+    from transformers import GPT2Config
+    from oracle.ref_import import load_reference_narrator
+    ref = load_reference_narrator()
+    c, d = NARRATOR, DECODER
+    out = {'config': c, 'decoder': {k: v for k, v in d.items() if k != 'variants'}, 'variants': {}}
+    for vi, (name, var) in enumerate(d['variants'].items()):
+        torch.manual_seed(0)
+        vis = ref.timesformer.SpaceTimeTransformer(
+            img_size=c['img'], patch_size=c['patch'], embed_dim=c['dim'], depth=c['depth'], num_heads=c['heads'],
+            num_frames=c['frames'], time_init='zeros', attention_style='frozen-in-time', ln_pre=True,
+            act_layer=ref.openai_model.QuickGELU, is_tanh_gating=False)
+        vis.head = nn.Identity()
+        vis.pre_logits = nn.Identity()
+        vis.fc = nn.Identity()
+        base = GPT2Config(vocab_size=d['vocab'], n_positions=d['positions'], n_embd=c['text_width'], n_layer=d['layers'],
+                          n_head=c['pool_heads'], use_cache=False, bos_token_id=d['vocab'] - 1, eos_token_id=d['vocab'] - 1)
+        cfg = ref.gpt2_gated.augment_gpt2_config(base, **var)
+        dec = ref.gpt2_gated.GPT2LMHeadModel(cfg)
+        model = ref.narrator.VCLM_HF(vision_width=c['dim'], vision_model=vis, text_width=c['text_width'],
+                                     text_decoder=dec, num_img_queries=c['queries'], dim_head=64, heads=c['pool_heads'])
+        shapes, keep, weights = decoder_weights(model, seed=29 + vi)
+        model.load_state_dict(weights, strict=True)
+        dec.lm_head.weight = dec.transformer.wte.weight
+        model.eval()
+        video, _ = O.synthetic_batch(c['batch'], c['frames'], c['img'], seed=78)
+        g = torch.Generator().manual_seed(11 + vi)
+        bos = d['vocab'] - 1
+        text = torch.randint(1, d['vocab'] - 1, (c['batch'], d['text_len']), generator=g)
+        text[:, 0] = bos
+        text[1, 9:] = 0                                              # pad (id 0) tail: ignored by the target nll
+        with torch.no_grad():
+            fwd = model(video, text)
+            image_tokens = model.encode_image(video)
+            tok = types.SimpleNamespace(bos_token_id=bos, eos_token_id=-1, pad_token_id=0)
+            free_ids, free_ppl = model.generate(image_tokens, tok, max_text_length=d['max_text_length'], top_k=1)
+            # an eos id that the free-running greedy decode really emits (row 0, step 5), so the eos bookkeeping is live
+            tok.eos_token_id = int(free_ids[0, 6])
+            eos_ids, eos_ppl = model.generate(image_tokens, tok, max_text_length=d['max_text_length'], top_k=1)
+            stop_ids, stop_ppl = model.generate(image_tokens[:1], tok, max_text_length=d['max_text_length'], top_k=1,
+                                                early_stopping=True)
+            tf_ids, tf_ppl = model.generate(image_tokens, tok, target=text, max_text_length=d['text_len'], top_k=1,
+                                            teacher_forcing=True)
+            tgt_ids, tgt_ppl = model.generate(image_tokens, tok, target=text, max_text_length=d['text_len'], top_k=1)
+            rep_ids, rep_ppl = model.generate(image_tokens, tok, max_text_length=8, top_k=1, num_return_sequences=2)
+        out['variants'][name] = {
+            'variant': var, 'shapes': shapes, 'kept_buffers': keep, 'weight_seed': 29 + vi, 'input_seed': 78,
+            'text': text, 'bos': bos, 'eos': tok.eos_token_id, 'pad': 0,
+            'image_tokens': image_tokens, 'logits': fwd['text_tokens_logits'], 'labels': fwd['labels'],
+            'free_ids': free_ids, 'free_ppl': free_ppl, 'eos_ids': eos_ids, 'eos_ppl': eos_ppl,
+            'stop_ids': stop_ids, 'stop_ppl': stop_ppl, 'tf_ids': tf_ids, 'tf_ppl': tf_ppl,
+            'tgt_ids': tgt_ids, 'tgt_ppl': tgt_ppl, 'rep_ids': rep_ids, 'rep_ppl': rep_ppl,
+        }
+        print('narrator_decoder', name, tuple(fwd['text_tokens_logits'].shape), float(fwd['text_tokens_logits'].abs().mean()),
+              free_ids[0].tolist(), free_ppl.tolist(), tuple(stop_ids.shape))
+    torch.save(out, os.path.join(GOLDEN, 'narrator_decoder.pt'))
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     torch.set_num_threads(8)
@@ -388,6 +470,8 @@ def main():
         run_ssl_loss_golden(ref)
     if not only or 'narrator' in only:
         run_narrator_pool_golden(ref)
+    if not only or 'decoder' in only:
+        run_narrator_decoder_golden()
 
 
 if __name__ == '__main__':

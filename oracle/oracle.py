@@ -218,6 +218,148 @@ def narrator_encode_image(video_bcthw: Tensor, w: Dict[str, Tensor], vis_heads: 
     return coca_layer_norm(pooled, w['img_attn_pool_norm.gamma'])
 
 
+# --------------------------------------------------------------------------------------
+# narrator decoder (gated-cross-attention GPT-2) and greedy / teacher-forced decoding
+# --------------------------------------------------------------------------------------
+def gelu_new(x: Tensor) -> Tensor:
+    """GPT-2's tanh GELU (config.activation_function == 'gelu_new', gpt2_gated.py:389 via transformers ACT2FN):
+    0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))."""
+    return 0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * x ** 3)))
+
+
+def sq_relu(x: Tensor) -> Tensor:
+    """relu(x)^2 of the cross-attention MLP (gpt2_gated.py:363-376, 413)."""
+    return torch.relu(x) ** 2
+
+
+def conv1d(x: Tensor, weight_in_out: Tensor, bias: Tensor) -> Tensor:
+    """transformers Conv1D (pytorch_utils.py, used at gpt2_gated.py:184-188,383-384): y = x @ W + b with W stored
+    [in, out] -- the TRANSPOSE of nn.Linear's layout."""
+    return x @ weight_in_out + bias
+
+
+def gpt2_attention_core(q: Tensor, k: Tensor, v: Tensor, heads: int, causal: bool) -> Tensor:
+    """GPT2Attention._attn + head split / merge (gpt2_gated.py:206-307) for the configuration the narrator uses
+    (scale_attn_weights, no layer-index scaling, no reordering): softmax(q k^T / sqrt(dh) [causal: where(tril, ., -1e4)]) v.
+    q [B, Lq, D], k / v [B, Lk, D]; causal rows are the LAST Lq positions of the Lk keys (`bias[Lk-Lq:Lk, :Lk]`)."""
+    B, Lq, D = q.shape
+    Lk = k.shape[1]
+    dh = D // heads
+    qh = q.reshape(B, Lq, heads, dh).permute(0, 2, 1, 3)
+    kh = k.reshape(B, Lk, heads, dh).permute(0, 2, 1, 3)
+    vh = v.reshape(B, Lk, heads, dh).permute(0, 2, 1, 3)
+    s = qh @ kh.transpose(-1, -2) / (dh ** 0.5)
+    if causal:
+        allowed = torch.ones(Lk, Lk, dtype=torch.bool).tril_()[Lk - Lq:Lk, :Lk]
+        s = torch.where(allowed, s, torch.tensor(-1e4, dtype=s.dtype))
+    o = torch.softmax(s, -1) @ vh
+    return o.permute(0, 2, 1, 3).reshape(B, Lq, D)
+
+
+def gpt2_mlp(x: Tensor, w: Dict[str, Tensor], prefix: str, squared_relu: bool) -> Tensor:
+    """GPT2MLP.forward (gpt2_gated.py:391-396); dropout is identity in eval."""
+    h = conv1d(x, w[prefix + 'c_fc.weight'], w[prefix + 'c_fc.bias'])
+    h = sq_relu(h) if squared_relu else gelu_new(h)
+    return conv1d(h, w[prefix + 'c_proj.weight'], w[prefix + 'c_proj.bias'])
+
+
+def gpt2_block(x: Tensor, enc: Optional[Tensor], w: Dict[str, Tensor], prefix: str, heads: int, eps: float,
+               past: Optional[tuple] = None):
+    """GPT2Block.forward (gpt2_gated.py:421-495). When the block owns a `crossattention` (layer_idx % freq == 0) and
+    encoder states are given: x += tanh(alpha_cattn) * CrossAttn(ln_cross_attn x, enc); x += tanh(alpha_dense) *
+    MLP_sqrelu(ln_2_crossattention x) (gates only when the parameters exist), THEN the ordinary GPT-2 block
+    (causal self-attention, gelu_new MLP). Returns (x, (k, v)): the self-attention keys / values incl. `past`."""
+    p = prefix
+    D = x.shape[-1]
+    if enc is not None and (p + 'crossattention.q_attn.weight') in w:
+        h = layer_norm(x, w[p + 'ln_cross_attn.weight'], w[p + 'ln_cross_attn.bias'], eps)
+        q = conv1d(h, w[p + 'crossattention.q_attn.weight'], w[p + 'crossattention.q_attn.bias'])
+        kv = conv1d(enc, w[p + 'crossattention.c_attn.weight'], w[p + 'crossattention.c_attn.bias'])
+        a = gpt2_attention_core(q, kv[..., :D], kv[..., D:], heads, causal=False)
+        a = conv1d(a, w[p + 'crossattention.c_proj.weight'], w[p + 'crossattention.c_proj.bias'])
+        if (p + 'alpha_cattn') in w:
+            a = torch.tanh(w[p + 'alpha_cattn']) * a
+        x = x + a
+        h = layer_norm(x, w[p + 'ln_2_crossattention.weight'], w[p + 'ln_2_crossattention.bias'], eps)
+        f = gpt2_mlp(h, w, p + 'mlp_crossattention.', squared_relu=True)
+        if (p + 'alpha_dense') in w:
+            f = torch.tanh(w[p + 'alpha_dense']) * f
+        x = x + f
+    h = layer_norm(x, w[p + 'ln_1.weight'], w[p + 'ln_1.bias'], eps)
+    qkv = conv1d(h, w[p + 'attn.c_attn.weight'], w[p + 'attn.c_attn.bias'])
+    q, k, v = qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:]
+    if past is not None:
+        k = torch.cat([past[0], k], 1)
+        v = torch.cat([past[1], v], 1)
+    a = gpt2_attention_core(q, k, v, heads, causal=True)
+    x = x + conv1d(a, w[p + 'attn.c_proj.weight'], w[p + 'attn.c_proj.bias'])
+    h = layer_norm(x, w[p + 'ln_2.weight'], w[p + 'ln_2.bias'], eps)
+    return x + gpt2_mlp(h, w, p + 'mlp.', squared_relu=False), (k, v)
+
+
+def gpt2_lm_logits(ids: Tensor, enc: Optional[Tensor], w: Dict[str, Tensor], heads: int, eps: float = 1e-5,
+                   prefix: str = '', past: Optional[list] = None):
+    """GPT2LMHeadModel.forward -> logits (gpt2_gated.py:802-1001, 1092-1162): wte[ids] + wpe[past_len + arange(L)] ->
+    blocks -> ln_f -> lm_head (no bias). `past`: per-layer (k, v) of the tokens before `ids` (None = none); returns
+    (logits [B, L, V], presents)."""
+    p = prefix + 'transformer.'
+    depth = 1 + max(int(k[len(p) + 2:].split('.')[0]) for k in w if k.startswith(p + 'h.'))
+    past_len = 0 if past is None else past[0][0].shape[1]
+    L = ids.shape[1]
+    x = w[p + 'wte.weight'][ids] + w[p + 'wpe.weight'][past_len:past_len + L]
+    presents = []
+    for i in range(depth):
+        x, kv = gpt2_block(x, enc, w, f'{p}h.{i}.', heads, eps, None if past is None else past[i])
+        presents.append(kv)
+    x = layer_norm(x, w[p + 'ln_f.weight'], w[p + 'ln_f.bias'], eps)
+    return x @ w[prefix + 'lm_head.weight'].t(), presents
+
+
+def narrator_forward(video_bcthw: Tensor, text: Tensor, w: Dict[str, Tensor], vis_heads: int, pool_heads: int,
+                     dec_heads: int) -> Dict[str, Tensor]:
+    """VCLM_HF.forward (narrator.py:89-104): decoder over text[:, :-1] against the pooled image tokens; logits come
+    back class-major [B, V, L-1] with labels text[:, 1:]."""
+    image_tokens = narrator_encode_image(video_bcthw, w, vis_heads, pool_heads)
+    logits, _ = gpt2_lm_logits(text[:, :-1], image_tokens, w, dec_heads, prefix='text_decoder.')
+    return {'text_tokens_logits': logits.permute(0, 2, 1), 'labels': text[:, 1:]}
+
+
+def narrator_generate_greedy(image_tokens: Tensor, w: Dict[str, Tensor], dec_heads: int, bos: int, eos: int, pad: int,
+                             max_text_length: int, target: Optional[Tensor] = None, teacher_forcing: bool = False,
+                             early_stopping: bool = False, use_cache: bool = True):
+    """VCLM_HF.generate (narrator.py:106-147) with top_k=1, i.e. the multinomial draw is an argmax (deterministic): the
+    only sampling setting that has a reference answer. Per step: logits of the last position -> nll (cross entropy
+    against target[:, i+1] ignoring pad, or the entropy of the softmax while the row has not emitted eos) -> next token.
+    `use_cache=False` re-runs the whole prefix each step exactly like the reference; `use_cache=True` feeds one token
+    against cached keys / values (same numbers up to rounding). Returns (ids [B, <=max_text_length], perplexity [B])."""
+    B = image_tokens.shape[0]
+    generated = torch.full((B, 1), bos, dtype=torch.long)
+    condition = generated.clone()
+    nlls = torch.zeros(B)
+    num = torch.zeros(B)
+    reached = torch.zeros(B, dtype=torch.bool)
+    past = None
+    for i in range(max_text_length - 1):
+        if use_cache:
+            logits, past = gpt2_lm_logits(condition[:, -1:], image_tokens, w, dec_heads, prefix='text_decoder.', past=past)
+        else:
+            logits, _ = gpt2_lm_logits(condition, image_tokens, w, dec_heads, prefix='text_decoder.')
+        nxt = logits[:, -1, :]
+        if target is not None:
+            nlls += F.cross_entropy(nxt, target[:, i + 1], ignore_index=pad, reduction='none')
+            num += target[:, i + 1].ne(pad)
+        else:
+            nlls += torch.special.entr(F.softmax(nxt, dim=1)).sum(dim=1) * (~reached)
+            num += (~reached)
+        tok = nxt.argmax(-1, keepdim=True)
+        reached = reached | (tok[:, 0] == eos)
+        if early_stopping and bool(torch.all(reached)):
+            break
+        condition = target[:, :i + 2] if teacher_forcing else torch.cat([generated, tok], 1)
+        generated = torch.cat([generated, tok], 1)
+    return generated, torch.exp(nlls / num)
+
+
 def causal_attention_core(qkv: Tensor, heads: int) -> Tensor:
     """nn.MultiheadAttention core with the additive causal mask of CLIP.build_attention_mask
     (models.py:131-137; openai_model.py:196-198): softmax((q dh^-0.5) k^T + mask) v, packed
@@ -353,8 +495,10 @@ def procedural_weights(shapes: Dict[str, tuple], seed: int = 0) -> Dict[str, Ten
         leaf = name.split('.')[-1]
         if name == 'logit_scale':
             t = torch.tensor(math.log(1 / 0.07))
-        elif name.endswith('alpha_timeattn'):
+        elif name.endswith('alpha_timeattn') or leaf in ('alpha_cattn', 'alpha_dense'):
             t = torch.randn(shape, generator=g) * 0.5
+        elif name.endswith('transformer.ln_f.weight'):      # GPT-2 final LayerNorm: logits of a few units
+            t = 4.0 + 0.4 * torch.randn(shape, generator=g)
         elif leaf == 'weight' and len(shape) == 1:          # LayerNorm gains
             t = 1.0 + 0.1 * torch.randn(shape, generator=g)
         elif leaf in ('bias', 'in_proj_bias'):
@@ -371,3 +515,15 @@ def procedural_weights(shapes: Dict[str, tuple], seed: int = 0) -> Dict[str, Ten
             t = torch.randn(shape, generator=g) * shape[-1] ** -0.5
         out[name] = t
     return out
+
+
+def narrator_weights(shapes: Dict[str, tuple], seed: int) -> Dict[str, Tensor]:
+    """procedural_weights for a VCLM_HF state dict (tests/golden/narrator_decoder.pt lists `shapes` without the causal-mask
+    buffers and without lm_head): the coca `beta` buffers are zeros (coca.py:31) and lm_head is tied to wte
+    (GPT-2's tie_word_embeddings)."""
+    w = procedural_weights({k: v for k, v in shapes.items() if not k.endswith('.beta')}, seed=seed)
+    for k, shape in shapes.items():
+        if k.endswith('.beta'):
+            w[k] = torch.zeros(shape)
+    w['text_decoder.lm_head.weight'] = w['text_decoder.transformer.wte.weight']
+    return w

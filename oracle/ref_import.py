@@ -82,7 +82,76 @@ def _install_stubs():
             sys.modules[name] = m
 
 
+def _install_transformers_4_27_names():
+    """lavila/models/gpt2_gated.py:36-48 and narrator.py:16 import names of transformers 4.27 that 5.x dropped
+    (SequenceSummary, head pruning helpers, model_parallel_utils, the docstring decorators, BeamSearchScorer). None of
+    them is on the path the goldens exercise (GPT2LMHeadModel.forward, VCLM_HF.forward / generate), so inert stand-ins
+    are installed under the old names before the unmodified reference source is imported. `get_head_mask` /
+    `invert_attention_mask` (PreTrainedModel methods the forward calls, gpt2_gated.py:884,889) are restated from their
+    4.27 definitions when the installed base class no longer has them."""
+    import torch
+    import torch.nn as nn
+    import transformers
+    import transformers.modeling_utils as mu
+    import transformers.pytorch_utils as pu
+    import transformers.utils as tu
+
+    if not hasattr(mu, "SequenceSummary"):
+        class SequenceSummary(nn.Module):            # only GPT2DoubleHeadsModel builds one
+            def __init__(self, config):
+                super().__init__()
+        mu.SequenceSummary = SequenceSummary
+
+    def _unused(*a, **k):
+        raise RuntimeError("stand-in for a transformers 4.27 helper that the golden path never calls")
+
+    for name in ("find_pruneable_heads_and_indices", "prune_conv1d_layer"):
+        if not hasattr(pu, name):
+            setattr(pu, name, _unused)
+
+    def _decorator(*a, **k):
+        return lambda fn: fn
+
+    for name in ("add_code_sample_docstrings", "add_start_docstrings", "add_start_docstrings_to_model_forward",
+                 "replace_return_docstrings"):
+        if not hasattr(tu, name):
+            setattr(tu, name, _decorator)
+    if "transformers.utils.model_parallel_utils" not in sys.modules:
+        try:
+            importlib.import_module("transformers.utils.model_parallel_utils")
+        except Exception:
+            m = _mod("transformers.utils.model_parallel_utils")
+            m.assert_device_map = _unused
+            m.get_device_map = _unused
+            sys.modules["transformers.utils.model_parallel_utils"] = m
+            tu.model_parallel_utils = m
+    if not hasattr(transformers, "BeamSearchScorer"):
+        class BeamSearchScorer:                       # beam_sample / group_beam_search only
+            def __init__(self, *a, **k):
+                _unused()
+        transformers.BeamSearchScorer = BeamSearchScorer
+
+    base = mu.PreTrainedModel
+    if not hasattr(base, "get_head_mask"):
+        def get_head_mask(self, head_mask, num_hidden_layers, is_attention_chunked=False):
+            if head_mask is not None:
+                raise RuntimeError("head masks are not on the golden path")
+            return [None] * num_hidden_layers
+        base.get_head_mask = get_head_mask
+    if not hasattr(base, "invert_attention_mask"):
+        def invert_attention_mask(self, encoder_attention_mask):
+            # transformers 4.27 modeling_utils.ModuleUtilsMixin.invert_attention_mask
+            if encoder_attention_mask.dim() == 3:
+                ext = encoder_attention_mask[:, None, :, :]
+            else:
+                ext = encoder_attention_mask[:, None, None, :]
+            ext = ext.to(dtype=self.dtype)
+            return (1.0 - ext) * torch.finfo(self.dtype).min
+        base.invert_attention_mask = invert_attention_mask
+
+
 _REF = None
+_REF_NARRATOR = None
 
 
 def load_reference():
@@ -123,3 +192,39 @@ def load_reference():
         sys.modules.update({k: v for k, v in saved.items() if k not in stubs})
     _REF = ns
     return ns
+
+
+def load_reference_narrator():
+    """The reference's narrator side, unmodified source: namespace with `gpt2_gated` (GPT2LMHeadModel,
+    augment_gpt2_config; gpt2_gated.py), `narrator` (VCLM_HF; narrator.py) and `coca`, plus everything of
+    load_reference(). The module objects are created outside sys.modules' `lavila.*` names (which keep pointing at this
+    repository's drop-in package)."""
+    global _REF_NARRATOR
+    if _REF_NARRATOR is not None:
+        return _REF_NARRATOR
+    ns = load_reference()
+    _install_transformers_4_27_names()
+    saved = {k: v for k, v in sys.modules.items() if k == "lavila" or k.startswith("lavila.")}
+    for k in saved:
+        del sys.modules[k]
+    # the narrator imports coca / openai_model / timesformer by their `lavila.models.*` names: hand it the reference
+    # modules load_reference() already holds, so that its isinstance checks see the reference towers
+    sys.modules.update({
+        "lavila.models.coca": ns.coca, "lavila.models.openai_model": ns.openai_model,
+        "lavila.models.timesformer": ns.timesformer,
+    })
+    saved_path = list(sys.path)
+    sys.path.insert(0, REFERENCE_ROOT)
+    try:
+        out = types.SimpleNamespace(**vars(ns))
+        out.gpt2_gated = importlib.import_module("lavila.models.gpt2_gated")
+        out.narrator = importlib.import_module("lavila.models.narrator")
+        assert out.gpt2_gated.__file__.startswith(REFERENCE_ROOT), out.gpt2_gated.__file__
+        assert out.narrator.__file__.startswith(REFERENCE_ROOT), out.narrator.__file__
+    finally:
+        sys.path[:] = saved_path
+        for k in [k for k in sys.modules if k == "lavila" or k.startswith("lavila.")]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+    _REF_NARRATOR = out
+    return out

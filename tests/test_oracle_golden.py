@@ -172,3 +172,44 @@ def test_narrator_pool_oracle_matches_reference():
     torch.testing.assert_close(feats, fx['features'], atol=1e-5, rtol=1e-4)
     torch.testing.assert_close(tokens, fx['image_tokens'], atol=1e-5, rtol=1e-4)
     torch.testing.assert_close(general, fx['pool_general'], atol=1e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize('variant', ['freq1_gated', 'freq2_plain'])
+def test_narrator_decoder_oracle_matches_reference(variant):
+    """oracle.narrator_forward / narrator_generate_greedy against the reference's own VCLM_HF.forward and
+    VCLM_HF.generate(top_k=1) (unmodified narrator.py + gpt2_gated.py, tests/golden/narrator_decoder.pt): teacher-forced
+    logits, free-running ids / perplexities with and without an eos, early stopping, target scoring with and without
+    teacher forcing, num_return_sequences -- each with the reference's full-prefix recompute AND with a key/value cache."""
+    fx = load_golden('narrator_decoder.pt')
+    c, d, v = fx['config'], fx['decoder'], fx['variants'][variant]
+    w = O.narrator_weights(v['shapes'], seed=v['weight_seed'])
+    video, _ = O.synthetic_batch(c['batch'], c['frames'], c['img'], seed=v['input_seed'])
+    H = c['pool_heads']
+    with torch.no_grad():
+        out = O.narrator_forward(video, v['text'], w, c['heads'], H, H)
+        torch.testing.assert_close(out['text_tokens_logits'], v['logits'], atol=2e-4, rtol=1e-4)
+        assert torch.equal(out['labels'], v['labels'])
+        img = O.narrator_encode_image(video, w, c['heads'], H)
+        torch.testing.assert_close(img, v['image_tokens'], atol=1e-5, rtol=1e-4)
+        for cache in (False, True):
+            kw = dict(w=w, dec_heads=H, bos=v['bos'], pad=v['pad'], use_cache=cache)
+            ids, ppl = O.narrator_generate_greedy(img, eos=-1, max_text_length=d['max_text_length'], **kw)
+            assert torch.equal(ids, v['free_ids'])
+            torch.testing.assert_close(ppl, v['free_ppl'], atol=0, rtol=2e-4)
+            ids, ppl = O.narrator_generate_greedy(img, eos=v['eos'], max_text_length=d['max_text_length'], **kw)
+            assert torch.equal(ids, v['eos_ids'])
+            torch.testing.assert_close(ppl, v['eos_ppl'], atol=0, rtol=2e-4)
+            ids, ppl = O.narrator_generate_greedy(img[:1], eos=v['eos'], max_text_length=d['max_text_length'],
+                                                  early_stopping=True, **kw)
+            assert torch.equal(ids, v['stop_ids'])
+            torch.testing.assert_close(ppl, v['stop_ppl'], atol=0, rtol=2e-4)
+            ids, ppl = O.narrator_generate_greedy(img, eos=v['eos'], max_text_length=d['text_len'], target=v['text'],
+                                                  teacher_forcing=True, **kw)
+            assert torch.equal(ids, v['tf_ids'])
+            torch.testing.assert_close(ppl, v['tf_ppl'], atol=0, rtol=1e-3)
+            ids, ppl = O.narrator_generate_greedy(img, eos=v['eos'], max_text_length=d['text_len'], target=v['text'], **kw)
+            assert torch.equal(ids, v['tgt_ids'])
+            torch.testing.assert_close(ppl, v['tgt_ppl'], atol=0, rtol=1e-3)
+            ids, ppl = O.narrator_generate_greedy(img.repeat_interleave(2, dim=0), eos=v['eos'], max_text_length=8, **kw)
+            assert torch.equal(ids, v['rep_ids'])
+            torch.testing.assert_close(ppl, v['rep_ppl'], atol=0, rtol=2e-4)
