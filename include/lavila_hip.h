@@ -31,6 +31,8 @@ enum { LVL_F32 = 0, LVL_BF16 = 1 };
 enum { LVL_OK = 0, LVL_EINVAL = -22, LVL_ENOSYS = -38, LVL_EHIP = -5 };
 enum { LVL_ATTN_SPACE = 0, LVL_ATTN_TIME = 1, LVL_ATTN_CAUSAL = 2 /* lvl_attention_fast_path only */ };
 enum { LVL_EPI_BIAS = 0, LVL_EPI_BIAS_QUICKGELU = 1, LVL_EPI_QUICKGELU_BWD = 2 };
+/* activations of the narrator decoder's MLPs (lvl_act_inplace) */
+enum { LVL_ACT_GELU_NEW = 0, LVL_ACT_SQRELU = 1 };
 
 /* library identification / diagnostics (host pointers) */
 const char* lvl_version(void);
@@ -194,6 +196,40 @@ int lvl_cls_attn_bwd(const void* q, const void* kv, const void* out, const void*
  * repeats its learned img_queries); kv: [B, Tk, 128] = k | v as to_kv writes them; out: [B, NQ, H*64]. Forward only. */
 int lvl_mq_cross_attn_fwd(const void* q, int64_t q_batch_stride, const void* kv, void* out, int B, int NQ, int H,
                           int Tk, int dtype, void* stream);
+
+/* ---- narrator decoder: gated-cross-attention GPT-2 (inference) --------------------------------------------------
+ * The row passes of lavila/models/gpt2_gated.py's GPT2LMHeadModel around its Conv1D GEMMs (which run on lvl_linear_tn
+ * against [out,in] bf16 copies of the [in,out] Conv1D weights). The reference's VCLM_HF.generate re-runs the whole prefix
+ * for every token (narrator.py:118-143, use_cache=False); this ABI decodes ONE row per sequence and step against a
+ * key/value cache whose fill level `pos_dev` is an int32 in DEVICE memory, so one captured hipGraph serves every step.
+ * dtype = element type of activations, caches and embedding tables (LVL_F32 / LVL_BF16); arithmetic is f32.
+ *
+ * lvl_gpt2_embed (gpt2_gated.py:892-895): out[r,:] = wte[ids[r],:] + wpe[p0 + r % L,:], p0 = *pos_dev (0 when NULL);
+ *   ids [rows] int64 (clamped into the table), wte [vocab, D], wpe [positions, D], D % 8 == 0.
+ * lvl_gated_add_layernorm: s = res + (*gate) * y (gate NULL = 1, y NULL = no add), h = LayerNorm(s) * gamma + beta with
+ *   biased variance over the D channels -- the residual adds of GPT2Block.forward (gpt2_gated.py:442-458 with the
+ *   tanh(alpha) gates, :475, :483-487) fused with the LayerNorm that reads the sum next (ln_2_crossattention, ln_1, ln_2,
+ *   the next block's first norm, ln_f). res / y / s / h: [rows, D]; s may be res (in place) or NULL; gate: one f32
+ *   (tanh(alpha), computed by the caller); gamma / beta [D] f32; D % 8 == 0, D <= 4096.
+ * lvl_act_inplace (gpt2_gated.py:363-396): u <- gelu_new(u) = 0.5 u (1 + tanh(sqrt(2/pi) (u + 0.044715 u^3))) or
+ *   relu(u)^2 (mlp_crossattention), n % 8 == 0.
+ * lvl_decode_self_attn (gpt2_gated.py:206-238,337-345 for one new token): qkv [B, 3*H*64] = q | k | v of the new token;
+ *   cache [B, Tcap, 2*H*64] = k | v rows of the tokens so far. p = *pos_dev: row p of the cache is WRITTEN with this
+ *   step's k | v, then out[b,h,:] = softmax_{j<=p}(0.125 q . k_j) v_j (the causal mask of a last-row query = all rows
+ *   so far). The caller advances *pos_dev after the last layer.
+ * lvl_cross_attn_rows_fwd (gpt2_gated.py:327-334 + _attn without a mask): multi-head attention of `rows` independent
+ *   query rows q [rows, H*64] over per-context keys / values kv [rows/qrep, Tk, 2*H*64] = k | v (the cross-attention
+ *   c_attn applied to the image tokens once per clip); qrep consecutive query rows share one context (the L positions
+ *   of a teacher-forced caption, or the num_return_sequences samples of a clip). out [rows, H*64]. */
+int lvl_gpt2_embed(const int64_t* ids, const void* wte, const void* wpe, const int* pos_dev, void* out, int rows, int L,
+                   int D, int vocab, int positions, int dtype, void* stream);
+int lvl_gated_add_layernorm(const void* res, const void* y, const float* gate, const float* gamma, const float* beta,
+                            float eps, void* sum_out, void* h_out, int rows, int D, int dtype, void* stream);
+int lvl_act_inplace(void* u, int64_t n, int act, int dtype, void* stream);
+int lvl_decode_self_attn(const void* qkv, void* cache, const int* pos_dev, void* out, int B, int Tcap, int H, int dtype,
+                         void* stream);
+int lvl_cross_attn_rows_fwd(const void* q, const void* kv, void* out, int rows, int qrep, int Tk, int H, int dtype,
+                            void* stream);
 
 /* ---- Linear layers: forward and input-gradient GEMMs with fused epilogues -------------------------------------
  * y[M,N] = epilogue(x[M,K] . w[N,K]^T): both operands bf16, row-major, contraction-contiguous; f32 accumulation.

@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'liblavila_hip.so')
 LVL_F32, LVL_BF16 = 0, 1
 ATTN_SPACE, ATTN_TIME = 0, 1
 EPI_BIAS, EPI_BIAS_QUICKGELU, EPI_QUICKGELU_BWD = 0, 1, 2
+ACT_GELU_NEW, ACT_SQRELU = 0, 1
 
 _c = ctypes
 _P, _I, _L, _F = _c.c_void_p, _c.c_int, _c.c_int64, _c.c_float
@@ -48,6 +49,11 @@ SIGNATURES = {
     'lvl_cls_attn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'lvl_mq_cross_attn_fwd': (_I, [_P, _L, _P, _P, _I, _I, _I, _I, _I, _P]),
     'lvl_qkv_bias_grad': (_I, [_P, _P, _P, _P, _L, _I, _I, _P]),
+    'lvl_gpt2_embed': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    'lvl_gated_add_layernorm': (_I, [_P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _P]),
+    'lvl_act_inplace': (_I, [_P, _L, _I, _I, _P]),
+    'lvl_decode_self_attn': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    'lvl_cross_attn_rows_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
 }
 
 _lib = None

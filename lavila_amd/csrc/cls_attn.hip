@@ -15,7 +15,7 @@ constexpr int SLOTS = 32;      // keys in flight per workgroup step (256 threads
 template <typename T>
 __global__ __launch_bounds__(256) void cls_attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ kv,
                                                            T* __restrict__ out, float* __restrict__ lse, int Tk,
-                                                           int H) {
+                                                           int H, int qrep) {
   __shared__ float sm[SLOTS], sl[SLOTS], sacc[SLOTS][64];
   const int tid = threadIdx.x, sub = tid & 7, slot = tid >> 3;
   const int h = blockIdx.x % H, b = blockIdx.x / H;
@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void cls_attn_fwd_kernel(const T* __restrict__
   Elem<T>::load8(q + (int64_t)b * D + h * 64 + sub * 8, qv);
 #pragma unroll
   for (int c = 0; c < 8; ++c) qv[c] *= 0.125f;
-  const T* kb = kv + (int64_t)b * Tk * 2 * D + h * 64 + sub * 8;
+  const T* kb = kv + (int64_t)(b / qrep) * Tk * 2 * D + h * 64 + sub * 8;     // qrep consecutive query rows share a context
   float m = -INFINITY, l = 0.f, acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   for (int j = slot; j < Tk; j += SLOTS) {
     float kx[8], vx[8];
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void cls_attn_fwd_kernel(const T* __restrict__
       o = fmaf(sacc[s][tid], w, o);
     }
     Elem<T>::store(out + (int64_t)b * D + h * 64 + tid, o / L);
-    if (tid == 0) lse[(int64_t)b * H + h] = M + __logf(L);
+    if (tid == 0 && lse) lse[(int64_t)b * H + h] = M + __logf(L);
   }
 }
 
@@ -131,8 +131,24 @@ extern "C" int lvl_cls_attn_fwd(const void* q, const void* kv, void* out, float*
   LVL_REQUIRE(lvl_aligned16(q) && lvl_aligned16(kv) && lvl_aligned16(out), "cls_attn_fwd: pointers must be 16-byte aligned");
   if (B == 0) return LVL_OK;
   LVL_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((cls_attn_fwd_kernel<T>), dim3((unsigned)(B * H)), dim3(256), 0,
-                                               (hipStream_t)stream, (const T*)q, (const T*)kv, (T*)out, lse, Tk, H));
+                                               (hipStream_t)stream, (const T*)q, (const T*)kv, (T*)out, lse, Tk, H, 1));
   LVL_CHECK_LAUNCH("cls_attn_fwd");
+  return LVL_OK;
+}
+
+extern "C" int lvl_cross_attn_rows_fwd(const void* q, const void* kv, void* out, int rows, int qrep, int Tk, int H,
+                                       int dtype, void* stream) {
+  LVL_REQUIRE(rows == 0 || (q && kv && out), "cross_attn_rows_fwd: null pointer");
+  LVL_REQUIRE(rows >= 0 && qrep > 0 && rows % qrep == 0 && Tk > 0 && H > 0,
+              "cross_attn_rows_fwd: bad shape rows=%d qrep=%d T=%d H=%d", rows, qrep, Tk, H);
+  LVL_REQUIRE((int64_t)rows * H < (1ll << 31), "cross_attn_rows_fwd: rows * heads must stay below 2^31");
+  LVL_REQUIRE(lvl_aligned16(q) && lvl_aligned16(kv) && lvl_aligned16(out),
+              "cross_attn_rows_fwd: pointers must be 16-byte aligned");
+  if (rows == 0) return LVL_OK;
+  LVL_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((cls_attn_fwd_kernel<T>), dim3((unsigned)(rows * H)), dim3(256), 0,
+                                               (hipStream_t)stream, (const T*)q, (const T*)kv, (T*)out, (float*)nullptr,
+                                               Tk, H, qrep));
+  LVL_CHECK_LAUNCH("cross_attn_rows_fwd");
   return LVL_OK;
 }
 

@@ -2,8 +2,9 @@
 `CLIP` (:75-173), `get_loss` (:293-304), `get_metric_names` (:307-313) and the named constructors
 `CLIP_OPENAI_TIMESFORMER_{BASE,LARGE,LARGE_336PX}` (:316-491) -- same names, kwargs (unknown kwargs are
 swallowed exactly as the reference's **kwargs do), output dict keys and state_dict keys, so that
-main_pretrain.py / eval_zeroshot.py drive it unchanged. Only the dual-encoder pretraining path is built
-(SURVEY.md section 8); narrator (VCLM_*), DistilBERT and fine-tuning heads are out of scope and absent.
+main_pretrain.py / eval_zeroshot.py drive it unchanged. Built: the dual-encoder pretraining path
+and, for inference, the narrator on TimeSformer towers (`VCLM_OPENAI_TIMESFORMER_*`, :887-1198; lavila_amd.narrator +
+lavila_amd.gpt2_gated). The per-frame ViT narrators (`VCLM_OPENAI_VIT*`), DistilBERT and fine-tuning heads are absent.
 """
 import contextlib
 import os
@@ -15,6 +16,9 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import loss, ops
+from .gpt2_gated import GPT2LMHeadModel as GatedGPT2LMHeadModel
+from .gpt2_gated import augment_gpt2_config, gpt2_config
+from .narrator import VCLM_HF
 from .openai_model import QuickGELU, Transformer
 from .timesformer import LayerNorm, SpaceTimeTransformer
 from .utils import remap_keys, rsetattr  # noqa: F401  (re-exported like the reference)
@@ -337,3 +341,109 @@ def CLIP_OPENAI_TIMESFORMER_LARGE_336PX(
     return _clip_openai_timesformer('ViT-L/14@336px', vk, 1024, 768, 12, 24, num_frames, timesformer_gated_xattn,
                                     drop_path_rate, timesformer_freeze_space, temperature_init, project_embed_dim,
                                     kwargs)
+
+
+# --------------------------------------------------------------------------------------------------
+# narrator constructors (inference): TimeSformer tower + attention pooling + gated-cross-attention GPT-2
+# --------------------------------------------------------------------------------------------------
+def load_pretrained_gpt2(name):
+    """The reference fetches the GPT-2 checkpoint from the hub (`GPT2LMHeadModel.from_pretrained`, models.py:914-917).
+    Offline: LAVILA_GPT2_WEIGHTS_DIR/<name>.pt holding the HF state_dict, else the decoder keeps its initialisation."""
+    root = os.environ.get('LAVILA_GPT2_WEIGHTS_DIR')
+    if not root:
+        import warnings
+        warnings.warn(f'lavila_amd: pretrained {name} weights are NOT loaded (no network; set LAVILA_GPT2_WEIGHTS_DIR): '
+                      'the decoder keeps its random initialisation, unlike the reference constructor', stacklevel=3)
+        return None
+    path = os.path.join(root, name + '.pt')
+    if not os.path.isfile(path):
+        raise RuntimeError(f'GPT-2 checkpoint {name} not found at {path}')
+    return torch.load(path, map_location='cpu', weights_only=True)
+
+
+def _vclm_openai_timesformer(clip_name, vision_kwargs, vision_width, vision_layers, gpt2_name, cross_attn_freq, text_width,
+                             heads, gated_xattn, random_init_gpt2, freeze_lm_vclm, freeze_visual_vclm,
+                             freeze_visual_vclm_temporal, num_frames, timesformer_gated_xattn, kwargs):
+    """The common body of models.py:887-1198's TimeSformer narrators."""
+    vision_model = SpaceTimeTransformer(
+        num_frames=num_frames, time_init='zeros', attention_style='frozen-in-time', ln_pre=True,
+        act_layer=QuickGELU, is_tanh_gating=timesformer_gated_xattn, **vision_kwargs)
+    clip_sd = load_openai_clip(clip_name, 'cpu')
+    if clip_sd is not None:
+        print(f"=> Loading CLIP ({clip_name}) weights")
+        vis = {k[len('visual.'):]: v for k, v in clip_sd.items() if k.startswith('visual.')}
+        print(vision_model.load_state_dict(remap_keys(vis, transformer_layers=vision_layers), strict=False))
+    vision_model.head = nn.Identity()
+    vision_model.pre_logits = nn.Identity()
+    vision_model.fc = nn.Identity()
+    config = augment_gpt2_config(gpt2_config(gpt2_name), cross_attn_freq=cross_attn_freq, gated_xattn=gated_xattn)
+    text_decoder = GatedGPT2LMHeadModel(config)
+    if not random_init_gpt2:
+        gpt2_sd = load_pretrained_gpt2(gpt2_name)
+        if gpt2_sd is not None:
+            print('Loading LM from pretrained weights..')
+            own = dict(text_decoder.named_parameters())
+            with torch.no_grad():
+                for n, v in gpt2_sd.items():
+                    if n in own:                          # models.py:921-923: every parameter of the plain GPT-2
+                        own[n].copy_(v)
+    if freeze_lm_vclm:
+        print('Freeze the LM part of TextDecoder of VCLM')
+        text_decoder.freeze_lm_weights()
+    if freeze_visual_vclm:
+        print('Freeze the spatial part of VideoEncoder of VCLM')
+        vision_model.freeze_spatial_weights()
+    if freeze_visual_vclm_temporal:
+        print('Freeze the temporal part of VideoEncoder of VCLM')
+        vision_model.freeze_temporal_weights()
+    return VCLM_HF(vision_width=vision_width, vision_model=vision_model, text_width=text_width,
+                   text_decoder=text_decoder, num_img_queries=256, dim_head=64, heads=heads, **kwargs)
+
+
+_TSF_L14 = dict(img_size=224, patch_size=14, embed_dim=1024, depth=24, num_heads=16)
+_TSF_L14_336 = dict(img_size=336, patch_size=14, embed_dim=1024, depth=24, num_heads=16)
+
+
+def VCLM_OPENAI_TIMESFORMER_BASE_GPT2(gated_xattn=False, random_init_gpt2=False, freeze_lm_vclm=False,
+                                      freeze_visual_vclm=False, freeze_visual_vclm_temporal=False, num_frames=4,
+                                      timesformer_gated_xattn=False, **kwargs):
+    """models.py:887-948: TSF-B/16 + GPT-2 (768 wide, 12 layers), cross-attention in every block."""
+    return _vclm_openai_timesformer('ViT-B/16', {}, 768, 12, 'gpt2', 1, 768, 12, gated_xattn, random_init_gpt2,
+                                    freeze_lm_vclm, freeze_visual_vclm, freeze_visual_vclm_temporal, num_frames,
+                                    timesformer_gated_xattn, kwargs)
+
+
+def VCLM_OPENAI_TIMESFORMER_BASE_GPT2_XL(gated_xattn=False, freeze_lm_vclm=False, freeze_visual_vclm=False,
+                                         freeze_visual_vclm_temporal=False, num_frames=4, timesformer_gated_xattn=False,
+                                         **kwargs):
+    """models.py:951-1009: TSF-B/16 + GPT-2 XL (1600 wide, 48 layers), cross-attention in every 2nd block."""
+    return _vclm_openai_timesformer('ViT-B/16', {}, 768, 12, 'gpt2-xl', 2, 1600, 25, gated_xattn, False, freeze_lm_vclm,
+                                    freeze_visual_vclm, freeze_visual_vclm_temporal, num_frames, timesformer_gated_xattn,
+                                    kwargs)
+
+
+def VCLM_OPENAI_TIMESFORMER_LARGE_GPT2_XL(gated_xattn=False, freeze_lm_vclm=False, freeze_visual_vclm=False,
+                                          freeze_visual_vclm_temporal=False, num_frames=4, timesformer_gated_xattn=False,
+                                          **kwargs):
+    """models.py:1012-1072: TSF-L/14 + GPT-2 XL, cross-attention in every 2nd block."""
+    return _vclm_openai_timesformer('ViT-L/14', dict(_TSF_L14), 1024, 24, 'gpt2-xl', 2, 1600, 25, gated_xattn, False,
+                                    freeze_lm_vclm, freeze_visual_vclm, freeze_visual_vclm_temporal, num_frames,
+                                    timesformer_gated_xattn, kwargs)
+
+
+def VCLM_OPENAI_TIMESFORMER_LARGE_GPT2(gated_xattn=False, freeze_lm_vclm=False, freeze_visual_vclm=False,
+                                       freeze_visual_vclm_temporal=False, num_frames=4, timesformer_gated_xattn=False,
+                                       **kwargs):
+    """models.py:1075-1135: TSF-L/14 + GPT-2, cross-attention in every block."""
+    return _vclm_openai_timesformer('ViT-L/14', dict(_TSF_L14), 1024, 24, 'gpt2', 1, 768, 12, gated_xattn, False,
+                                    freeze_lm_vclm, freeze_visual_vclm, freeze_visual_vclm_temporal, num_frames,
+                                    timesformer_gated_xattn, kwargs)
+
+
+def VCLM_OPENAI_TIMESFORMER_LARGE_336PX_GPT2_XL(gated_xattn=False, freeze_lm_vclm=False, freeze_visual_vclm=False,
+                                                freeze_visual_vclm_temporal=False, num_frames=4,
+                                                timesformer_gated_xattn=False, **kwargs):
+    """models.py:1138-1198: TSF-L/14 @336 + GPT-2 XL, cross-attention in every 3rd block."""
+    return _vclm_openai_timesformer('ViT-L/14@336px', dict(_TSF_L14_336), 1024, 24, 'gpt2-xl', 3, 1600, 25, gated_xattn,
+                                    False, freeze_lm_vclm, freeze_visual_vclm, freeze_visual_vclm_temporal, num_frames,
+                                    timesformer_gated_xattn, kwargs)

@@ -1,20 +1,24 @@
-"""Tower-side seam of the narrator (BASELINE configs[4] / SURVEY.md section 8f rank 4), MI355X-native:
-`VCLM_HF.encode_image` = video tower (all-token features) -> attention pooling onto `num_img_queries` learned queries
--> LayerNorm, i.e. everything of `lavila/models/narrator.py:31-90` that runs BEFORE the GPT-2 decoder, with the
-reference's module / parameter names (`img_queries`, `img_attn_pool.{norm.gamma, context_norm.gamma, to_q.weight,
-to_kv.weight, to_out.weight}`, `img_attn_pool_norm.gamma`; the `beta` buffers included) so that a reference
-`VCLM_*` checkpoint's `visual.*`, `img_queries`, `img_attn_pool*` entries load unchanged.
+"""The narrator (BASELINE configs[4] / SURVEY.md section 8f rank 4), MI355X-native, inference only:
+`VCLM_HF` = video tower (all-token features) -> attention pooling onto `num_img_queries` learned queries -> LayerNorm
+(`encode_image`, narrator.py:63-87) -> gated-cross-attention GPT-2 (`lavila_amd.gpt2_gated`) -> `forward` (teacher-forced
+logits, narrator.py:89-104) and `generate` (multinomial / top-k / top-p sampling with perplexities, narrator.py:106-147),
+with the reference's module / parameter names (`visual.*`, `img_queries`, `img_attn_pool.{norm.gamma,
+context_norm.gamma, to_q.weight, to_kv.weight, to_out.weight}`, `img_attn_pool_norm.gamma`, the `beta` buffers,
+`text_decoder.*`) so that a reference `VCLM_*` checkpoint loads unchanged.
 
 `CrossAttention` / `LayerNorm` mirror `lavila/models/coca.py:25-131` (same constructor); the pooling core is one
 C-ABI call (lvl_mq_cross_attn_fwd), the projections go through ops.linear (own MFMA GEMMs where the widths tile),
-the LayerNorms through lvl_layernorm_fwd. Inference only (the narrator row of the scope table is inference): the
-pooling core has no backward kernel and says so. The gated-cross-attention GPT-2 decoder and `generate()`
-(narrator.py:92-389, gpt2_gated.py) are NOT built: `VCLM_HF.forward` works with any decoder module handed to the
-constructor (it only calls it), `generate` raises. This module is deliberately not aliased under
-`lavila.models.narrator`, which keeps resolving to the reference's full implementation.
+the LayerNorms through lvl_layernorm_fwd. The pooling core has no backward kernel and says so.
+
+`generate` keeps the reference's signature and bookkeeping (nll / entropy accumulation, eos tracking, teacher forcing,
+num_return_sequences) but decodes against a key/value cache, one hipGraph replay per token (gpt2_gated.DecodeSession)
+-- the reference re-runs the whole prefix for every token; `kv_cache=False` runs that schedule for comparison.
+`beam_sample` / `group_beam_search` (narrator.py:149-366, built on transformers' BeamSearchScorer) are not built.
+This module is deliberately not aliased under `lavila.models.narrator`, which keeps resolving to the reference's file.
 """
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from . import _cabi as C
 from . import ops
@@ -94,8 +98,8 @@ class CrossAttention(nn.Module):
 
 
 class VCLM_HF(nn.Module):
-    """narrator.py:31-115: same constructor; encode_image is built on the HIP path, forward() only wires the given
-    decoder, generate()/beam search belong to the decoder side and are not built."""
+    """narrator.py:31-147: same constructor; encode_image, forward and generate run on the HIP path (`text_decoder`:
+    a lavila_amd.gpt2_gated.GPT2LMHeadModel); the beam-search variants are not built."""
 
     def __init__(self, vision_width: int, vision_model: nn.Module, text_width: int, text_decoder: nn.Module,
                  num_img_queries=256, dim_head=64, heads=8, **kwargs):
@@ -127,8 +131,7 @@ class VCLM_HF(nn.Module):
     def forward(self, image, text, mask=None, use_checkpoint=False, norm_embed=False):
         """narrator.py:92-110 around whatever decoder the constructor was given."""
         if self.text_decoder is None:
-            raise NotImplementedError('VCLM_HF.forward needs a text decoder; the gated GPT-2 of the reference '
-                                      '(gpt2_gated.py) is not built in lavila_amd')
+            raise NotImplementedError('VCLM_HF.forward needs a text decoder (lavila_amd.gpt2_gated.GPT2LMHeadModel)')
         if use_checkpoint:
             self.text_decoder.gradient_checkpointing_enable()
         else:
@@ -138,6 +141,75 @@ class VCLM_HF(nn.Module):
         logits = self.text_decoder(text.contiguous(), encoder_hidden_states=image_tokens).logits
         return {'text_tokens_logits': logits.permute(0, 2, 1), 'labels': labels}
 
-    def generate(self, *args, **kwargs):
-        raise NotImplementedError('narrator decoding (narrator.py:112-389) is outside the built scope: only the '
-                                  'tower-side seam (encode_image) runs on the HIP path')
+    @staticmethod
+    def _warp(logits, top_k, top_p, temperature):
+        """The logits warpers narrator.py:368-389 builds for num_beams=1 (transformers' Temperature / TopK / TopP warpers,
+        min_tokens_to_keep=1), restated: scale by 1/temperature; keep the top_k largest; drop the low-probability tail
+        whose cumulative mass is <= 1 - top_p (always keeping the most probable token)."""
+        if temperature is not None and temperature != 1.0:
+            logits = logits / temperature
+        if top_k is not None and top_k != 0:
+            k = min(int(top_k), logits.shape[-1])
+            kth = torch.topk(logits, k)[0][..., -1, None]
+            logits = logits.masked_fill(logits < kth, float('-inf'))
+        if top_p is not None and top_p < 1.0:
+            sorted_logits, sorted_idx = torch.sort(logits, descending=False)
+            cum = sorted_logits.softmax(dim=-1).cumsum(dim=-1)
+            remove = cum <= (1 - top_p)
+            remove[..., -1:] = False
+            logits = logits.masked_fill(remove.scatter(1, sorted_idx, remove), float('-inf'))
+        return logits
+
+    def generate(self, image_tokens, tokenizer, target=None, max_text_length=77, top_k=None, top_p=None,
+                 num_return_sequences=1, temperature=1.0, teacher_forcing=False, early_stopping=False, kv_cache=True,
+                 graph=True):
+        """narrator.py:106-147, same arguments and return value (ids [B*n, <=max_text_length], perplexity [B*n]).
+        Per step the decoder yields the next-token logits of every caption; the reference's bookkeeping follows on them
+        unchanged (cross entropy against target[:, i+1] ignoring pad, or the entropy of the distribution while the row
+        has not emitted eos; warp -> softmax -> multinomial). kv_cache=True (default): one new row per caption against
+        cached keys / values, the image keys / values projected once per CLIP (shared by its num_return_sequences
+        samples), one hipGraph replay per token when graph=True. kv_cache=False: the reference's schedule (the whole
+        prefix through the decoder every step)."""
+        n = int(num_return_sequences)
+        B = image_tokens.shape[0] * n
+        device = image_tokens.device
+        bos, eos, pad = tokenizer.bos_token_id, tokenizer.eos_token_id, tokenizer.pad_token_id
+        generated = torch.full((B, 1), bos, dtype=torch.long, device=device)
+        condition = generated.clone()
+        nlls = torch.zeros(B, device=device)
+        num_tokens = torch.zeros(B, device=device)
+        reached = torch.zeros(B, dtype=torch.bool, device=device)
+        if kv_cache and teacher_forcing and target is not None and bool((target[:, 0] != bos).any()):
+            kv_cache = False        # the reference conditions on target[:, :i+2] INCLUDING its first token (narrator.py:140)
+        with torch.no_grad():
+            session = repeated = None
+            if kv_cache:
+                session = self.text_decoder.decode_session(image_tokens, max_text_length, seqs_per_context=n, graph=graph)
+            else:
+                repeated = image_tokens.repeat_interleave(n, dim=0)
+            for i in range(max_text_length - 1):
+                if kv_cache:
+                    logits = session.step(condition[:, -1]).float()
+                else:
+                    logits = self.text_decoder(condition.contiguous(), encoder_hidden_states=repeated).logits[:, -1, :].float()
+                if target is not None:
+                    nlls += F.cross_entropy(logits, target[:, i + 1], ignore_index=pad, reduction='none')
+                    num_tokens += target[:, i + 1].ne(pad)
+                else:
+                    nlls += torch.special.entr(F.softmax(logits, dim=1)).sum(dim=1) * (~reached)
+                    num_tokens += (~reached)
+                probs = F.softmax(self._warp(logits, top_k, top_p, temperature), dim=-1)
+                next_token = torch.multinomial(probs, num_samples=1)
+                reached = reached | (next_token[:, 0] == eos)
+                if early_stopping and bool(torch.all(reached)):
+                    break
+                condition = target[:, :i + 2] if teacher_forcing else torch.cat((generated, next_token), dim=1)
+                generated = torch.cat((generated, next_token), dim=1)
+        return generated, torch.exp(nlls / num_tokens)
+
+    def beam_sample(self, *args, **kwargs):
+        raise NotImplementedError('VCLM_HF.beam_sample (narrator.py:149-241, transformers BeamSearchScorer) is not built; '
+                                  'use generate() -- the reference drivers\' default caption_sample=multinomial_sample')
+
+    def group_beam_search(self, *args, **kwargs):
+        raise NotImplementedError('VCLM_HF.group_beam_search (narrator.py:243-366) is not built; use generate()')

@@ -1,0 +1,335 @@
+"""GPU (-m gpu): the narrator's decoder side (SURVEY.md 8f rank 4 / BASELINE configs[4]) through the C ABI --
+the row kernels of lavila_amd/csrc/decode.hip against the oracle, and `VCLM_HF.forward` / `VCLM_HF.generate` on the
+reference's own outputs (tests/golden/narrator_decoder.pt, generated from the unmodified narrator.py + gpt2_gated.py)."""
+import contextlib
+import io
+import types
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import load_golden
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _tol(dt):
+    return dict(atol=1e-5, rtol=1e-5) if dt == torch.float32 else dict(atol=2e-2, rtol=2e-2)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# kernels
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('rows,L,D,vocab,positions', [(6, 3, 192, 331, 40), (64, 1, 768, 50257, 1024), (5, 5, 1600, 100, 8)])
+def test_gpt2_embed(dt, rows, L, D, vocab, positions):
+    from lavila_amd import _cabi as C
+    g = torch.Generator().manual_seed(1)
+    wte = torch.randn(vocab, D, generator=g).to(dt)
+    wpe = torch.randn(positions, D, generator=g).to(dt)
+    ids = torch.randint(0, vocab, (rows,), generator=g)
+    ids_d, wte_d, wpe_d = ids.to(DEV), wte.to(DEV), wpe.to(DEV)
+    for p0 in (None, 2):
+        pos = None if p0 is None else torch.tensor([p0], dtype=torch.int32, device=DEV)
+        out = torch.empty(rows, D, dtype=dt, device=DEV)
+        C.check(C.lib().lvl_gpt2_embed(C.ptr(ids_d), C.ptr(wte_d), C.ptr(wpe_d), C.ptr(pos), C.ptr(out),
+                                       rows, L, D, vocab, positions, C.dtype_code(out), C.stream_ptr()), 'embed')
+        want = (wte[ids].float() + wpe[(p0 or 0) + torch.arange(rows) % L].float()).to(dt)
+        assert torch.equal(out.cpu(), want)
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('rows,D', [(3, 192), (64, 768), (7, 1600), (2, 4096), (5, 8)])
+def test_gated_add_layernorm(dt, rows, D):
+    from lavila_amd import _cabi as C
+    g = torch.Generator().manual_seed(2)
+    res = torch.randn(rows, D, generator=g).to(dt)
+    y = (2 * torch.randn(rows, D, generator=g)).to(dt)
+    gamma = 1 + 0.1 * torch.randn(D, generator=g)
+    beta = 0.1 * torch.randn(D, generator=g)
+    gate = torch.tensor([0.37])
+    y_d, gate_d, gamma_d, beta_d = y.to(DEV), gate.to(DEV), gamma.to(DEV), beta.to(DEV)
+    for use_y, use_gate, in_place in ((True, True, True), (True, False, False), (False, False, False)):
+        r = res.to(DEV).clone()
+        s = r if in_place else (torch.empty_like(r) if use_y else None)
+        h = torch.empty_like(r)
+        C.check(C.lib().lvl_gated_add_layernorm(C.ptr(r), C.ptr(y_d) if use_y else None,
+                                                C.ptr(gate_d) if use_gate else None, C.ptr(gamma_d),
+                                                C.ptr(beta_d), 1e-5, C.ptr(s), C.ptr(h), rows, D, C.dtype_code(r),
+                                                C.stream_ptr()), 'gated_add_layernorm')
+        want_s = res.float()
+        if use_y:
+            want_s = (want_s + (0.37 if use_gate else 1.0) * y.float()).to(dt).float()
+        want_h = O.layer_norm(want_s, gamma, beta, 1e-5)
+        if s is not None:
+            torch.testing.assert_close(s.float().cpu(), want_s, **(dict(atol=1e-6, rtol=1e-6) if dt == torch.float32
+                                                                   else dict(atol=0, rtol=2 ** -7)))
+        torch.testing.assert_close(h.float().cpu(), want_h, **_tol(dt))
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+def test_decoder_activations(dt):
+    from lavila_amd import _cabi as C
+    x = (3 * torch.randn(40, 3072, generator=torch.Generator().manual_seed(3))).to(dt)
+    for act, fn in ((C.ACT_GELU_NEW, O.gelu_new), (C.ACT_SQRELU, O.sq_relu)):
+        u = x.to(DEV).clone()
+        C.check(C.lib().lvl_act_inplace(C.ptr(u), u.numel(), act, C.dtype_code(u), C.stream_ptr()), 'act')
+        torch.testing.assert_close(u.float().cpu(), fn(x.float()), **_tol(dt))
+        want_torch = F.gelu(x.float(), approximate='tanh') if act == C.ACT_GELU_NEW else torch.relu(x.float()) ** 2
+        torch.testing.assert_close(u.float().cpu(), want_torch, **_tol(dt))
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('B,H,steps,cap', [(2, 3, 9, 12), (3, 12, 70, 77), (1, 1, 1, 1), (2, 2, 40, 64)])
+def test_decode_self_attention_steps(dt, B, H, steps, cap):
+    """Every step appends its k | v row and attends to rows 0..pos: equals the LAST row of the causal attention over the
+    prefix (gpt2_attention_core, gpt2_gated.py:206-238)."""
+    from lavila_amd import _cabi as C
+    D = H * 64
+    g = torch.Generator().manual_seed(4)
+    qkv_all = torch.randn(B, steps, 3 * D, generator=g).to(dt)
+    cache = torch.full((B, cap, 2 * D), float('nan'), dtype=dt, device=DEV)       # unwritten rows must never be read
+    pos = torch.zeros(1, dtype=torch.int32, device=DEV)
+    f = qkv_all.float()
+    want = O.gpt2_attention_core(f[..., :D], f[..., D:2 * D], f[..., 2 * D:], H, causal=True)
+    for t in range(steps):
+        qkv = qkv_all[:, t].contiguous().to(DEV)
+        out = torch.empty(B, D, dtype=dt, device=DEV)
+        C.check(C.lib().lvl_decode_self_attn(C.ptr(qkv), C.ptr(cache), C.ptr(pos), C.ptr(out), B, cap, H,
+                                             C.dtype_code(qkv), C.stream_ptr()), 'decode_self_attn')
+        pos.add_(1)
+        torch.testing.assert_close(out.float().cpu(), want[:, t], **_tol(dt))
+    assert torch.equal(cache[:, :steps].cpu(), qkv_all[..., D:])
+    assert torch.isnan(cache[:, steps:].float()).all()
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('contexts,qrep,H,T', [(2, 1, 3, 24), (3, 12, 12, 256), (2, 5, 2, 37), (1, 3, 1, 1)])
+def test_cross_attention_rows(dt, contexts, qrep, H, T):
+    from lavila_amd import _cabi as C
+    D = H * 64
+    g = torch.Generator().manual_seed(5)
+    q = torch.randn(contexts * qrep, D, generator=g).to(dt)
+    kv = torch.randn(contexts, T, 2 * D, generator=g).to(dt)
+    out = torch.empty(contexts * qrep, D, dtype=dt, device=DEV)
+    q_d, kv_d = q.to(DEV), kv.to(DEV)
+    C.check(C.lib().lvl_cross_attn_rows_fwd(C.ptr(q_d), C.ptr(kv_d), C.ptr(out), contexts * qrep, qrep, T, H,
+                                            C.dtype_code(out), C.stream_ptr()), 'cross_attn_rows')
+    kf = kv.float()
+    want = O.gpt2_attention_core(q.float().reshape(contexts, qrep, D), kf[..., :D], kf[..., D:], H, causal=False)
+    torch.testing.assert_close(out.float().cpu(), want.reshape(-1, D), **_tol(dt))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the model on the reference's outputs
+# ----------------------------------------------------------------------------------------------------------------------
+def _build(c, d, var, width=None, heads=None):
+    from lavila.models.openai_model import QuickGELU
+    from lavila.models.timesformer import SpaceTimeTransformer
+    from lavila_amd.gpt2_gated import GPT2LMHeadModel, augment_gpt2_config, gpt2_config
+    from lavila_amd.narrator import VCLM_HF
+    width, heads = width or c['text_width'], heads or c['pool_heads']
+    with contextlib.redirect_stdout(io.StringIO()):
+        vis = SpaceTimeTransformer(img_size=c['img'], patch_size=c['patch'], embed_dim=c['dim'], depth=c['depth'],
+                                   num_heads=c['heads'], num_frames=c['frames'], time_init='zeros',
+                                   attention_style='frozen-in-time', ln_pre=True, act_layer=QuickGELU)
+    vis.head = vis.pre_logits = vis.fc = torch.nn.Identity()
+    base = gpt2_config('gpt2', vocab_size=d['vocab'], n_positions=d['positions'], n_embd=width, n_layer=d['layers'],
+                       n_head=heads)
+    dec = GPT2LMHeadModel(augment_gpt2_config(base, **var))
+    return VCLM_HF(vision_width=c['dim'], vision_model=vis, text_width=width, text_decoder=dec,
+                   num_img_queries=c['queries'], dim_head=64, heads=heads)
+
+
+def _golden_model(variant):
+    fx = load_golden('narrator_decoder.pt')
+    c, d, v = fx['config'], fx['decoder'], fx['variants'][variant]
+    m = _build(c, d, v['variant'])
+    w = O.narrator_weights(v['shapes'], seed=v['weight_seed'])
+    own = m.state_dict()
+    assert set(v['shapes']) | set(v['kept_buffers']) | {'text_decoder.lm_head.weight'} == set(own)
+    for k in v['kept_buffers']:                     # causal-mask buffers / beta zeros keep their constructed values
+        w[k] = own[k]
+    m.load_state_dict(w, strict=True)
+    assert m.text_decoder.lm_head.weight is m.text_decoder.transformer.wte.weight
+    video, _ = O.synthetic_batch(c['batch'], c['frames'], c['img'], seed=v['input_seed'])
+    tok = types.SimpleNamespace(bos_token_id=v['bos'], eos_token_id=v['eos'], pad_token_id=v['pad'])
+    return m.to(DEV).eval(), c, d, v, video.to(DEV), tok
+
+
+@pytest.mark.parametrize('variant', ['freq1_gated', 'freq2_plain'])
+def test_narrator_forward_matches_reference_f32(variant):
+    """VCLM_HF.forward (narrator.py:89-104): teacher-forced logits [B, V, L-1] and labels, float32 within 1e-3 of the
+    reference's CPU output (logits of a few units)."""
+    m, c, d, v, video, tok = _golden_model(variant)
+    with torch.no_grad():
+        out = m(video, v['text'].to(DEV))
+    assert out['text_tokens_logits'].dtype == torch.float32
+    assert torch.equal(out['labels'].cpu(), v['labels'])
+    torch.testing.assert_close(out['text_tokens_logits'].cpu(), v['logits'], atol=2e-3, rtol=1e-3)
+
+
+@pytest.mark.parametrize('graph', [False, True])
+@pytest.mark.parametrize('variant', ['freq1_gated', 'freq2_plain'])
+def test_narrator_generate_matches_reference_f32(variant, graph):
+    """VCLM_HF.generate(top_k=1) (narrator.py:106-147) on the reference's own ids / perplexities: free running, with a
+    live eos, early stopping, target scoring with and without teacher forcing, num_return_sequences -- decoded against the
+    key/value cache (eagerly and as hipGraph replays), and once more on the reference's recompute schedule."""
+    m, c, d, v, video, tok = _golden_model(variant)
+    no_eos = types.SimpleNamespace(bos_token_id=v['bos'], eos_token_id=-1, pad_token_id=v['pad'])
+    text = v['text'].to(DEV)
+    with torch.no_grad():
+        img = m.encode_image(video)
+        torch.testing.assert_close(img.cpu(), v['image_tokens'], atol=1e-3, rtol=1e-3)
+        runs = [
+            ('free', dict(tokenizer=no_eos, max_text_length=d['max_text_length'])),
+            ('eos', dict(tokenizer=tok, max_text_length=d['max_text_length'])),
+            ('tf', dict(tokenizer=tok, target=text, max_text_length=d['text_len'], teacher_forcing=True)),
+            ('tgt', dict(tokenizer=tok, target=text, max_text_length=d['text_len'])),
+            ('rep', dict(tokenizer=tok, max_text_length=8, num_return_sequences=2)),
+        ]
+        for name, kw in runs:
+            for cache in ((True,) if graph else (True, False)):
+                ids, ppl = m.generate(img, top_k=1, kv_cache=cache, graph=graph, **kw)
+                assert torch.equal(ids.cpu(), v[name + '_ids']), (name, cache)
+                torch.testing.assert_close(ppl.cpu(), v[name + '_ppl'], atol=0, rtol=5e-3, msg=lambda s: f'{name} {cache}: {s}')
+        ids, ppl = m.generate(img[:1], tok, max_text_length=d['max_text_length'], top_k=1, early_stopping=True, graph=graph)
+        assert torch.equal(ids.cpu(), v['stop_ids'])
+        torch.testing.assert_close(ppl.cpu(), v['stop_ppl'], atol=0, rtol=5e-3)
+
+
+def test_narrator_sampling_warpers_and_shapes():
+    """top-k / top-p / temperature restate transformers' warpers (narrator.py:368-389); multinomial sampling stays inside
+    the kept set and the outputs have the reference's shapes."""
+    from lavila_amd.narrator import VCLM_HF
+    g = torch.Generator().manual_seed(6)
+    logits = torch.randn(4, 50, generator=g).to(DEV)
+    w = VCLM_HF._warp(logits, top_k=5, top_p=None, temperature=0.7)
+    assert ((w > float('-inf')).sum(-1) == 5).all()
+    kept = torch.topk(logits, 5).indices
+    assert torch.equal(torch.sort((w > float('-inf')).nonzero()[:, 1].reshape(4, 5)).values, torch.sort(kept).values)
+    torch.testing.assert_close(w.gather(1, kept), logits.gather(1, kept) / 0.7)
+    w = VCLM_HF._warp(logits, top_k=None, top_p=0.6, temperature=1.0)
+    p = logits.softmax(-1)
+    for r in range(4):
+        keep = w[r] > float('-inf')
+        order = torch.argsort(p[r], descending=True)
+        k = int(keep.sum())
+        assert torch.equal(torch.sort(order[:k]).values, keep.nonzero()[:, 0])       # a prefix of the sorted probabilities
+        assert p[r][order[:k]].sum() >= 0.6 - 1e-6 and (k == 1 or p[r][order[:k - 1]].sum() < 0.6 + 1e-6)
+    m, c, d, v, video, tok = _golden_model('freq1_gated')
+    with torch.no_grad():
+        img = m.encode_image(video)
+        torch.manual_seed(0)
+        ids, ppl = m.generate(img, tok, max_text_length=10, top_k=3, top_p=0.9, temperature=0.8, num_return_sequences=3)
+    assert ids.shape == (3 * c['batch'], 10) and ppl.shape == (3 * c['batch'],)
+    assert (ids[:, 0] == v['bos']).all() and ids.max() < d['vocab'] and torch.isfinite(ppl).all()
+
+
+def _mid_model(dtype_mode, width=256, heads=4, layers=2, vocab=331, freq=1):
+    """A decoder whose widths tile the own GEMM (out % 256, in % 64) with procedural weights; the oracle is its checker."""
+    fx = load_golden('narrator_decoder.pt')
+    c = dict(fx['config'])
+    c.update(text_width=width, pool_heads=heads)
+    d = dict(fx['decoder'], layers=layers, vocab=vocab)
+    m = _build(c, d, dict(cross_attn_freq=freq, gated_xattn=True), width, heads)
+    sd = m.state_dict()
+    keep = [k for k in sd if k.endswith('.attn.bias') or k.endswith('.crossattention.bias') or k.endswith('masked_bias')
+            or k.endswith('.beta')]
+    shapes = {k: tuple(t.shape) for k, t in sd.items() if k not in keep and k != 'text_decoder.lm_head.weight'}
+    w = O.narrator_weights(shapes, seed=41)
+    m.load_state_dict({**w, **{k: sd[k] for k in keep}}, strict=True)
+    return m.to(DEV).eval(), c, d, w
+
+
+@pytest.mark.parametrize('mode', ['bf16', 'half', 'autocast'])
+def test_decoder_low_precision_on_own_gemms(mode, monkeypatch):
+    """bf16 parameters, the --use-half recipe (fp16 parameters, docs/PRETRAIN.md:85-91) and f32 masters under autocast:
+    every Conv1D of the decoder runs on lvl_linear_tn (no library GEMM), teacher-forced logits and cached decoding agree
+    with the f32 oracle within the bf16 bound, cached == recomputed."""
+    from lavila_amd import ops
+    m, c, d, w = _mid_model(mode)
+    H = c['pool_heads']
+    g = torch.Generator().manual_seed(9)
+    B, L, NQ = 3, 11, c['queries']
+    ids = torch.randint(1, d['vocab'], (B, L), generator=g)
+    enc = torch.randn(B, NQ, c['text_width'], generator=g)
+    want, _ = O.gpt2_lm_logits(ids, enc, w, H, prefix='text_decoder.')
+    calls = []
+    real = ops.linear_tn_raw
+    monkeypatch.setattr(ops, 'linear_tn_raw', lambda *a, **k: (calls.append(a[1].shape), real(*a, **k))[1])
+    monkeypatch.setattr(F, 'linear', lambda *a, **k: (_ for _ in ()).throw(AssertionError('library GEMM in the decoder')))
+    dec = m.text_decoder
+    ctx = contextlib.nullcontext()
+    if mode == 'bf16':
+        dec = dec.bfloat16()
+        enc_dev = enc.to(DEV).bfloat16()
+    elif mode == 'half':
+        dec = dec.half()
+        enc_dev = enc.to(DEV).half()
+    else:
+        enc_dev = enc.to(DEV)
+        ctx = torch.autocast('cuda', dtype=torch.bfloat16)
+    with torch.no_grad(), ctx:
+        got = dec(ids.to(DEV), encoder_hidden_states=enc_dev).logits
+        assert got.dtype == {'bf16': torch.bfloat16, 'half': torch.float16, 'autocast': torch.bfloat16}[mode]
+        n_full = len(calls)
+        assert n_full == d['layers'] * 9 + 1              # 4 + 4 Conv1Ds and the image k|v projection per block, lm_head
+        scale = want.abs().max().item()
+        assert (got.float().cpu() - want).abs().max().item() < 0.04 * scale
+        for graph in (False, True):
+            sess = dec.decode_session(enc_dev, L, graph=graph)
+            for t in range(L):
+                step = sess.step(ids[:, t].to(DEV)).float().cpu()
+                assert (step - want[:, t]).abs().max().item() < 0.04 * scale, (graph, t)
+                assert (step - got[:, t].float().cpu()).abs().max().item() < 0.04 * scale
+            assert not sess.stale()
+            with pytest.raises(RuntimeError):
+                sess.step(ids[:, 0].to(DEV))             # the cache is full
+
+
+def test_decode_session_graph_equals_eager_bitwise_and_tracks_weights():
+    """The captured step replays the eager step's kernels: identical bits; a parameter write makes the session stale and
+    the next forward rebuilds the packed weights."""
+    m, c, d, w = _mid_model('bf16')
+    dec = m.text_decoder.bfloat16()
+    g = torch.Generator().manual_seed(10)
+    ids = torch.randint(1, d['vocab'], (4, 7), generator=g).to(DEV)
+    enc = torch.randn(2, c['queries'], c['text_width'], generator=g).to(DEV).bfloat16()
+    with torch.no_grad():
+        a = dec.decode_session(enc, 7, seqs_per_context=2, graph=False)
+        b = dec.decode_session(enc, 7, seqs_per_context=2, graph=True)
+        for t in range(7):
+            assert torch.equal(a.step(ids[:, t]), b.step(ids[:, t]))
+        full = dec(ids, encoder_hidden_states=enc.repeat_interleave(2, dim=0)).logits
+        before = full.clone()
+        dec.transformer.ln_f.weight.mul_(2.0)           # in place under no_grad: bumps the version the pack is keyed on
+        assert a.stale() and b.stale()
+        after = dec(ids, encoder_hidden_states=enc.repeat_interleave(2, dim=0)).logits
+        assert not torch.equal(before, after)
+
+
+def test_decoder_is_loud_about_what_it_does_not_do():
+    m, c, d, w = _mid_model('f32')
+    dec = m.text_decoder
+    ids = torch.zeros(1, 4, dtype=torch.long, device=DEV)
+    with pytest.raises(NotImplementedError):
+        dec(ids)                                                     # gradients enabled on trainable parameters
+    with torch.no_grad():
+        for kw in (dict(attention_mask=torch.ones(1, 4, device=DEV)), dict(use_cache=True),
+                   dict(past_key_values=((None, None),))):
+            with pytest.raises(NotImplementedError):
+                dec(ids, **kw)
+        with pytest.raises(ValueError):
+            dec(torch.zeros(1, d['positions'] + 1, dtype=torch.long, device=DEV))
+        plain = dec(ids).logits                                      # no image tokens: plain GPT-2 (gpt2_gated.py:432)
+        want, _ = O.gpt2_lm_logits(ids.cpu(), None, w, c['pool_heads'], prefix='text_decoder.')
+        torch.testing.assert_close(plain.cpu(), want, atol=2e-3, rtol=1e-3)
+        with pytest.raises(NotImplementedError):
+            m.beam_sample(None, None)
+        from lavila_amd._cabi import HipExtensionError
+        with pytest.raises(HipExtensionError):
+            m.text_decoder.cpu()(ids.cpu())                          # no CPU fallback

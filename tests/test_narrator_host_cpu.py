@@ -1,0 +1,163 @@
+"""CPU (-m "not gpu"): the HOST logic of the narrator's decoder side -- the order of Conv1Ds, gates, fused add+LayerNorm
+hand-overs and the key/value-cache bookkeeping of lavila_amd.gpt2_gated, and VCLM_HF.generate's sampling bookkeeping --
+with every device primitive (the C-ABI calls) replaced by its oracle formula on CPU tensors. What is checked is the
+plan around the kernels, against the reference's own outputs (tests/golden/narrator_decoder.pt); the kernels themselves
+are checked on the GPU (tests/test_gpu_narrator.py). Nothing here is a product path: lavila_amd has no CPU fallback."""
+import contextlib
+import io
+import types
+
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import oracle as O
+
+
+def _emulate_device_primitives(monkeypatch):
+    from lavila_amd import _cabi as C
+    from lavila_amd import gpt2_gated as G
+    from lavila_amd import ops
+    monkeypatch.setattr(C, 'require_device', lambda *a: None)
+
+    def embed(self, ids, L, pos_dev=None):
+        ids = ids.reshape(-1)
+        p0 = 0 if pos_dev is None else int(pos_dev)
+        return (self.wte[ids] + self.wpe[p0 + torch.arange(ids.shape[0]) % L]).to(self.dtype)
+
+    def add_ln(self, res, y, gate, ln):
+        if y is not None:
+            res += (1.0 if gate is None else gate) * y
+        return O.layer_norm(res, ln[0], ln[1], self.eps)
+
+    def act(self, u, which):
+        u.copy_(O.gelu_new(u) if which == C.ACT_GELU_NEW else O.sq_relu(u))
+        return u
+
+    def cross_attn(self, q, kv, qrep):
+        D = self.D
+        ctx = kv.shape[0]
+        return O.gpt2_attention_core(q.reshape(ctx, qrep, D), kv[..., :D], kv[..., D:], self.heads, causal=False).reshape(-1, D)
+
+    def causal_attention(qkv, heads, bias=None):
+        D = qkv.shape[-1] // 3
+        return O.gpt2_attention_core(qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:], heads, causal=True)
+
+    def self_attention(self, i, qkv):
+        D = self.pack.D
+        p = int(self.pos)
+        self.cache[i][:, p] = qkv[:, D:]
+        kv = self.cache[i][:, :p + 1]
+        return O.gpt2_attention_core(qkv[:, None, :D], kv[..., :D], kv[..., D:], self.pack.heads, causal=True)[:, 0]
+
+    monkeypatch.setattr(G._Pack, 'embed', embed)
+    monkeypatch.setattr(G._Pack, 'add_ln', add_ln)
+    monkeypatch.setattr(G._Pack, 'act', act)
+    monkeypatch.setattr(G._Pack, 'cross_attn', cross_attn)
+    monkeypatch.setattr(G.DecodeSession, '_self_attention', self_attention)
+    monkeypatch.setattr(ops, 'causal_attention', causal_attention)
+
+
+def _model(variant):
+    from lavila.models.openai_model import QuickGELU
+    from lavila.models.timesformer import SpaceTimeTransformer
+    from lavila_amd.gpt2_gated import GPT2LMHeadModel, augment_gpt2_config, gpt2_config
+    from lavila_amd.narrator import VCLM_HF
+    fx = load_golden('narrator_decoder.pt')
+    c, d, v = fx['config'], fx['decoder'], fx['variants'][variant]
+    with contextlib.redirect_stdout(io.StringIO()):
+        vis = SpaceTimeTransformer(img_size=c['img'], patch_size=c['patch'], embed_dim=c['dim'], depth=c['depth'],
+                                   num_heads=c['heads'], num_frames=c['frames'], time_init='zeros',
+                                   attention_style='frozen-in-time', ln_pre=True, act_layer=QuickGELU)
+    vis.head = vis.pre_logits = vis.fc = torch.nn.Identity()
+    base = gpt2_config('gpt2', vocab_size=d['vocab'], n_positions=d['positions'], n_embd=c['text_width'],
+                       n_layer=d['layers'], n_head=c['pool_heads'])
+    dec = GPT2LMHeadModel(augment_gpt2_config(base, **v['variant']))
+    m = VCLM_HF(vision_width=c['dim'], vision_model=vis, text_width=c['text_width'], text_decoder=dec,
+                num_img_queries=c['queries'], dim_head=64, heads=c['pool_heads'])
+    w = O.narrator_weights(v['shapes'], seed=v['weight_seed'])
+    own = m.state_dict()
+    assert set(v['shapes']) | set(v['kept_buffers']) | {'text_decoder.lm_head.weight'} == set(own)
+    for k in v['kept_buffers']:
+        w[k] = own[k]
+    m.load_state_dict(w, strict=True)
+    assert dec.lm_head.weight is dec.transformer.wte.weight
+    return m.eval(), c, d, v
+
+
+@pytest.mark.parametrize('variant', ['freq1_gated', 'freq2_plain'])
+def test_decoder_plan_and_generate_bookkeeping(variant, monkeypatch):
+    _emulate_device_primitives(monkeypatch)
+    m, c, d, v = _model(variant)
+    img = v['image_tokens']
+    text = v['text']
+    tok = types.SimpleNamespace(bos_token_id=v['bos'], eos_token_id=v['eos'], pad_token_id=v['pad'])
+    no_eos = types.SimpleNamespace(bos_token_id=v['bos'], eos_token_id=-1, pad_token_id=v['pad'])
+    with torch.no_grad():
+        out = m.text_decoder(text[:, :-1].contiguous(), encoder_hidden_states=img)
+        torch.testing.assert_close(out.logits.permute(0, 2, 1), v['logits'], atol=2e-4, rtol=1e-4)
+        assert out[0] is out.logits
+        lab = m.text_decoder(text, encoder_hidden_states=img, labels=text)
+        assert lab.loss is not None and lab[0] is lab.loss and torch.isfinite(lab.loss)
+        runs = [
+            ('free', dict(tokenizer=no_eos, max_text_length=d['max_text_length'])),
+            ('eos', dict(tokenizer=tok, max_text_length=d['max_text_length'])),
+            ('tf', dict(tokenizer=tok, target=text, max_text_length=d['text_len'], teacher_forcing=True)),
+            ('tgt', dict(tokenizer=tok, target=text, max_text_length=d['text_len'])),
+            ('rep', dict(tokenizer=tok, max_text_length=8, num_return_sequences=2)),
+        ]
+        for name, kw in runs:
+            for cache in (True, False):
+                ids, ppl = m.generate(img, top_k=1, kv_cache=cache, graph=False, **kw)
+                assert torch.equal(ids, v[name + '_ids']), (name, cache)
+                torch.testing.assert_close(ppl, v[name + '_ppl'], atol=0, rtol=1e-3)
+        ids, ppl = m.generate(img[:1], tok, max_text_length=d['max_text_length'], top_k=1, early_stopping=True, graph=False)
+        assert torch.equal(ids, v['stop_ids'])
+        torch.testing.assert_close(ppl, v['stop_ppl'], atol=0, rtol=1e-3)
+        # a target whose first token is not bos: the reference conditions on it from the second step on (narrator.py:140)
+        odd = text.clone()
+        odd[:, 0] = 5
+        a = m.generate(img, tok, target=odd, max_text_length=6, top_k=1, teacher_forcing=True, graph=False)
+        want = O.narrator_generate_greedy(img, O.narrator_weights(v['shapes'], seed=v['weight_seed']), c['pool_heads'],
+                                          v['bos'], v['eos'], v['pad'], 6, target=odd, teacher_forcing=True, use_cache=False)
+        assert torch.equal(a[0], want[0])
+        torch.testing.assert_close(a[1], want[1], atol=0, rtol=1e-3)
+
+
+def test_reference_state_dict_names_and_shapes():
+    """Every key / shape / dtype of the reference's gated GPT2LMHeadModel (gpt2_gated.py, imported unmodified) exists in
+    lavila_amd.gpt2_gated.GPT2LMHeadModel and vice versa, for both cross-attention layouts."""
+    from oracle.ref_import import load_reference_narrator, reference_available
+    if not reference_available():
+        pytest.skip('reference not mounted')
+    from transformers import GPT2Config
+    from lavila_amd.gpt2_gated import GPT2LMHeadModel, augment_gpt2_config
+    ref = load_reference_narrator()
+    for freq, gated in ((1, True), (2, False), (3, True)):
+        base = GPT2Config(vocab_size=97, n_positions=24, n_embd=128, n_layer=4, n_head=2, use_cache=False,
+                          bos_token_id=96, eos_token_id=96)
+        theirs = ref.gpt2_gated.GPT2LMHeadModel(ref.gpt2_gated.augment_gpt2_config(base, cross_attn_freq=freq,
+                                                                                   gated_xattn=gated)).state_dict()
+        ours = GPT2LMHeadModel(augment_gpt2_config(base, cross_attn_freq=freq, gated_xattn=gated)).state_dict()
+        assert set(ours) == set(theirs)
+        for k in ours:
+            assert ours[k].shape == theirs[k].shape and ours[k].dtype == theirs[k].dtype, k
+            if k.endswith('.bias') and ours[k].dtype == torch.uint8 or k.endswith('masked_bias'):
+                assert torch.equal(ours[k], theirs[k]), k
+
+
+def test_vclm_constructors_and_cpu_is_loud():
+    import warnings
+    from lavila.models import models
+    from lavila_amd._cabi import HipExtensionError
+    with warnings.catch_warnings(), contextlib.redirect_stdout(io.StringIO()):
+        warnings.simplefilter('ignore')
+        m = models.VCLM_OPENAI_TIMESFORMER_BASE_GPT2(gated_xattn=True, freeze_lm_vclm=True, num_frames=4)
+    dec = m.text_decoder
+    assert len(dec.transformer.h) == 12 and all(b.has_cross for b in dec.transformer.h)
+    assert dec.transformer.h[0].alpha_cattn.requires_grad and not dec.transformer.h[0].attn.c_attn.weight.requires_grad
+    assert m.img_queries.shape == (256, 768) and dec.lm_head.weight is dec.transformer.wte.weight
+    with torch.no_grad(), pytest.raises(HipExtensionError):
+        dec(torch.zeros(1, 3, dtype=torch.long))
+    with pytest.raises(NotImplementedError):
+        m.group_beam_search()
