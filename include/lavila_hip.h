@@ -221,6 +221,16 @@ int lvl_mq_cross_attn_fwd(const void* q, int64_t q_batch_stride, const void* kv,
  *   query rows q [rows, H*64] over per-context keys / values kv [rows/qrep, Tk, 2*H*64] = k | v (the cross-attention
  *   c_attn applied to the image tokens once per clip); qrep consecutive query rows share one context (the L positions
  *   of a teacher-forced caption, or the num_return_sequences samples of a clip). out [rows, H*64]. */
+/* lvl_linear_skinny: y[M,N] = act(x[M,K] . w[N,K]^T + bias) for FEW rows -- the decoder's Conv1Ds while decoding
+ * (M = captions in flight; gpt2_gated.py:327-334,337,354,392-394) and its lm_head. bf16 x / w / y, f32 bias (nullable)
+ * and accumulation; act: -1 none, LVL_ACT_GELU_NEW, LVL_ACT_SQRELU (applied to the f32 sum before the bf16 store).
+ * One workgroup per 16 rows x 16 (N < 2048) or 32 columns, its 8 waves splitting K (lvl_linear_tn gives a 256-column
+ * panel to one compute unit, which at M <= 64 leaves the chip idle). N % 16 == 0 and K % 32 == 0, else LVL_ENOSYS; any
+ * M >= 0 (every 16-row block re-reads its weight strip, from the L2 of the XCD the strip's blocks share). */
+int lvl_linear_skinny(const void* x, const void* w, const float* bias, void* y, int M, int N, int K, int act, void* stream);
+/* Measurement hook (tools/probe_skinny.py): selects another workgroup tiling / k-step assignment of lvl_linear_skinny for
+ * shapes that allow it (0 = the shipped choice). Results are the same up to f32 summation order. */
+int lvl_debug_skinny_variant(int variant);
 int lvl_gpt2_embed(const int64_t* ids, const void* wte, const void* wpe, const int* pos_dev, void* out, int rows, int L,
                    int D, int vocab, int positions, int dtype, void* stream);
 int lvl_gated_add_layernorm(const void* res, const void* y, const float* gate, const float* gamma, const float* beta,
@@ -230,6 +240,27 @@ int lvl_decode_self_attn(const void* qkv, void* cache, const int* pos_dev, void*
                          void* stream);
 int lvl_cross_attn_rows_fwd(const void* q, const void* kv, void* out, int rows, int qrep, int Tk, int H, int dtype,
                             void* stream);
+/* Measurement hook: waves per workgroup (4 / 8 / 16) of lvl_cross_attn_rows_fwd's shared-context kernel; 0 = by qrep. */
+int lvl_debug_cross_attn_waves(int waves);
+
+/* lvl_sample_next_token: everything VCLM_HF.generate does with one step's logits (narrator.py:122-137 and the warpers
+ * of :368-389 = transformers' Temperature / TopK / TopP logits warpers with min_tokens_to_keep = 1), one workgroup per
+ * caption, the row resident in LDS as 16-bit keys -- no sort, no [rows, vocab] temporaries:
+ *   nll[r]     = target ? (target[r] == pad_id ? 0 : logsumexp(l_r) - l_r[target[r]])      F.cross_entropy(ignore_index=pad)
+ *                       : entropy of softmax(l_r)                                          torch.special.entr(softmax).sum()
+ *   counted[r] = target ? (target[r] != pad_id) : 1
+ *   next_token[r] ~ softmax(warp(l_r)): l / temperature; keep the top_k largest (0 = off; ties with the k-th stay);
+ *                drop the ascending-probability tail whose cumulative mass is <= 1 - top_p (1 = off), always keeping
+ *                the largest; inverse CDF over the kept entries in index order at uniform[r] (in [0,1), e.g. torch.rand).
+ * logits: [rows, >= vocab] bf16, row stride row_stride elements (a multiple of 8, rows 16-byte aligned, >= vocab rounded
+ * up to 8: the padded product the lm_head GEMM leaves). vocab <= lvl_sample_max_vocab() (the row must fit 160 KB of
+ * LDS; GPT-2's 50257 does), else LVL_ENOSYS. target / dbg nullable; dbg [rows,12] f32 = (lowest kept value, ties dropped
+ * at the top-p boundary, kept mass relative to e^max, top-p boundary value; microseconds spent in the kernel's 5 phases,
+ * start time) for tests and tools/probe_narrator.py. */
+int lvl_sample_max_vocab(void);
+int lvl_sample_next_token(const void* logits, int64_t row_stride, int rows, int vocab, float temperature, int top_k,
+                          float top_p, const float* uniform, const int64_t* target, int64_t pad_id, int64_t* next_token,
+                          float* nll, float* counted, float* dbg, void* stream);
 
 /* ---- Linear layers: forward and input-gradient GEMMs with fused epilogues -------------------------------------
  * y[M,N] = epilogue(x[M,K] . w[N,K]^T): both operands bf16, row-major, contraction-contiguous; f32 accumulation.

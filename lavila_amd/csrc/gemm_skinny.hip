@@ -1,0 +1,197 @@
+// y[M,N] = act(x[M,K] . w[N,K]^T + bias) for FEW rows (decoding: M = captions in flight), bf16 operands, gfx950.
+//
+// The persistent 256x256-tile GEMM (gemm_tn_mfma.hip) hands a whole 256-column weight panel to ONE compute unit: at
+// M = 64 a GPT-2 Conv1D then costs ~32 us however small it is (measured, profiles/r03_narrator_decode.txt) -- one CU
+// streams 0.4..1.5 MB of weights alone while 250 CUs idle. A decode step is ~100 such GEMMs. Here the work is cut into
+// (16 rows) x (16 or 32 columns) outputs, one workgroup each, so that hundreds of compute units pull 50..200 KB each:
+//   * the 8 waves of a workgroup split the CONTRACTION: wave w takes the 32-wide k-steps w, w+8, w+16, ... (adjacent
+//     waves read adjacent 64-byte segments of every weight / activation row), keeps one f32 accumulator per column
+//     block, and the eight partial sums meet in LDS at the end;
+//   * v_mfma_f32_16x16x32_bf16 with the WEIGHT rows as operand A and the activation rows as operand B: a lane then
+//     holds 4 consecutive output columns of one row (8-byte stores), as in the big kernel;
+//   * fragments go straight from memory to registers (16-byte loads, up to 6 k-steps in flight per wave before the first
+//     MFMA). The first version of this kernel gave a workgroup all 64 rows of a strip: 0.5 MB through one CU's
+//     texture path, 15 us per GEMM; 16 rows per workgroup cut that to the weights' share;
+//   * beyond 128 rows a workgroup takes 64 rows x 32 columns, wide matrices (N >= 2048) 32 rows x 64 columns: more reuse
+//     of every fragment while there are still hundreds of workgroups (the choice per shape is measured, see the
+//     dispatch at the bottom); a wave's k-steps come in PAIRS where that wins (both 64-byte halves of a 128-byte line);
+//   * the 16-row blocks of one column strip re-read the strip's weights: the workgroup id is laid out so that they
+//     run on the SAME XCD (id % 8) within 8 * row-blocks consecutive ids -- the re-reads hit that XCD's L2;
+//   * epilogue: + bias, optional gelu_new / relu^2 (the two MLP activations of the gated GPT-2, gpt2_gated.py:363-396),
+//     bf16 store. Rows >= M are never stored (their loads are clamped to row M-1).
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 sk_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float sk_f32x4;
+
+namespace {
+
+constexpr int WAVES = 8;     // waves per workgroup = ways the contraction is split
+constexpr int CH = 6;        // k-steps fetched ahead per wave (6 steps x 8 waves = 1536 contraction elements per round)
+constexpr int ACT_NONE = -1;
+
+__device__ __forceinline__ sk_f32x4 sk_mfma(uint4 a, uint4 b, sk_f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(sk_bf16x8, a), __builtin_bit_cast(sk_bf16x8, b), c,
+                                                 0, 0, 0);
+}
+
+template <int ACT>
+__device__ __forceinline__ float sk_act(float v) {
+  if (ACT == LVL_ACT_GELU_NEW) {
+    const float t = tanhf(0.7978845608028654f * (v + 0.044715f * v * v * v));
+    return 0.5f * v * (1.f + t);
+  }
+  if (ACT == LVL_ACT_SQRELU) {
+    const float t = fmaxf(v, 0.f);
+    return t * t;
+  }
+  return v;
+}
+
+template <int NB, int RB, int ACT, bool PAIR>
+__global__ __launch_bounds__(512) void skinny_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w,
+                                                     const float* __restrict__ bias, uint16_t* __restrict__ y, int M,
+                                                     int N, int K, int nstrips, int nmb) {
+  extern __shared__ __align__(16) unsigned char sk_smem[];
+  sk_f32x4 (*part)[NB * RB][64] = reinterpret_cast<sk_f32x4 (*)[NB * RB][64]>(sk_smem);   // [wave][block][lane]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  // id = (strip / 8) * (8 * nmb) + mb * 8 + strip % 8: the row groups of a strip share an XCD and arrive together
+  const int id = blockIdx.x;
+  const int strip = (id / (8 * nmb)) * 8 + (id & 7), mb = (id >> 3) % nmb;
+  if (strip >= nstrips) return;                            // uniform: the grid is padded to whole groups of 8 strips
+  const int n0 = strip * (16 * NB), m0 = mb * (16 * RB);
+  const uint16_t* wp[NB];
+  const uint16_t* xp[RB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) wp[nb] = w + (int64_t)(n0 + nb * 16 + c) * K + g * 8;
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const int row = m0 + rb * 16 + c;
+    xp[rb] = x + (int64_t)(row < M ? row : M - 1) * K + g * 8;
+  }
+  sk_f32x4 acc[NB][RB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) acc[nb][rb] = sk_f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nsteps = K >> 5;
+  // step of slot i in a round starting at s0. PAIR: a wave takes both 64-byte halves of a 128-byte line (steps 2w, 2w+1)
+  auto step_of = [&](int s0, int i) { return PAIR ? s0 + (i >> 1) * (2 * WAVES) + (i & 1) : s0 + WAVES * i; };
+  for (int s0 = PAIR ? 2 * wave : wave; s0 < nsteps; s0 += WAVES * CH) {
+    uint4 wf[CH][NB], xf[CH][RB];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int s = step_of(s0, i);
+      if (s < nsteps) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) wf[i][nb] = *reinterpret_cast<const uint4*>(wp[nb] + s * 32);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) xf[i][rb] = *reinterpret_cast<const uint4*>(xp[rb] + s * 32);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+      const int s = step_of(s0, i);
+      if (s < nsteps) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+          for (int rb = 0; rb < RB; ++rb) acc[nb][rb] = sk_mfma(wf[i][nb], xf[i][rb], acc[nb][rb]);
+      }
+    }
+  }
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) part[wave][nb * RB + rb][lane] = acc[nb][rb];
+  __syncthreads();
+  // wave q (and q + 8, ...) finishes block (nb, rb) = (q / RB, q % RB): v[r] = y[row m0 + rb*16 + c][col n0 + nb*16 + g*4 + r]
+#pragma unroll
+  for (int q0 = 0; q0 < NB * RB; q0 += WAVES) {
+    const int q = q0 + wave;
+    const int nb = q / RB, rb = q % RB;
+    const int row = m0 + rb * 16 + c;
+    if (q < NB * RB && row < M) {
+      sk_f32x4 v = part[0][q][lane];
+#pragma unroll
+      for (int ww = 1; ww < WAVES; ++ww) {
+        const sk_f32x4 t = part[ww][q][lane];
+        v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+      }
+      const int n = n0 + nb * 16 + g * 4;
+      if (bias) {
+        const float4 b = *reinterpret_cast<const float4*>(bias + n);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+      }
+      const uint2 o = make_uint2(f32x2_to_bf16x2(sk_act<ACT>(v[0]), sk_act<ACT>(v[1])),
+                                 f32x2_to_bf16x2(sk_act<ACT>(v[2]), sk_act<ACT>(v[3])));
+      *reinterpret_cast<uint2*>(y + (int64_t)row * N + n) = o;
+    }
+  }
+}
+
+template <int NB, int RB, bool PAIR>
+int launch_skinny(const void* x, const void* w, const float* bias, void* y, int M, int N, int K, int act,
+                  hipStream_t st) {
+  const int nstrips = N / (16 * NB), nmb = (M + 16 * RB - 1) / (16 * RB);
+  const dim3 grid((unsigned)(((nstrips + 7) / 8) * 8 * nmb));
+  constexpr size_t lds = (size_t)WAVES * NB * RB * 64 * sizeof(sk_f32x4);
+#define LVL_SK(A)                                                                                                 \
+  do {                                                                                                            \
+    if (lds > 64 * 1024)                                                                                          \
+      if (int rc = lvl_allow_lds<skinny_kernel<NB, RB, A, PAIR>>()) return rc;                                    \
+    hipLaunchKernelGGL((skinny_kernel<NB, RB, A, PAIR>), grid, dim3(64 * WAVES), lds, st, (const uint16_t*)x,     \
+                       (const uint16_t*)w, bias, (uint16_t*)y, M, N, K, nstrips, nmb);                            \
+  } while (0)
+  if (act == LVL_ACT_GELU_NEW) LVL_SK(LVL_ACT_GELU_NEW);
+  else if (act == LVL_ACT_SQRELU) LVL_SK(LVL_ACT_SQRELU);
+  else LVL_SK(ACT_NONE);
+#undef LVL_SK
+  LVL_CHECK_LAUNCH("linear_skinny");
+  return LVL_OK;
+}
+
+std::atomic<int> g_variant{0};      // lvl_debug_skinny_variant: 0 = the shipped choice
+
+}  // namespace
+
+extern "C" int lvl_linear_skinny(const void* x, const void* w, const float* bias, void* y, int M, int N, int K, int act,
+                                 void* stream) {
+  LVL_REQUIRE(M == 0 || (x && w && y), "linear_skinny: null pointer");
+  LVL_REQUIRE(M >= 0 && N > 0 && K > 0, "linear_skinny: bad shape M=%d N=%d K=%d", M, N, K);
+  LVL_REQUIRE(act == -1 || act == LVL_ACT_GELU_NEW || act == LVL_ACT_SQRELU, "linear_skinny: unknown activation %d", act);
+  if (N % 16 != 0 || K % 32 != 0 || (int64_t)(N / 16 + 8) * ((M + 15) / 16) >= (1ll << 31))
+    return lvl_fail(LVL_ENOSYS, "linear_skinny: needs N %% 16 == 0 and K %% 32 == 0 (N=%d K=%d)", N, K);
+  LVL_REQUIRE(lvl_aligned16(x) && lvl_aligned16(w) && lvl_aligned16(y) && lvl_aligned16(bias),
+              "linear_skinny: pointers must be 16-byte aligned");
+  if (M == 0) return LVL_OK;
+  // Output block per workgroup, from measurements on the decoder's shapes (tools/probe_skinny.py,
+  // profiles/r03_skinny_variants.json): up to 128 rows a 16 x 16 block with PAIRED k-steps (a wave reads whole 128-byte
+  // lines: 12.6 -> 7.6 us at K = 3072), or 32 rows x 64 columns once N >= 2048 gives >= 64 strips; beyond 128 rows
+  // (64 clips x 10 sampled captions = 640) 64 rows x 32 columns, which halves the re-reads of the weight strip
+  // (25.6 -> 19.3 us for [768 x 3072]).
+  const hipStream_t st = (hipStream_t)stream;
+  switch (g_variant.load(std::memory_order_relaxed)) {       // measurement variants (tools/probe_skinny.py)
+    case 1: if (N % 32 == 0) return launch_skinny<2, 2, true>(x, w, bias, y, M, N, K, act, st); break;
+    case 2: if (N % 32 == 0) return launch_skinny<2, 4, false>(x, w, bias, y, M, N, K, act, st); break;
+    case 3: if (N % 64 == 0) return launch_skinny<4, 4, false>(x, w, bias, y, M, N, K, act, st); break;
+    case 4: if (N % 32 == 0) return launch_skinny<2, 4, true>(x, w, bias, y, M, N, K, act, st); break;
+    case 5: if (N % 32 == 0) return launch_skinny<2, 1, true>(x, w, bias, y, M, N, K, act, st); break;
+    case 6: return launch_skinny<1, 1, true>(x, w, bias, y, M, N, K, act, st);
+    case 7: if (N % 64 == 0) return launch_skinny<4, 2, false>(x, w, bias, y, M, N, K, act, st); break;
+    case 8: if (N % 32 == 0) return launch_skinny<2, 2, false>(x, w, bias, y, M, N, K, act, st); break;
+    case 9: return launch_skinny<1, 1, false>(x, w, bias, y, M, N, K, act, st);
+    default: break;
+  }
+  if (M > 128)
+    return N % 32 == 0 ? launch_skinny<2, 4, false>(x, w, bias, y, M, N, K, act, st)
+                       : launch_skinny<1, 2, false>(x, w, bias, y, M, N, K, act, st);
+  if (N >= 2048 && N % 64 == 0) return launch_skinny<4, 2, false>(x, w, bias, y, M, N, K, act, st);
+  return launch_skinny<1, 1, true>(x, w, bias, y, M, N, K, act, st);
+}
+
+extern "C" int lvl_debug_skinny_variant(int v) {
+  g_variant.store(v, std::memory_order_relaxed);
+  return LVL_OK;
+}

@@ -34,6 +34,10 @@ import torch.nn.functional as F
 from . import _cabi as C
 from . import ops
 
+# rows up to which a Conv1D goes to lvl_linear_skinny (one workgroup per 16/32 weight columns) instead of the
+# 256x256-tile kernel: a decode step of 64 captions measured 32 us per GEMM on the latter (one CU per 256-column panel)
+SKINNY_MAX_ROWS = 1024
+
 _SIZES = {  # hidden, layers, heads of the published GPT-2 checkpoints (models.py:729,770,914: "gpt2", "gpt2-large", "gpt2-xl")
     'gpt2': (768, 12, 12), 'gpt2-medium': (1024, 24, 16), 'gpt2-large': (1280, 36, 20), 'gpt2-xl': (1600, 48, 25),
 }
@@ -232,20 +236,44 @@ class _Pack:
             self.head = self.wte if tied else f32(head)
 
     # ---- primitives --------------------------------------------------------------------------------
-    def gemm(self, x2, entry):
+    def _skinny(self, x2, w, b, act):
+        M, K = x2.shape
+        y = torch.empty(M, w.shape[0], dtype=torch.bfloat16, device=x2.device)
+        C.require_device(x2, w, b)
+        C.check(C.lib().lvl_linear_skinny(C.ptr(x2), C.ptr(w), C.ptr(b), C.ptr(y), M, w.shape[0], K,
+                                          -1 if act is None else act, C.stream_ptr()), 'lvl_linear_skinny')
+        return y
+
+    def gemm(self, x2, entry, act=None):
+        """Conv1D (+ activation). bf16: few rows (decoding) -> lvl_linear_skinny with the activation in its epilogue;
+        many rows (teacher-forced captions, the image keys / values) -> lvl_linear_tn, activation in place afterwards;
+        widths neither kernel tiles -> library GEMM (logged). f32: library GEMM against the [in, out] master."""
         w, b, n_out, n_in = entry
+        rows = x2.shape[0]
         if self.dtype == torch.bfloat16:
-            if ops._tn_ok(x2.shape[0], n_out, n_in):
-                return ops.linear_tn_raw(x2, w, b, C.EPI_BIAS)
-            ops.warn_once(('conv1d', n_out, n_in), f'decoder Conv1D [{n_in}->{n_out}] runs on the library GEMM '
-                                                   '(lvl_linear_tn needs out % 256 == 0 and in % 64 == 0)')
-            return F.linear(x2, w, b.to(torch.bfloat16))
-        return torch.addmm(b, x2, w)
+            if rows <= SKINNY_MAX_ROWS and n_out % 16 == 0 and n_in % 32 == 0:
+                return self._skinny(x2, w, b, act)
+            if ops._tn_ok(rows, n_out, n_in):
+                y = ops.linear_tn_raw(x2, w, b, C.EPI_BIAS)
+            else:
+                ops.warn_once(('conv1d', n_out, n_in), f'decoder Conv1D [{n_in}->{n_out}] on {rows} rows runs on the '
+                              'library GEMM (lvl_linear_tn needs out % 256 == 0 and in % 64 == 0)')
+                y = F.linear(x2, w, b.to(torch.bfloat16))
+        else:
+            y = torch.addmm(b, x2, w)
+        return y if act is None else self.act(y, act)
 
     def logits(self, h2):
         """lm_head (no bias, gpt2_gated.py:1010,1139): [rows, D] -> [rows, vocab] (a view of the padded product)."""
-        if self.dtype == torch.bfloat16 and ops._tn_ok(h2.shape[0], self.head.shape[0], self.D):
-            return ops.linear_tn_raw(h2, self.head, None, C.EPI_BIAS)[:, :self.vocab]
+        if self.dtype == torch.bfloat16:
+            # 50432 x 768: enough 256-column panels (197) for the persistent kernel at any row count -- 32 us at 64 rows,
+            # 74 us at 640, where the strip kernel needs 41 / 300 us (profiles/r03_skinny_variants.json)
+            if ops._tn_ok(h2.shape[0], self.head.shape[0], self.D) and self.head.shape[0] >= 8192:
+                return ops.linear_tn_raw(h2, self.head, None, C.EPI_BIAS)[:, :self.vocab]
+            if h2.shape[0] <= SKINNY_MAX_ROWS and self.D % 32 == 0:
+                return self._skinny(h2, self.head, None, None)[:, :self.vocab]
+            if ops._tn_ok(h2.shape[0], self.head.shape[0], self.D):
+                return ops.linear_tn_raw(h2, self.head, None, C.EPI_BIAS)[:, :self.vocab]
         return F.linear(h2, self.head)[:, :self.vocab]
 
     def embed(self, ids, L, pos_dev=None):
@@ -297,11 +325,11 @@ class _Pack:
             if e['cross'] and with_image:
                 a = self.cross_attn(self.gemm(h, e['xq']), xkv[i], qrep)
                 h = self.add_ln(x, self.gemm(a, e['xproj']), e['gate_c'], e['ln_2x'])
-                u = self.act(self.gemm(h, e['xfc']), C.ACT_SQRELU)
+                u = self.gemm(h, e['xfc'], C.ACT_SQRELU)
                 h = self.add_ln(x, self.gemm(u, e['xfproj']), e['gate_d'], e['ln_1'])
             a = self_attention(i, self.gemm(h, e['c_attn']))
             h = self.add_ln(x, self.gemm(a, e['c_proj']), None, e['ln_2'])
-            u = self.act(self.gemm(h, e['fc']), C.ACT_GELU_NEW)
+            u = self.gemm(h, e['fc'], C.ACT_GELU_NEW)
             h = self.add_ln(x, self.gemm(u, e['proj']), None, self.first_ln(i + 1, with_image))
         return h
 

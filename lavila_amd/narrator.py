@@ -16,6 +16,8 @@ num_return_sequences) but decodes against a key/value cache, one hipGraph replay
 `beam_sample` / `group_beam_search` (narrator.py:149-366, built on transformers' BeamSearchScorer) are not built.
 This module is deliberately not aliased under `lavila.models.narrator`, which keeps resolving to the reference's file.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -97,6 +99,37 @@ class CrossAttention(nn.Module):
         return _like_caller(ops.linear(out, self.to_out.weight), context)
 
 
+def sample_next_token(logits, top_k, top_p, temperature, target=None, pad_id=-100, uniform=None, debug=False):
+    """One lvl_sample_next_token call on a step's logits [rows, vocab] (bf16, unit column stride, rows padded to a
+    multiple of 8 columns -- what DecodeSession.step returns): -> (next_token [rows, 1] int64, nll [rows] f32,
+    counted [rows] f32), or None when the tensor is not in that form (f32 logits of the parity configuration, the
+    recompute schedule's strided slices): the caller then runs the framework ops. `uniform` [rows] in [0, 1) defaults to
+    torch.rand on the device (torch's generator: torch.manual_seed reproduces a run)."""
+    if logits.dtype != torch.bfloat16 or not logits.is_cuda or logits.dim() != 2 or logits.stride(1) != 1:
+        return None
+    rows, vocab = logits.shape
+    stride = logits.stride(0)
+    if stride % 8 != 0 or stride < ((vocab + 7) & ~7) or logits.data_ptr() % 16 != 0 or \
+            vocab > C.lib().lvl_sample_max_vocab():
+        return None
+    dev = logits.device
+    if uniform is None:
+        uniform = torch.rand(rows, device=dev)
+    tgt = None if target is None else target.contiguous()
+    nxt = torch.empty(rows, dtype=torch.int64, device=dev)
+    nll = torch.empty(rows, dtype=torch.float32, device=dev)
+    cnt = torch.empty(rows, dtype=torch.float32, device=dev)
+    dbg = torch.zeros(rows, 12, dtype=torch.float32, device=dev) if debug else None
+    k = 0 if not top_k else min(int(top_k), vocab)
+    p = 1.0 if top_p is None else float(top_p)
+    t = 1.0 if temperature is None else float(temperature)
+    C.check(C.lib().lvl_sample_next_token(C.ptr(logits), stride, rows, vocab, t, k, p, C.ptr(uniform), C.ptr(tgt),
+                                          int(pad_id) if pad_id is not None else -100, C.ptr(nxt), C.ptr(nll), C.ptr(cnt),
+                                          C.ptr(dbg), C.stream_ptr()), 'lvl_sample_next_token')
+    out = (nxt[:, None], nll, cnt)
+    return out + (dbg,) if debug else out
+
+
 class VCLM_HF(nn.Module):
     """narrator.py:31-147: same constructor; encode_image, forward and generate run on the HIP path (`text_decoder`:
     a lavila_amd.gpt2_gated.GPT2LMHeadModel); the beam-search variants are not built."""
@@ -169,7 +202,9 @@ class VCLM_HF(nn.Module):
         has not emitted eos; warp -> softmax -> multinomial). kv_cache=True (default): one new row per caption against
         cached keys / values, the image keys / values projected once per CLIP (shared by its num_return_sequences
         samples), one hipGraph replay per token when graph=True. kv_cache=False: the reference's schedule (the whole
-        prefix through the decoder every step)."""
+        prefix through the decoder every step). bf16 logits go through ONE sampling kernel (lvl_sample_next_token:
+        perplexity term, warpers and the draw; LAVILA_NARRATOR_SAMPLER=torch keeps the framework ops, which f32 logits
+        always use): the same distribution as warp -> softmax -> multinomial, another mapping of random numbers to tokens."""
         n = int(num_return_sequences)
         B = image_tokens.shape[0] * n
         device = image_tokens.device
@@ -187,19 +222,32 @@ class VCLM_HF(nn.Module):
                 session = self.text_decoder.decode_session(image_tokens, max_text_length, seqs_per_context=n, graph=graph)
             else:
                 repeated = image_tokens.repeat_interleave(n, dim=0)
+            fused = os.environ.get('LAVILA_NARRATOR_SAMPLER', 'fused') != 'torch'
             for i in range(max_text_length - 1):
                 if kv_cache:
-                    logits = session.step(condition[:, -1]).float()
+                    logits = session.step(condition[:, -1])
                 else:
-                    logits = self.text_decoder(condition.contiguous(), encoder_hidden_states=repeated).logits[:, -1, :].float()
-                if target is not None:
-                    nlls += F.cross_entropy(logits, target[:, i + 1], ignore_index=pad, reduction='none')
-                    num_tokens += target[:, i + 1].ne(pad)
+                    logits = self.text_decoder(condition.contiguous(), encoder_hidden_states=repeated).logits[:, -1, :]
+                tgt = None if target is None else target[:, i + 1]
+                drawn = sample_next_token(logits, top_k, top_p, temperature, tgt, pad) if fused else None
+                if drawn is not None:                     # one kernel: perplexity term + warpers + draw
+                    next_token, nll, counted = drawn
+                    if target is not None:
+                        nlls += nll
+                        num_tokens += counted
+                    else:
+                        nlls += nll * (~reached)
+                        num_tokens += (~reached)
                 else:
-                    nlls += torch.special.entr(F.softmax(logits, dim=1)).sum(dim=1) * (~reached)
-                    num_tokens += (~reached)
-                probs = F.softmax(self._warp(logits, top_k, top_p, temperature), dim=-1)
-                next_token = torch.multinomial(probs, num_samples=1)
+                    logits = logits.float()
+                    if target is not None:
+                        nlls += F.cross_entropy(logits, tgt, ignore_index=pad, reduction='none')
+                        num_tokens += tgt.ne(pad)
+                    else:
+                        nlls += torch.special.entr(F.softmax(logits, dim=1)).sum(dim=1) * (~reached)
+                        num_tokens += (~reached)
+                    probs = F.softmax(self._warp(logits, top_k, top_p, temperature), dim=-1)
+                    next_token = torch.multinomial(probs, num_samples=1)
                 reached = reached | (next_token[:, 0] == eos)
                 if early_stopping and bool(torch.all(reached)):
                     break

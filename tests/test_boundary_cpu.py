@@ -374,7 +374,7 @@ def test_gemm_tile_counter_reply_register_is_untouched_in_isa(tmp_path):
 def test_narrator_seam_state_dict_matches_reference_names():
     """lavila_amd.narrator.VCLM_HF owns `visual.*`, `img_queries`, `img_attn_pool.*`, `img_attn_pool_norm.*` under the
     reference's names (narrator.py:44-49, coca.py:27-31,76-82), beta buffers included, so those entries of a VCLM_*
-    checkpoint load unchanged; decoding stays out of scope and says so."""
+    checkpoint load unchanged; without a decoder module forward says so, and the beam-search variants are not built."""
     import contextlib
     import io
     from lavila.models.openai_model import QuickGELU
@@ -395,7 +395,7 @@ def test_narrator_seam_state_dict_matches_reference_names():
     assert [k for k, _ in m.named_buffers()] == ['img_attn_pool.norm.beta', 'img_attn_pool.context_norm.beta',
                                                  'img_attn_pool_norm.beta']
     with pytest.raises(NotImplementedError):
-        m.generate(None, None)
+        m.beam_sample(None, None)
     with pytest.raises(NotImplementedError):
         m(torch.zeros(1, 3, 2, 32, 32), torch.zeros(1, 8, dtype=torch.long))
     with pytest.raises(NotImplementedError):

@@ -1,0 +1,13 @@
+#!/bin/bash
+set -u
+O=gpurun_out/r3n
+mkdir -p $O
+export TMPDIR=/tmp
+(timeout 900 python tools/probe_narrator.py --batch 64 --length 77 --returns 10 --sample --half --reps 2 --out $O/narrator_b64_r10.json 2>&1 | tail -5) > $O/probe.log
+cd /tmp
+(timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/prof -o nar -- python $GRAFT_REPO_ROOT/tools/probe_narrator.py --batch 64 --length 20 --returns 10 --sample --half --reps 1 --skip-recompute 2>&1 | head -40) > $GRAFT_REPO_ROOT/$O/prof.log
+cd $GRAFT_REPO_ROOT
+DB=$(find $O/prof -name "*.db" | head -1)
+[ -n "$DB" ] && python tools/kernel_stats.py $DB 1 > $O/kernel_stats.csv 2>$O/kernel_stats.err
+rm -rf $O/prof
+echo done > $O/finished

@@ -58,9 +58,9 @@ def main():
     clips = torch.randn(a.batch, 3, 4, 224, 224, device='cuda', dtype=torch.float16 if a.half else torch.float32)
     amp = contextlib.nullcontext() if a.half else torch.autocast('cuda', dtype=torch.bfloat16)
     kw = dict(max_text_length=a.length, num_return_sequences=a.returns)
-    kw.update(dict(top_k=None, top_p=0.95) if a.sample else dict(top_k=1))
+    kw.update(dict(top_k=None, top_p=0.95, temperature=0.7) if a.sample else dict(top_k=1))   # main_infer_narrator.py:55-59
     res = {'batch': a.batch, 'length': a.length, 'returns': a.returns, 'dtype': 'fp16 in / bf16 compute' if a.half else 'f32 masters, bf16 autocast',
-           'sampling': 'nucleus 0.95' if a.sample else 'top_k=1', 'device': torch.cuda.get_device_name(0)}
+           'sampling': 'nucleus top_p=0.95, temperature 0.7' if a.sample else 'top_k=1', 'device': torch.cuda.get_device_name(0)}
     with torch.no_grad(), amp:
         t_enc, img = timed(lambda: m.encode_image(clips), a.reps)
         res['encode_image_ms'] = round(t_enc * 1e3, 2)
@@ -84,6 +84,21 @@ def main():
         if 'recompute' in res:
             res['speedup_graph_vs_recompute'] = round(res['recompute']['generate_ms'] / res['graph']['generate_ms'], 2)
         res['speedup_graph_vs_eager'] = round(res['eager']['generate_ms'] / res['graph']['generate_ms'], 2)
+    # where the sampling kernel spends its time (phase clocks of lvl_sample_next_token's debug output), on logits
+    # of the decoder's shape
+    from lavila_amd.narrator import sample_next_token
+    rows = a.batch * a.returns
+    lg = (3 * torch.randn(rows, 50432, device='cuda')).bfloat16()[:, :50257]
+    skw = dict(top_k=None, top_p=0.95, temperature=0.7) if a.sample else dict(top_k=1, top_p=None, temperature=1.0)
+    for _ in range(2):
+        out = sample_next_token(lg, debug=True, **skw)
+    torch.cuda.synchronize()
+    dbg = out[3].cpu()
+    ph = dbg[:, 4:9].mean(0).tolist()
+    res['sampler_phase_us'] = dict(zip(['load+max', 'stats', 'top_k', 'top_p', 'draw'], [round(v, 1) for v in ph]))
+    res['sampler_workgroup_us'] = round(float(dbg[:, 4:9].sum(1).mean()), 1)
+    start = dbg[:, 9]
+    res['sampler_start_spread_us'] = round(float(start.max() - start.min()), 1)
     text = json.dumps(res, indent=1)
     print(text)
     if a.out:

@@ -1,0 +1,65 @@
+"""Times lvl_linear_skinny's tilings (lvl_debug_skinny_variant) on the decoder's Conv1D shapes, next to lvl_linear_tn and
+the library GEMM: python tools/probe_skinny.py [--out file]. Variants (rows x columns per workgroup): 0 shipped; 1 32x32 paired k-steps; 2 64x32; 3 64x64; 4 64x32 paired; 5 16x32
+paired; 6 16x16 paired; 7 32x64; 8 32x32; 9 16x16."""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from lavila_amd import _cabi as C  # noqa: E402
+from lavila_amd import ops  # noqa: E402
+
+
+def timed(fn, n=40):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n * 1e3          # us
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--out')
+    a = ap.parse_args()
+    shapes = [(M, N, K) for M in (64, 640) for (N, K) in ((768, 768), (768, 3072), (3072, 768), (2304, 768), (50432, 768))]
+    res = {}
+    for M, N, K in shapes:
+        g = torch.Generator().manual_seed(0)
+        x = torch.randn(M, K, generator=g).bfloat16().cuda()
+        w = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16().cuda()
+        b = torch.randn(N, generator=g).cuda()
+        y = torch.empty(M, N, dtype=torch.bfloat16, device='cuda')
+        want = (x.float() @ w.float().t() + b)
+        row = {}
+        for v in range(10):
+            C.lib().lvl_debug_skinny_variant(v)
+
+            def run():
+                C.check(C.lib().lvl_linear_skinny(C.ptr(x), C.ptr(w), C.ptr(b), C.ptr(y), M, N, K, -1, C.stream_ptr()), 'skinny')
+            run()
+            err = (y.float() - want).abs().max().item()
+            row[f'skinny_v{v}'] = round(timed(run), 2)
+            assert err < 0.1, (M, N, K, v, err)
+        C.lib().lvl_debug_skinny_variant(0)
+        row['linear_tn'] = round(timed(lambda: ops.linear_tn_raw(x, w, b)), 2)
+        bb = b.bfloat16()
+        row['library'] = round(timed(lambda: torch.nn.functional.linear(x, w, bb)), 2)
+        row['weights_MB'] = round(N * K * 2 / 1e6, 2)
+        res[f'M{M}_N{N}_K{K}'] = row
+        print(f'M{M}_N{N}_K{K}', row, flush=True)
+    if a.out:
+        with open(a.out, 'w') as f:
+            json.dump(res, f, indent=1)
+
+
+if __name__ == '__main__':
+    main()
