@@ -40,6 +40,7 @@ def main():
     ap.add_argument('--half', action='store_true', help='model.half() + images.half() (main_infer_narrator.py --use-half)')
     ap.add_argument('--sample', action='store_true')
     ap.add_argument('--skip-recompute', action='store_true')
+    ap.add_argument('--modes', default='graph,eager,recompute', help='comma list of graph, eager, recompute')
     ap.add_argument('--out')
     a = ap.parse_args()
     from lavila.models import models
@@ -67,7 +68,7 @@ def main():
         outs = {}
         for name, g in (('graph', dict(kv_cache=True, graph=True)), ('eager', dict(kv_cache=True, graph=False)),
                         ('recompute', dict(kv_cache=False))):
-            if name == 'recompute' and a.skip_recompute:
+            if (name == 'recompute' and a.skip_recompute) or name not in a.modes.split(','):
                 continue
             torch.manual_seed(1)
             t, out = timed(lambda: m.generate(img, tok, **kw, **g), 1 if name == 'recompute' else a.reps)
@@ -76,14 +77,15 @@ def main():
             res[name] = {'generate_ms': round(t * 1e3, 1), 'ms_per_token_step': round(t * 1e3 / steps, 3),
                          'captions_per_s_decode_only': round(a.batch * a.returns / t, 1),
                          'captions_per_s_with_encoder': round(a.batch * a.returns / (t + t_enc), 1)}
-        if not a.sample:
+        if not a.sample and 'graph' in outs:
             ref = outs['graph'][0]
             for name, (ids, ppl) in outs.items():
                 same = (ids == ref).float().mean().item()
                 res[name]['token_agreement_with_graph'] = round(same, 4)
-        if 'recompute' in res:
+        if 'recompute' in res and 'graph' in res:
             res['speedup_graph_vs_recompute'] = round(res['recompute']['generate_ms'] / res['graph']['generate_ms'], 2)
-        res['speedup_graph_vs_eager'] = round(res['eager']['generate_ms'] / res['graph']['generate_ms'], 2)
+        if 'eager' in res and 'graph' in res:
+            res['speedup_graph_vs_eager'] = round(res['eager']['generate_ms'] / res['graph']['generate_ms'], 2)
     # where the sampling kernel spends its time (phase clocks of lvl_sample_next_token's debug output), on logits
     # of the decoder's shape
     from lavila_amd.narrator import sample_next_token
