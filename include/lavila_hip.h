@@ -228,6 +228,15 @@ int lvl_mq_cross_attn_fwd(const void* q, int64_t q_batch_stride, const void* kv,
  * panel to one compute unit, which at M <= 64 leaves the chip idle). N % 16 == 0 and K % 32 == 0, else LVL_ENOSYS; any
  * M >= 0 (every 16-row block re-reads its weight strip, from the L2 of the XCD the strip's blocks share). */
 int lvl_linear_skinny(const void* x, const void* w, const float* bias, void* y, int M, int N, int K, int act, void* stream);
+/* lvl_linear_skinny_ln: out[M,N] = act(LayerNorm(res + (*gate) * y) . w^T + bias), res_out = bf16(res + (*gate) * y) --
+ * lvl_gated_add_layernorm folded into the prologue of the Conv1D that consumes it (q_attn / c_attn / the two c_fc of a
+ * GPT2Block, gpt2_gated.py:441-487): a workgroup of lvl_linear_skinny owns whole rows of its input, so it forms the sum,
+ * the row statistics and the normalised operand in registers before its first MFMA. y NULL = no add (res_out unused);
+ * gate NULL = 1; res_out must NOT be res (other column strips are still reading it). gamma / beta [K] f32.
+ * N % 16 == 0, K % 32 == 0, K <= 1792, else LVL_ENOSYS; meant for M <= 128 (decoding). */
+int lvl_linear_skinny_ln(const void* res, const void* y, const float* gate, const float* gamma, const float* beta,
+                         float eps, void* res_out, const void* w, const float* bias, void* out, int M, int N, int K,
+                         int act, void* stream);
 /* Measurement hook (tools/probe_skinny.py): selects another workgroup tiling / k-step assignment of lvl_linear_skinny for
  * shapes that allow it (0 = the shipped choice). Results are the same up to f32 summation order. */
 int lvl_debug_skinny_variant(int variant);

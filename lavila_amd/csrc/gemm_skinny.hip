@@ -48,6 +48,43 @@ __device__ __forceinline__ float sk_act(float v) {
   return v;
 }
 
+// The 8 partial accumulators of every output block meet in LDS; wave q (and q + 8, ...) finishes block (nb, rb) =
+// (q / RB, q % RB): v[r] = y[row m0 + rb*16 + c][column n0 + nb*16 + g*4 + r] -> + bias, activation, bf16 store.
+template <int NB, int RB, int ACT>
+__device__ __forceinline__ void skinny_finish(sk_f32x4 (*part)[NB * RB][64], const sk_f32x4 (&acc)[NB][RB],
+                                              const float* __restrict__ bias, uint16_t* __restrict__ y, int M, int N,
+                                              int n0, int m0) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) part[wave][nb * RB + rb][lane] = acc[nb][rb];
+  __syncthreads();
+#pragma unroll
+  for (int q0 = 0; q0 < NB * RB; q0 += WAVES) {
+    const int q = q0 + wave;
+    const int nb = q / RB, rb = q % RB;
+    const int row = m0 + rb * 16 + c;
+    if (q < NB * RB && row < M) {
+      sk_f32x4 v = part[0][q][lane];
+#pragma unroll
+      for (int ww = 1; ww < WAVES; ++ww) {
+        const sk_f32x4 t = part[ww][q][lane];
+        v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+      }
+      const int n = n0 + nb * 16 + g * 4;
+      if (bias) {
+        const float4 b = *reinterpret_cast<const float4*>(bias + n);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+      }
+      const uint2 o = make_uint2(f32x2_to_bf16x2(sk_act<ACT>(v[0]), sk_act<ACT>(v[1])),
+                                 f32x2_to_bf16x2(sk_act<ACT>(v[2]), sk_act<ACT>(v[3])));
+      *reinterpret_cast<uint2*>(y + (int64_t)row * N + n) = o;
+    }
+  }
+}
+
 template <int NB, int RB, int ACT, bool PAIR>
 __global__ __launch_bounds__(512) void skinny_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w,
                                                      const float* __restrict__ bias, uint16_t* __restrict__ y, int M,
@@ -101,34 +138,178 @@ __global__ __launch_bounds__(512) void skinny_kernel(const uint16_t* __restrict_
       }
     }
   }
+  skinny_finish<NB, RB, ACT>(part, acc, bias, y, M, N, n0, m0);
+}
+
+// ---- the same GEMM with the residual add and the LayerNorm of its INPUT in the prologue ---------------------------------
+// x = LayerNorm(res + gate * y) * gamma + beta is what every LN-fed Conv1D of the decoder multiplies (q_attn, c_attn and
+// the two c_fc of a block: gpt2_gated.py:441-487); as a kernel of its own that add + LayerNorm is 49 launches of ~4 us in
+// a 1.2 ms decode step. A workgroup here owns whole rows (its waves split K, and K <= 1792 fits one round of fragments),
+// so it forms the sum, the row statistics (two-pass, f32; partials across lanes by shuffles, across waves through LDS)
+// and the normalised bf16 fragments in registers before its first MFMA. Every column strip repeats that for its rows
+// (x is L2-resident and tiny); strip 0 also writes the new residual to res_out -- a DIFFERENT buffer than res, which the
+// other strips are still reading.
+struct LnPrologue {
+  const uint16_t* y;        // [M, K] branch output to add, nullable
+  const float* gate;        // one f32 (tanh(alpha)), nullable = 1
+  const float* gamma;       // [K]
+  const float* beta;        // [K]
+  uint16_t* res_out;        // [M, K] = bf16(res + gate * y), nullable when y is null
+  float eps;
+};
+
+__device__ __forceinline__ void sk_unpack(uint4 v, float (&f)[8]) {
+  f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+  f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+  f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+  f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 sk_pack(const float (&f)[8]) {
+  return make_uint4(f32x2_to_bf16x2(f[0], f[1]), f32x2_to_bf16x2(f[2], f[3]), f32x2_to_bf16x2(f[4], f[5]),
+                    f32x2_to_bf16x2(f[6], f[7]));
+}
+
+template <int NB, int RB, int ACT, int SPW>      // SPW: k-steps per wave held in registers (K <= 256 * SPW)
+__global__ __launch_bounds__(512) void skinny_ln_kernel(const uint16_t* __restrict__ res, const uint16_t* __restrict__ w,
+                                                        const float* __restrict__ bias, uint16_t* __restrict__ out,
+                                                        int M, int N, int K, int nstrips, int nmb, LnPrologue ln) {
+  extern __shared__ __align__(16) unsigned char sk_smem[];
+  sk_f32x4 (*part)[NB * RB][64] = reinterpret_cast<sk_f32x4 (*)[NB * RB][64]>(sk_smem);
+  float (*red)[WAVES][RB][16] =                                           // [pass][wave][row block][row]
+      reinterpret_cast<float (*)[WAVES][RB][16]>(sk_smem + sizeof(sk_f32x4) * WAVES * NB * RB * 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int id = blockIdx.x;
+  const int strip = (id / (8 * nmb)) * 8 + (id & 7), mb = (id >> 3) % nmb;
+  if (strip >= nstrips) return;
+  const int n0 = strip * (16 * NB), m0 = mb * (16 * RB);
+  const int nsteps = K >> 5;
+  const float gt = ln.gate ? *ln.gate : 1.f;
+  uint4 wf[SPW][NB], xf[SPW][RB];
+  float psum[RB];
+  // ---- loads: weights, residual rows, branch rows (steps wave, wave + 8, ...) ---------------------------------------------
+  {
+    uint4 yf[SPW][RB];
+#pragma unroll
+    for (int i = 0; i < SPW; ++i) {
+      const int s = wave + WAVES * i;
+      if (s < nsteps) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+          wf[i][nb] = *reinterpret_cast<const uint4*>(w + (int64_t)(n0 + nb * 16 + c) * K + g * 8 + s * 32);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+          const int row = m0 + rb * 16 + c;
+          const int64_t off = (int64_t)(row < M ? row : M - 1) * K + g * 8 + s * 32;
+          xf[i][rb] = *reinterpret_cast<const uint4*>(res + off);
+          if (ln.y) yf[i][rb] = *reinterpret_cast<const uint4*>(ln.y + off);
+        }
+      }
+    }
+    // ---- sum = bf16(res + gate * y): what the residual stream stores and what the LayerNorm sees ---------------------------
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) psum[rb] = 0.f;
+#pragma unroll
+    for (int i = 0; i < SPW; ++i) {
+      const int s = wave + WAVES * i;
+      if (s < nsteps) {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+          float f[8];
+          sk_unpack(xf[i][rb], f);
+          if (ln.y) {
+            float t[8];
+            sk_unpack(yf[i][rb], t);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) f[k] = fmaf(gt, t[k], f[k]);
+            xf[i][rb] = sk_pack(f);
+            sk_unpack(xf[i][rb], f);                                       // the rounded values
+            const int row = m0 + rb * 16 + c;
+            if (strip == 0 && row < M)
+              *reinterpret_cast<uint4*>(ln.res_out + (int64_t)row * K + g * 8 + s * 32) = xf[i][rb];
+          }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) psum[rb] += f[k];
+        }
+      }
+    }
+  }
+  // ---- row statistics: lanes c, c+16, c+32, c+48 hold the same row; then the 8 waves ---------------------------------------
+  float mean[RB], rstd[RB];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    float v = psum[rb];
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    if (g == 0) red[0][wave][rb][c] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    float t = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < WAVES; ++ww) t += red[0][ww][rb][c];
+    mean[rb] = t / (float)K;
+  }
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) psum[rb] = 0.f;
+#pragma unroll
+  for (int i = 0; i < SPW; ++i) {
+    const int s = wave + WAVES * i;
+    if (s < nsteps) {
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        float f[8];
+        sk_unpack(xf[i][rb], f);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const float d = f[k] - mean[rb];
+          psum[rb] = fmaf(d, d, psum[rb]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    float v = psum[rb];
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    if (g == 0) red[1][wave][rb][c] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    float t = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < WAVES; ++ww) t += red[1][ww][rb][c];
+    rstd[rb] = rsqrtf(t / (float)K + ln.eps);
+  }
+  // ---- normalise the fragments, multiply ------------------------------------------------------------------------------
+  sk_f32x4 acc[NB][RB];
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-    for (int rb = 0; rb < RB; ++rb) part[wave][nb * RB + rb][lane] = acc[nb][rb];
-  __syncthreads();
-  // wave q (and q + 8, ...) finishes block (nb, rb) = (q / RB, q % RB): v[r] = y[row m0 + rb*16 + c][col n0 + nb*16 + g*4 + r]
+    for (int rb = 0; rb < RB; ++rb) acc[nb][rb] = sk_f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int q0 = 0; q0 < NB * RB; q0 += WAVES) {
-    const int q = q0 + wave;
-    const int nb = q / RB, rb = q % RB;
-    const int row = m0 + rb * 16 + c;
-    if (q < NB * RB && row < M) {
-      sk_f32x4 v = part[0][q][lane];
+  for (int i = 0; i < SPW; ++i) {
+    const int s = wave + WAVES * i;
+    if (s < nsteps) {
+      float ga[8], be[8];
+      load8_f32(ln.gamma + s * 32 + g * 8, ga);
+      load8_f32(ln.beta + s * 32 + g * 8, be);
 #pragma unroll
-      for (int ww = 1; ww < WAVES; ++ww) {
-        const sk_f32x4 t = part[ww][q][lane];
-        v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+      for (int rb = 0; rb < RB; ++rb) {
+        float f[8];
+        sk_unpack(xf[i][rb], f);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) f[k] = fmaf((f[k] - mean[rb]) * rstd[rb], ga[k], be[k]);
+        const uint4 h = sk_pack(f);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) acc[nb][rb] = sk_mfma(wf[i][nb], h, acc[nb][rb]);
       }
-      const int n = n0 + nb * 16 + g * 4;
-      if (bias) {
-        const float4 b = *reinterpret_cast<const float4*>(bias + n);
-        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-      }
-      const uint2 o = make_uint2(f32x2_to_bf16x2(sk_act<ACT>(v[0]), sk_act<ACT>(v[1])),
-                                 f32x2_to_bf16x2(sk_act<ACT>(v[2]), sk_act<ACT>(v[3])));
-      *reinterpret_cast<uint2*>(y + (int64_t)row * N + n) = o;
     }
   }
+  skinny_finish<NB, RB, ACT>(part, acc, bias, out, M, N, n0, m0);
 }
 
 template <int NB, int RB, bool PAIR>
@@ -149,6 +330,27 @@ int launch_skinny(const void* x, const void* w, const float* bias, void* y, int 
   else LVL_SK(ACT_NONE);
 #undef LVL_SK
   LVL_CHECK_LAUNCH("linear_skinny");
+  return LVL_OK;
+}
+
+template <int NB, int RB, int SPW>
+int launch_skinny_ln(const void* res, const void* w, const float* bias, void* out, int M, int N, int K, int act,
+                     const LnPrologue& ln, hipStream_t st) {
+  const int nstrips = N / (16 * NB), nmb = (M + 16 * RB - 1) / (16 * RB);
+  const dim3 grid((unsigned)(((nstrips + 7) / 8) * 8 * nmb));
+  constexpr size_t lds = (size_t)WAVES * NB * RB * 64 * sizeof(sk_f32x4) + 2 * WAVES * RB * 16 * sizeof(float);
+#define LVL_SKL(A)                                                                                                \
+  do {                                                                                                            \
+    if (lds > 64 * 1024)                                                                                          \
+      if (int rc = lvl_allow_lds<skinny_ln_kernel<NB, RB, A, SPW>>()) return rc;                                  \
+    hipLaunchKernelGGL((skinny_ln_kernel<NB, RB, A, SPW>), grid, dim3(64 * WAVES), lds, st, (const uint16_t*)res, \
+                       (const uint16_t*)w, bias, (uint16_t*)out, M, N, K, nstrips, nmb, ln);                      \
+  } while (0)
+  if (act == LVL_ACT_GELU_NEW) LVL_SKL(LVL_ACT_GELU_NEW);
+  else if (act == LVL_ACT_SQRELU) LVL_SKL(LVL_ACT_SQRELU);
+  else LVL_SKL(ACT_NONE);
+#undef LVL_SKL
+  LVL_CHECK_LAUNCH("linear_skinny_ln");
   return LVL_OK;
 }
 
@@ -194,4 +396,26 @@ extern "C" int lvl_linear_skinny(const void* x, const void* w, const float* bias
 extern "C" int lvl_debug_skinny_variant(int v) {
   g_variant.store(v, std::memory_order_relaxed);
   return LVL_OK;
+}
+
+extern "C" int lvl_linear_skinny_ln(const void* res, const void* y, const float* gate, const float* gamma,
+                                    const float* beta, float eps, void* res_out, const void* w, const float* bias,
+                                    void* out, int M, int N, int K, int act, void* stream) {
+  LVL_REQUIRE(M == 0 || (res && gamma && beta && w && out), "linear_skinny_ln: null pointer");
+  LVL_REQUIRE(!y || (res_out && res_out != res), "linear_skinny_ln: the new residual needs its own buffer (other strips still read res)");
+  LVL_REQUIRE(M >= 0 && N > 0 && K > 0, "linear_skinny_ln: bad shape M=%d N=%d K=%d", M, N, K);
+  LVL_REQUIRE(act == -1 || act == LVL_ACT_GELU_NEW || act == LVL_ACT_SQRELU, "linear_skinny_ln: unknown activation %d", act);
+  if (N % 16 != 0 || K % 32 != 0 || K > 256 * 7 || (int64_t)(N / 16 + 8) * ((M + 15) / 16) >= (1ll << 31))
+    return lvl_fail(LVL_ENOSYS, "linear_skinny_ln: needs N %% 16 == 0, K %% 32 == 0, K <= 1792 (N=%d K=%d)", N, K);
+  LVL_REQUIRE(lvl_aligned16(res) && lvl_aligned16(y) && lvl_aligned16(res_out) && lvl_aligned16(w) && lvl_aligned16(out) &&
+                  lvl_aligned16(bias) && lvl_aligned16(gamma) && lvl_aligned16(beta),
+              "linear_skinny_ln: pointers must be 16-byte aligned");
+  if (M == 0) return LVL_OK;
+  const LnPrologue ln{(const uint16_t*)y, gate, gamma, beta, (uint16_t*)res_out, eps};
+  const hipStream_t st = (hipStream_t)stream;
+  const bool wide = N >= 2048 && N % 64 == 0;                 // same cut as lvl_linear_skinny up to 128 rows
+  if (K <= 256 * 3)
+    return wide ? launch_skinny_ln<4, 2, 3>(res, w, bias, out, M, N, K, act, ln, st)
+                : launch_skinny_ln<1, 1, 3>(res, w, bias, out, M, N, K, act, ln, st);
+  return launch_skinny_ln<1, 1, 7>(res, w, bias, out, M, N, K, act, ln, st);   // GPT-2 XL (K = 1600): 7 steps per wave
 }

@@ -11,7 +11,8 @@ strict=True. The modules only HOLD parameters; the computation is laid out for t
     parameter state; the vocabulary is padded to the GEMM's 256-column tiles), f32 models (the parity configuration) on
     the library GEMM against the masters;
   * every residual add (with its tanh(alpha) gate) is fused with the LayerNorm that reads the sum next
-    (lvl_gated_add_layernorm), the embedding is one gather (lvl_gpt2_embed);
+    (lvl_gated_add_layernorm) and, while decoding, both are folded into the prologue of the Conv1D that consumes the
+    normalised rows (lvl_linear_skinny_ln); the embedding is one gather (lvl_gpt2_embed);
   * teacher-forced forward (`GPT2LMHeadModel.forward`, what VCLM_HF.forward and target scoring call): the causal
     self-attention is lvl_causal_attn_fwd, the cross-attention lvl_cross_attn_rows_fwd over keys / values projected from
     the image tokens ONCE per clip;
@@ -37,6 +38,8 @@ from . import ops
 # rows up to which a Conv1D goes to lvl_linear_skinny (one workgroup per 16/32 weight columns) instead of the
 # 256x256-tile kernel: a decode step of 64 captions measured 32 us per GEMM on the latter (one CU per 256-column panel)
 SKINNY_MAX_ROWS = 1024
+# rows up to which the residual add + LayerNorm in front of a Conv1D is folded into that GEMM (lvl_linear_skinny_ln)
+FUSED_LN_MAX_ROWS = 128
 
 _SIZES = {  # hidden, layers, heads of the published GPT-2 checkpoints (models.py:729,770,914: "gpt2", "gpt2-large", "gpt2-xl")
     'gpt2': (768, 12, 12), 'gpt2-medium': (1024, 24, 16), 'gpt2-large': (1280, 36, 20), 'gpt2-xl': (1600, 48, 25),
@@ -316,22 +319,49 @@ class _Pack:
         e = self.blocks[i]
         return e['ln_x'] if (e['cross'] and with_image) else e['ln_1']
 
-    def run(self, x, xkv, qrep, self_attention):
-        """The block stack on rows x [rows, D] (modified in place) -> LayerNorm_f(x). xkv: per block image keys / values
-        or None (no encoder states: plain GPT-2, gpt2_gated.py:432); `self_attention(i, qkv)` -> [rows, D]."""
+    def gemm_ln(self, x, pend, entry, act=None, fuse=True):
+        """Conv1D of LayerNorm(x + gate * y) for the pending (y, gate, ln): -> (product, new residual). Few rows in bf16
+        and `fuse`: ONE kernel (lvl_linear_skinny_ln: add, statistics and normalisation in the GEMM's prologue; the new
+        residual goes to a fresh buffer because the other column strips still read the old one). Otherwise the fused
+        add + LayerNorm kernel (residual updated in place) followed by the GEMM. Measured at 64 captions
+        (profiles/r03_narrator_decode_n1.json): launched one by one the folded form is 15 % faster per token step (48
+        launches fewer); inside a replayed hipGraph it is 2.5 % SLOWER (the prologue's two barriers sit on the critical
+        path of every column strip, where the stand-alone kernel costs 2.5 us once) -- so graph replay keeps them apart."""
+        y, gate, ln = pend
+        w, b, n_out, n_in = entry
+        rows = x.shape[0]
+        if (fuse and self.dtype == torch.bfloat16 and rows <= FUSED_LN_MAX_ROWS and n_out % 16 == 0 and n_in % 32 == 0
+                and n_in <= 1792):
+            out = torch.empty(rows, n_out, dtype=torch.bfloat16, device=x.device)
+            new_x = torch.empty_like(x) if y is not None else x
+            C.require_device(x, y, w, b)
+            C.check(C.lib().lvl_linear_skinny_ln(C.ptr(x), C.ptr(y), C.ptr(gate), C.ptr(ln[0]), C.ptr(ln[1]), self.eps,
+                                                 C.ptr(new_x) if y is not None else None, C.ptr(w), C.ptr(b), C.ptr(out),
+                                                 rows, n_out, n_in, -1 if act is None else act, C.stream_ptr()),
+                    'lvl_linear_skinny_ln')
+            return out, new_x
+        h = self.add_ln(x, y, gate, ln)
+        return self.gemm(h, entry, act), x
+
+    def run(self, x, xkv, qrep, self_attention, fuse_ln=True):
+        """The block stack on rows x [rows, D] -> LayerNorm_f of the final residual. xkv: per block image keys / values
+        or None (no encoder states: plain GPT-2, gpt2_gated.py:432); `self_attention(i, qkv)` -> [rows, D]. Every
+        residual add + LayerNorm is PENDING until the Conv1D that reads it (gemm_ln)."""
         with_image = xkv is not None
-        h = self.add_ln(x, None, None, self.first_ln(0, with_image))
+        pend = (None, None, self.first_ln(0, with_image))
         for i, e in enumerate(self.blocks):
             if e['cross'] and with_image:
-                a = self.cross_attn(self.gemm(h, e['xq']), xkv[i], qrep)
-                h = self.add_ln(x, self.gemm(a, e['xproj']), e['gate_c'], e['ln_2x'])
-                u = self.gemm(h, e['xfc'], C.ACT_SQRELU)
-                h = self.add_ln(x, self.gemm(u, e['xfproj']), e['gate_d'], e['ln_1'])
-            a = self_attention(i, self.gemm(h, e['c_attn']))
-            h = self.add_ln(x, self.gemm(a, e['c_proj']), None, e['ln_2'])
-            u = self.gemm(h, e['fc'], C.ACT_GELU_NEW)
-            h = self.add_ln(x, self.gemm(u, e['proj']), None, self.first_ln(i + 1, with_image))
-        return h
+                q, x = self.gemm_ln(x, pend, e['xq'], None, fuse_ln)
+                a = self.cross_attn(q, xkv[i], qrep)
+                pend = (self.gemm(a, e['xproj']), e['gate_c'], e['ln_2x'])
+                u, x = self.gemm_ln(x, pend, e['xfc'], C.ACT_SQRELU, fuse_ln)
+                pend = (self.gemm(u, e['xfproj']), e['gate_d'], e['ln_1'])
+            qkv, x = self.gemm_ln(x, pend, e['c_attn'], None, fuse_ln)
+            a = self_attention(i, qkv)
+            pend = (self.gemm(a, e['c_proj']), None, e['ln_2'])
+            u, x = self.gemm_ln(x, pend, e['fc'], C.ACT_GELU_NEW, fuse_ln)
+            pend = (self.gemm(u, e['proj']), None, self.first_ln(i + 1, with_image))
+        return self.add_ln(x, *pend)                     # ln_f feeds lm_head (the 256-column-panel kernel): materialised
 
 
 class DecodeSession:
@@ -355,6 +385,7 @@ class DecodeSession:
         self.steps = 0
         self._logits = None
         self._graph = None
+        self.graphed = bool(graph)
         if graph:
             self._capture()
 
@@ -371,7 +402,7 @@ class DecodeSession:
     def _run(self):
         p = self.pack
         x = p.embed(self.ids, 1, self.pos)
-        h = p.run(x, self.xkv, self.qrep, self._self_attention)
+        h = p.run(x, self.xkv, self.qrep, self._self_attention, fuse_ln=not self.graphed)
         logits = p.logits(h)
         self.pos.add_(1)
         return logits

@@ -153,6 +153,51 @@ def test_skinny_gemm(M, N, K, act):
 
 
 
+
+@pytest.mark.parametrize('M,N,K', [(64, 768, 768), (64, 3072, 768), (7, 2304, 768), (128, 192, 192), (33, 1600, 1600),
+                                   (64, 4800, 1600), (1, 48, 32), (100, 256, 1024)])
+def test_skinny_gemm_with_layernorm_prologue(M, N, K):
+    """lvl_linear_skinny_ln == lvl_gated_add_layernorm followed by lvl_linear_skinny: the new residual to the bit (same
+    fma, same rounding), the product within one bf16 rounding of the normalised operand (the row statistics are summed
+    in another order); and against the f32 formula."""
+    from lavila_amd import _cabi as C
+    g = torch.Generator().manual_seed(M + N + K)
+    res = torch.randn(M, K, generator=g).bfloat16().to(DEV)
+    y = (2 * torch.randn(M, K, generator=g)).bfloat16().to(DEV)
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).bfloat16().to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    gamma = (1 + 0.1 * torch.randn(K, generator=g)).to(DEV)
+    beta = (0.1 * torch.randn(K, generator=g)).to(DEV)
+    gate = torch.tensor([0.37], device=DEV)
+    for use_y, use_gate, act in ((True, True, -1), (True, False, C.ACT_GELU_NEW), (False, False, C.ACT_SQRELU)):
+        out = torch.full((M + 1, N), float('nan'), dtype=torch.bfloat16, device=DEV)
+        new_res = torch.full((M + 1, K), float('nan'), dtype=torch.bfloat16, device=DEV)
+        C.check(C.lib().lvl_linear_skinny_ln(C.ptr(res), C.ptr(y) if use_y else None, C.ptr(gate) if use_gate else None,
+                                             C.ptr(gamma), C.ptr(beta), 1e-5, C.ptr(new_res) if use_y else None, C.ptr(w),
+                                             C.ptr(b), C.ptr(out), M, N, K, act, C.stream_ptr()), 'lvl_linear_skinny_ln')
+        s_ref, h_ref = res.clone(), torch.empty_like(res)
+        C.check(C.lib().lvl_gated_add_layernorm(C.ptr(s_ref), C.ptr(y) if use_y else None, C.ptr(gate) if use_gate else None,
+                                                C.ptr(gamma), C.ptr(beta), 1e-5, C.ptr(s_ref) if use_y else None,
+                                                C.ptr(h_ref), M, K, C.LVL_BF16, C.stream_ptr()), 'gated_add_layernorm')
+        o_ref = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        C.check(C.lib().lvl_linear_skinny(C.ptr(h_ref), C.ptr(w), C.ptr(b), C.ptr(o_ref), M, N, K, act, C.stream_ptr()), 'skinny')
+        if use_y:
+            assert torch.equal(new_res[:M], s_ref)
+            assert torch.isnan(new_res[M].float()).all()
+        torch.testing.assert_close(out[:M].float(), o_ref.float(), atol=3e-2, rtol=3e-2)
+        assert (out[:M].float() - o_ref.float()).abs().mean().item() < 2e-3
+        assert torch.isnan(out[M].float()).all()
+        hf = O.layer_norm(s_ref.float().cpu(), gamma.cpu(), beta.cpu(), 1e-5)
+        want = hf @ w.float().cpu().t() + b.cpu()
+        want = {-1: lambda t: t, C.ACT_GELU_NEW: O.gelu_new, C.ACT_SQRELU: O.sq_relu}[act](want)
+        torch.testing.assert_close(out[:M].float().cpu(), want, atol=4e-2, rtol=4e-2)
+    other = torch.empty_like(res)
+    assert C.lib().lvl_linear_skinny_ln(C.ptr(res), C.ptr(y), None, C.ptr(gamma), C.ptr(beta), 1e-5, C.ptr(res), C.ptr(w),
+                                        C.ptr(b), C.ptr(out), M, N, K, -1, C.stream_ptr()) == -22       # in place: refused
+    assert C.lib().lvl_linear_skinny_ln(C.ptr(res), C.ptr(y), None, C.ptr(gamma), C.ptr(beta), 1e-5, C.ptr(other), C.ptr(w),
+                                        C.ptr(b), C.ptr(out), M, N, 2048, -1, C.stream_ptr()) == -38     # K too long
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # the sampling kernel
 # ----------------------------------------------------------------------------------------------------------------------
@@ -383,8 +428,8 @@ def _mid_model(dtype_mode, width=256, heads=4, layers=2, vocab=331, freq=1):
 @pytest.mark.parametrize('mode', ['bf16', 'half', 'autocast'])
 def test_decoder_low_precision_on_own_gemms(mode, monkeypatch):
     """bf16 parameters, the --use-half recipe (fp16 parameters, docs/PRETRAIN.md:85-91) and f32 masters under autocast:
-    every Conv1D of the decoder runs on lvl_linear_skinny (few rows) or lvl_linear_tn (many rows; forced here by setting
-    the row threshold to 0) -- never the library GEMM; teacher-forced logits and cached decoding agree with the f32 oracle
+    every Conv1D of the decoder runs on lvl_linear_skinny / lvl_linear_skinny_ln (few rows) or lvl_linear_tn (many rows;
+    forced here by setting the row thresholds to 0) -- never the library GEMM; teacher-forced logits and cached decoding agree with the f32 oracle
     within the bf16 bound on both kernels, cached == recomputed."""
     from lavila_amd import gpt2_gated as G
     from lavila_amd import ops
@@ -395,10 +440,13 @@ def test_decoder_low_precision_on_own_gemms(mode, monkeypatch):
     ids = torch.randint(1, d['vocab'], (B, L), generator=g)
     enc = torch.randn(B, NQ, c['text_width'], generator=g)
     want, _ = O.gpt2_lm_logits(ids, enc, w, H, prefix='text_decoder.')
-    calls = {'tn': 0, 'skinny': 0}
-    real_tn, real_sk = ops.linear_tn_raw, G._Pack._skinny
+    from lavila_amd import _cabi as C
+    calls = {'tn': 0, 'skinny': 0, 'fused': 0}
+    real_tn, real_sk, real_fused = ops.linear_tn_raw, G._Pack._skinny, C.lib().lvl_linear_skinny_ln
     monkeypatch.setattr(ops, 'linear_tn_raw', lambda *a, **k: (calls.__setitem__('tn', calls['tn'] + 1), real_tn(*a, **k))[1])
     monkeypatch.setattr(G._Pack, '_skinny', lambda *a, **k: (calls.__setitem__('skinny', calls['skinny'] + 1), real_sk(*a, **k))[1])
+    monkeypatch.setattr(C.lib(), 'lvl_linear_skinny_ln',
+                        lambda *a: (calls.__setitem__('fused', calls['fused'] + 1), real_fused(*a))[1])
     monkeypatch.setattr(F, 'linear', lambda *a, **k: (_ for _ in ()).throw(AssertionError('library GEMM in the decoder')))
     dec = m.text_decoder
     ctx = contextlib.nullcontext()
@@ -415,12 +463,16 @@ def test_decoder_low_precision_on_own_gemms(mode, monkeypatch):
     scale = want.abs().max().item()
     with torch.no_grad(), ctx:
         full = {}
-        for kernel, rows in (('skinny', G.SKINNY_MAX_ROWS), ('tn', 0)):
+        for kernel, rows, fused_rows in (('skinny', G.SKINNY_MAX_ROWS, G.FUSED_LN_MAX_ROWS), ('tn', 0, 0)):
             monkeypatch.setattr(G, 'SKINNY_MAX_ROWS', rows)
-            calls.update(tn=0, skinny=0)
+            monkeypatch.setattr(G, 'FUSED_LN_MAX_ROWS', fused_rows)
+            calls.update(tn=0, skinny=0, fused=0)
             got = dec(ids.to(DEV), encoder_hidden_states=enc_dev).logits
             assert got.dtype == {'bf16': torch.bfloat16, 'half': torch.float16, 'autocast': torch.bfloat16}[mode]
-            assert calls == {kernel: n_gemms, ('tn' if kernel == 'skinny' else 'skinny'): 0}, calls
+            if kernel == 'skinny':       # per block 4 LN-fed Conv1Ds fused with their LayerNorm, 4 plain + the image k|v
+                assert calls == {'skinny': d['layers'] * 5 + 1, 'fused': d['layers'] * 4, 'tn': 0}, calls
+            else:
+                assert calls == {'tn': n_gemms, 'skinny': 0, 'fused': 0}, calls
             assert (got.float().cpu() - want).abs().max().item() < 0.04 * scale
             full[kernel] = got
             for graph in (False, True):
@@ -435,19 +487,27 @@ def test_decoder_low_precision_on_own_gemms(mode, monkeypatch):
             dec._sessions.clear()                            # the other kernel needs its own captured graph
 
 
-def test_decode_session_graph_equals_eager_bitwise_and_tracks_weights():
-    """The captured step replays the eager step's kernels: identical bits; a parameter write makes the session stale and
-    the next forward rebuilds the packed weights."""
+def test_decode_session_graph_equals_eager_bitwise_and_tracks_weights(monkeypatch):
+    """The captured step replays the eager step's kernels: identical bits (with the LayerNorm folding that only the
+    eagerly launched step uses switched off; with it the logits agree within bf16 rounding); a parameter write makes the
+    session stale and the next forward rebuilds the packed weights."""
+    from lavila_amd import gpt2_gated as G
     m, c, d, w = _mid_model('bf16')
     dec = m.text_decoder.bfloat16()
     g = torch.Generator().manual_seed(10)
     ids = torch.randint(1, d['vocab'], (4, 7), generator=g).to(DEV)
     enc = torch.randn(2, c['queries'], c['text_width'], generator=g).to(DEV).bfloat16()
     with torch.no_grad():
+        folded = dec.decode_session(enc, 7, seqs_per_context=2, graph=False)
+        ref = [folded.step(ids[:, t]).float().clone() for t in range(7)]
+        dec._sessions.clear()
+        monkeypatch.setattr(G, 'FUSED_LN_MAX_ROWS', 0)
         a = dec.decode_session(enc, 7, seqs_per_context=2, graph=False)
         b = dec.decode_session(enc, 7, seqs_per_context=2, graph=True)
         for t in range(7):
-            assert torch.equal(a.step(ids[:, t]), b.step(ids[:, t]))
+            la, lb = a.step(ids[:, t]), b.step(ids[:, t])
+            assert torch.equal(la, lb)
+            assert (la.float() - ref[t]).abs().max().item() < 0.03 * ref[t].abs().max().item()
         full = dec(ids, encoder_hidden_states=enc.repeat_interleave(2, dim=0)).logits
         before = full.clone()
         dec.transformer.ln_f.weight.mul_(2.0)           # in place under no_grad: bumps the version the pack is keyed on
