@@ -249,7 +249,8 @@ int lvl_decode_self_attn(const void* qkv, void* cache, const int* pos_dev, void*
                          void* stream);
 int lvl_cross_attn_rows_fwd(const void* q, const void* kv, void* out, int rows, int qrep, int Tk, int H, int dtype,
                             void* stream);
-/* Measurement hook: waves per workgroup (4 / 8 / 16) of lvl_cross_attn_rows_fwd's shared-context kernel; 0 = by qrep. */
+/* Measurement hook: n = 4 / 8 / 16 forces lvl_cross_attn_rows_fwd's VALU shared-context kernel with n waves per
+ * workgroup (-1: 16) where the MFMA kernel would run (bf16, qrep >= 2, Tk <= 256); 0 = the shipped choice. */
 int lvl_debug_cross_attn_waves(int waves);
 
 /* lvl_sample_next_token: everything VCLM_HF.generate does with one step's logits (narrator.py:122-137 and the warpers

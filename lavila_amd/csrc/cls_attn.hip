@@ -245,6 +245,9 @@ extern "C" int lvl_cls_attn_fwd(const void* q, const void* kv, void* out, float*
 
 namespace { std::atomic<int> g_shared_waves{0}; }
 
+int lvl_launch_cross_attn_mfma(const void* q, const void* kv, void* out, int contexts, int qrep, int Tk, int H,
+                               hipStream_t st);          // cross_attn_mfma.hip
+
 // measurement hook (tools/probe_decode_kernels.py): waves per workgroup of the shared-context kernel (0 = by qrep)
 extern "C" int lvl_debug_cross_attn_waves(int waves) {
   g_shared_waves.store(waves, std::memory_order_relaxed);
@@ -260,11 +263,14 @@ extern "C" int lvl_cross_attn_rows_fwd(const void* q, const void* kv, void* out,
   LVL_REQUIRE(lvl_aligned16(q) && lvl_aligned16(kv) && lvl_aligned16(out),
               "cross_attn_rows_fwd: pointers must be 16-byte aligned");
   if (rows == 0) return LVL_OK;
+  // bf16, several rows per context, <= 256 keys: the MFMA kernel (lvl_debug_cross_attn_waves(n != 0) keeps the VALU form)
+  if (dtype == LVL_BF16 && qrep >= 2 && Tk <= 256 && g_shared_waves.load(std::memory_order_relaxed) == 0)
+    return lvl_launch_cross_attn_mfma(q, kv, out, rows / qrep, qrep, Tk, H, (hipStream_t)stream);
   const size_t lds = (size_t)Tk * 128 * (dtype == LVL_F32 ? 4 : 2);
   if (qrep >= 2 && lds <= 150 * 1024) {           // the context's keys / values fit LDS: read them once per (context, head)
     const unsigned grid = (unsigned)(rows / qrep * H);
     int nw = g_shared_waves.load(std::memory_order_relaxed);
-    if (nw == 0) nw = 16;      // measured (profiles/r03_decode_kernels.json): 16 waves win from qrep = 2 on (19 vs 25 us)
+    if (nw <= 0) nw = 16;      // measured (profiles/r03_decode_kernels.json): 16 waves win from qrep = 2 on (19 vs 25 us)
 #define LVL_CA(TT, NWV)                                                                                       \
   do {                                                                                                        \
     if (lds > 64 * 1024)                                                                                      \

@@ -27,7 +27,7 @@ typedef __attribute__((ext_vector_type(4))) float sk_f32x4;
 namespace {
 
 constexpr int WAVES = 8;     // waves per workgroup = ways the contraction is split
-constexpr int CH = 6;        // k-steps fetched ahead per wave (6 steps x 8 waves = 1536 contraction elements per round)
+// CH (template, default 6): k-steps fetched ahead per wave (6 steps x 8 waves = 1536 contraction elements per round)
 constexpr int ACT_NONE = -1;
 
 __device__ __forceinline__ sk_f32x4 sk_mfma(uint4 a, uint4 b, sk_f32x4 c) {
@@ -85,7 +85,7 @@ __device__ __forceinline__ void skinny_finish(sk_f32x4 (*part)[NB * RB][64], con
   }
 }
 
-template <int NB, int RB, int ACT, bool PAIR>
+template <int NB, int RB, int ACT, bool PAIR, int CH = 6>
 __global__ __launch_bounds__(512) void skinny_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w,
                                                      const float* __restrict__ bias, uint16_t* __restrict__ y, int M,
                                                      int N, int K, int nstrips, int nmb) {
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(512) void skinny_ln_kernel(const uint16_t* __restri
   skinny_finish<NB, RB, ACT>(part, acc, bias, out, M, N, n0, m0);
 }
 
-template <int NB, int RB, bool PAIR>
+template <int NB, int RB, bool PAIR, int CHV = 6>
 int launch_skinny(const void* x, const void* w, const float* bias, void* y, int M, int N, int K, int act,
                   hipStream_t st) {
   const int nstrips = N / (16 * NB), nmb = (M + 16 * RB - 1) / (16 * RB);
@@ -321,8 +321,8 @@ int launch_skinny(const void* x, const void* w, const float* bias, void* y, int 
 #define LVL_SK(A)                                                                                                 \
   do {                                                                                                            \
     if (lds > 64 * 1024)                                                                                          \
-      if (int rc = lvl_allow_lds<skinny_kernel<NB, RB, A, PAIR>>()) return rc;                                    \
-    hipLaunchKernelGGL((skinny_kernel<NB, RB, A, PAIR>), grid, dim3(64 * WAVES), lds, st, (const uint16_t*)x,     \
+      if (int rc = lvl_allow_lds<skinny_kernel<NB, RB, A, PAIR, CHV>>()) return rc;                               \
+    hipLaunchKernelGGL((skinny_kernel<NB, RB, A, PAIR, CHV>), grid, dim3(64 * WAVES), lds, st, (const uint16_t*)x, \
                        (const uint16_t*)w, bias, (uint16_t*)y, M, N, K, nstrips, nmb);                            \
   } while (0)
   if (act == LVL_ACT_GELU_NEW) LVL_SK(LVL_ACT_GELU_NEW);
@@ -372,7 +372,7 @@ extern "C" int lvl_linear_skinny(const void* x, const void* w, const float* bias
   // profiles/r03_skinny_variants.json): up to 128 rows a 16 x 16 block with PAIRED k-steps (a wave reads whole 128-byte
   // lines: 12.6 -> 7.6 us at K = 3072), or 32 rows x 64 columns once N >= 2048 gives >= 64 strips; beyond 128 rows
   // (64 clips x 10 sampled captions = 640) 64 rows x 32 columns, which halves the re-reads of the weight strip
-  // (25.6 -> 19.3 us for [768 x 3072]).
+  // (25.6 -> 19.3 us for [768 x 3072]), or 64 x 64 for N >= 2048.
   const hipStream_t st = (hipStream_t)stream;
   switch (g_variant.load(std::memory_order_relaxed)) {       // measurement variants (tools/probe_skinny.py)
     case 1: if (N % 32 == 0) return launch_skinny<2, 2, true>(x, w, bias, y, M, N, K, act, st); break;
@@ -384,11 +384,18 @@ extern "C" int lvl_linear_skinny(const void* x, const void* w, const float* bias
     case 7: if (N % 64 == 0) return launch_skinny<4, 2, false>(x, w, bias, y, M, N, K, act, st); break;
     case 8: if (N % 32 == 0) return launch_skinny<2, 2, false>(x, w, bias, y, M, N, K, act, st); break;
     case 9: return launch_skinny<1, 1, false>(x, w, bias, y, M, N, K, act, st);
+    case 10: if (N % 64 == 0) return launch_skinny<4, 4, false, 3>(x, w, bias, y, M, N, K, act, st); break;
+    case 11: if (N % 64 == 0) return launch_skinny<4, 4, false, 4>(x, w, bias, y, M, N, K, act, st); break;
+    case 12: if (N % 64 == 0) return launch_skinny<4, 4, true, 4>(x, w, bias, y, M, N, K, act, st); break;
+    case 13: if (N % 32 == 0) return launch_skinny<2, 4, false, 4>(x, w, bias, y, M, N, K, act, st); break;
     default: break;
   }
-  if (M > 128)
+  if (M > 128) {
+    // wide matrices: 64 x 64 outputs with 3 k-steps in flight (199 VGPRs) -- 16.6 vs 23.3 us for [3072 x 768] at 640 rows
+    if (N >= 2048 && N % 64 == 0) return launch_skinny<4, 4, false, 3>(x, w, bias, y, M, N, K, act, st);
     return N % 32 == 0 ? launch_skinny<2, 4, false>(x, w, bias, y, M, N, K, act, st)
                        : launch_skinny<1, 2, false>(x, w, bias, y, M, N, K, act, st);
+  }
   if (N >= 2048 && N % 64 == 0) return launch_skinny<4, 2, false>(x, w, bias, y, M, N, K, act, st);
   return launch_skinny<1, 1, true>(x, w, bias, y, M, N, K, act, st);
 }

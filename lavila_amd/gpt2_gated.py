@@ -408,6 +408,18 @@ class DecodeSession:
         return logits
 
     def _capture(self):
+        """One eager step on a side stream (lazy kernel attributes, allocator warm-up), then the capture. A capture that
+        fails (e.g. another thread launching on the device meanwhile) leaves the session on eager launches, loudly."""
+        try:
+            self._capture_step()
+        except RuntimeError as e:                        # hipGraph errors surface as RuntimeError from torch
+            import warnings
+            warnings.warn(f'DecodeSession: hipGraph capture failed ({e}); decoding with eager launches')
+            self._graph, self._logits, self.graphed = None, None, False
+            torch.cuda.synchronize()
+            self.pos.zero_()
+
+    def _capture_step(self):
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):           # first launch outside the capture: lazy kernel attributes, allocator warm-up
@@ -466,6 +478,13 @@ class GPT2LMHeadModel(nn.Module):
             self.lm_head.weight = self.transformer.wte.weight
         self._packs = {}
         self._sessions = {}
+
+    def __getstate__(self):
+        """The packed weights and decode sessions (device buffers, captured graphs) are caches of the parameters: they
+        are rebuilt on demand and never copied or pickled with the module (copy.deepcopy, torch.save(model))."""
+        state = self.__dict__.copy()
+        state['_packs'], state['_sessions'] = {}, {}
+        return state
 
     # ---- reference API ---------------------------------------------------------------------------------
     def freeze_lm_weights(self):

@@ -107,7 +107,8 @@ def test_decode_self_attention_steps(dt, B, H, steps, cap):
 
 
 @pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize('contexts,qrep,H,T', [(2, 1, 3, 24), (3, 12, 12, 256), (2, 5, 2, 37), (1, 3, 1, 1)])
+@pytest.mark.parametrize('contexts,qrep,H,T', [(2, 1, 3, 24), (3, 12, 12, 256), (2, 5, 2, 37), (1, 3, 1, 1), (2, 20, 3, 200),
+                                               (1, 76, 2, 256), (2, 16, 1, 16), (2, 4, 2, 300)])
 def test_cross_attention_rows(dt, contexts, qrep, H, T):
     from lavila_amd import _cabi as C
     D = H * 64
@@ -514,6 +515,31 @@ def test_decode_session_graph_equals_eager_bitwise_and_tracks_weights(monkeypatc
         assert a.stale() and b.stale()
         after = dec(ids, encoder_hidden_states=enc.repeat_interleave(2, dim=0)).logits
         assert not torch.equal(before, after)
+
+
+def test_gpt2_xl_widths_decode(monkeypatch):
+    """GPT-2 XL's layout (width 1600 = 25 heads, cross-attention in every 2nd block: models.py:981-1005) at 3 blocks:
+    widths lvl_linear_tn does not tile. Decoding runs on the strip kernels (no library GEMM), the teacher-forced pass on
+    few rows too; both agree with the f32 oracle and with each other."""
+    m, c, d, w = _mid_model('bf16', width=1600, heads=25, layers=3, vocab=331, freq=2)
+    dec = m.text_decoder.bfloat16()
+    H = 25
+    g = torch.Generator().manual_seed(13)
+    B, L = 2, 9
+    ids = torch.randint(1, d['vocab'], (B, L), generator=g)
+    enc = torch.randn(B, c['queries'], 1600, generator=g)
+    want, _ = O.gpt2_lm_logits(ids, enc, w, H, prefix='text_decoder.')
+    monkeypatch.setattr(F, 'linear', lambda *a, **k: (_ for _ in ()).throw(AssertionError('library GEMM in the decoder')))
+    scale = want.abs().max().item()
+    with torch.no_grad():
+        enc_dev = enc.to(DEV).bfloat16()
+        got = dec(ids.to(DEV), encoder_hidden_states=enc_dev).logits.float().cpu()
+        assert (got - want).abs().max().item() < 0.04 * scale
+        for graph in (False, True):
+            sess = dec.decode_session(enc_dev, L, graph=graph)
+            for t in range(L):
+                step = sess.step(ids[:, t].to(DEV)).float().cpu()
+                assert (step - want[:, t]).abs().max().item() < 0.04 * scale, (graph, t)
 
 
 def test_decoder_is_loud_about_what_it_does_not_do():

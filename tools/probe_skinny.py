@@ -1,6 +1,6 @@
 """Times lvl_linear_skinny's tilings (lvl_debug_skinny_variant) on the decoder's Conv1D shapes, next to lvl_linear_tn and
 the library GEMM: python tools/probe_skinny.py [--out file]. Variants (rows x columns per workgroup): 0 shipped; 1 32x32 paired k-steps; 2 64x32; 3 64x64; 4 64x32 paired; 5 16x32
-paired; 6 16x16 paired; 7 32x64; 8 32x32; 9 16x16."""
+paired; 6 16x16 paired; 7 32x64; 8 32x32; 9 16x16; 10 / 11 64x64 with 3 / 4 k-steps ahead; 12 the same paired; 13 64x32 with 4."""
 import argparse
 import json
 import os
@@ -14,7 +14,7 @@ from lavila_amd import ops  # noqa: E402
 
 
 def timed(fn, n=40):
-    for _ in range(5):
+    for _ in range(15):
         fn()
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -40,7 +40,7 @@ def main():
         y = torch.empty(M, N, dtype=torch.bfloat16, device='cuda')
         want = (x.float() @ w.float().t() + b)
         row = {}
-        for v in range(10):
+        for v in range(14):
             C.lib().lvl_debug_skinny_variant(v)
 
             def run():
