@@ -1,10 +1,8 @@
 #!/bin/bash
 set -u
-O=gpurun_out/r3u
+O=gpurun_out/r3z
 mkdir -p $O
 export TMPDIR=/tmp
-(timeout 300 python __graft_entry__.py smoke 2>&1 | tail -5) > $O/smoke.log
-(timeout 600 python tools/probe_skinny.py --out $O/skinny_variants.json 2>&1 | tail -12) > $O/skinny.log
 (timeout 900 python tools/probe_narrator.py --batch 64 --length 77 --half --reps 3 --out $O/narrator_b64.json 2>&1 | tail -3) > $O/probe_b64.log
 (timeout 900 python tools/probe_narrator.py --batch 64 --length 77 --returns 10 --sample --half --reps 2 --out $O/narrator_b64_r10.json 2>&1 | tail -3) > $O/probe_r10.log
 cd /tmp
