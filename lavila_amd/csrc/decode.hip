@@ -22,7 +22,8 @@ __global__ __launch_bounds__(128) void gpt2_embed_kernel(const int64_t* __restri
                                                          T* __restrict__ out, int L, int D, int vocab, int positions) {
   const int r = blockIdx.x;
   int64_t id = ids[r];
-  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);          // ids are validated on the host where that is free
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);          // no wild reads; GPT2LMHeadModel.forward range-checks on the host,
+                                                             // decode steps feed the sampler's own tokens
   int p = (pos_dev ? *pos_dev : 0) + r % L;
   p = p >= positions ? positions - 1 : p;
   const T* a = wte + id * D;

@@ -547,6 +547,9 @@ class GPT2LMHeadModel(nn.Module):
             raise ValueError(f'sequence of {L} tokens exceeds the decoder\'s {pack.positions} positions')
         ids = input_ids.reshape(-1, L)
         B = ids.shape[0]
+        lo, hi = int(ids.min()), int(ids.max())          # nn.Embedding would fail on these; the gather kernel clamps
+        if lo < 0 or hi >= pack.vocab:
+            raise IndexError(f'input_ids out of range [0, {pack.vocab}): min {lo}, max {hi}')
         with torch.no_grad(), torch.autocast('cuda', enabled=False):
             xkv = qrep = None
             if encoder_hidden_states is not None and any(e['cross'] for e in pack.blocks):

@@ -555,6 +555,8 @@ def test_decoder_is_loud_about_what_it_does_not_do():
                 dec(ids, **kw)
         with pytest.raises(ValueError):
             dec(torch.zeros(1, d['positions'] + 1, dtype=torch.long, device=DEV))
+        with pytest.raises(IndexError):
+            dec(torch.full((1, 3), d['vocab'], dtype=torch.long, device=DEV))
         plain = dec(ids).logits                                      # no image tokens: plain GPT-2 (gpt2_gated.py:432)
         want, _ = O.gpt2_lm_logits(ids.cpu(), None, w, c['pool_heads'], prefix='text_decoder.')
         torch.testing.assert_close(plain.cpu(), want, atol=2e-3, rtol=1e-3)
