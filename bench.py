@@ -24,6 +24,10 @@ Extra objects in the line:
                   lvl_divided_attn_fwd): algorithmic bytes per launch / average duration against 8 TB/s.
   cpu_baseline -- the CPU oracle (oracle/oracle.py, kind "port") timed on this box's host cores on a bounded
                   sample (one fwd+loss+bwd of a small batch of the same shapes), rank 0 at N=1 only.
+
+`--workload narrator` (not part of the driver contract; default stays the metric above) prints the same kind of line for
+BASELINE configs[4]: captions/s of VCLM_OPENAI_TIMESFORMER_BASE_GPT2 (encode_image + generate), with the decode step's
+HBM roofline and the CPU oracle's narrator as cpu_baseline.
 """
 import argparse
 import json
@@ -62,6 +66,11 @@ def parse():
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-batch', type=int, default=8)
     p.add_argument('--no-events', action='store_true', help='skip per-launch HIP events (A/B their overhead)')
+    p.add_argument('--workload', default='pretrain', choices=['pretrain', 'narrator'],
+                   help='pretrain (default) = BASELINE.json\'s metric; narrator = captions/s of BASELINE configs[4] '
+                        '(VCLM_OPENAI_TIMESFORMER_BASE_GPT2 inference), an extra line outside the driver contract')
+    p.add_argument('--returns', type=int, default=10, help='narrator: captions sampled per clip')
+    p.add_argument('--length', type=int, default=77, help='narrator: caption length in tokens')
     p.add_argument('--reuse-tokens', action='store_true',
                    help='feed the SAME token tensor object every step (A/B only: the caption-length read-back of the '
                         'text tower is memoised per tensor object; the default hands over a new tensor per step, as a '
@@ -173,6 +182,118 @@ def cpu_baseline(args, model, img):
                       f'(mean {mean:.2f} s, best {min(times):.2f} s)'}
 
 
+def narrator_cpu_baseline(args, model, tok):
+    """The CPU oracle's narrator (port of the reference: encode_image + generate with the reference's schedule, the whole
+    prefix and the image keys / values recomputed for every token) on ONE clip x `--returns` captions of `--length`
+    tokens, float32 (greedy: the oracle has no sampler; the arithmetic per caption is the same)."""
+    from oracle import oracle as O
+    cores = min(32, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    w = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    video, _ = O.synthetic_batch(1, args.frames, 224, seed=99)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        img = O.narrator_encode_image(video, w, 12, 12).repeat_interleave(args.returns, dim=0)
+        O.narrator_generate_greedy(img, w, 12, tok.bos_token_id, -1, tok.pad_token_id, args.length, use_cache=False)
+    dt = time.perf_counter() - t0
+    return {'value': round(args.returns / dt, 4), 'unit': 'captions/s', 'cores': cores, 'kind': 'port',
+            'cpu': f'{_cpu_model()} ({os.cpu_count()} logical cores on the box)',
+            'sample': f'oracle/oracle.py narrator_encode_image + narrator_generate_greedy(use_cache=False), f32: 1 clip of '
+                      f'{args.frames}x224^2, {args.returns} captions x {args.length} tokens, one run ({dt:.1f} s)'}
+
+
+def narrator_main(args, world, rank, device):
+    """captions/s of the narrator (BASELINE configs[4]): one step = encode_image of `--batch` clips + generate() of
+    `--returns` nucleus samples per clip (top_p 0.95, temperature 0.7: main_infer_narrator.py:53-62) of `--length` tokens,
+    fp16 parameters / clips (`--use-half`), bf16 inside; random-init weights with live gates, synthetic clips. Ranks are
+    independent replicas (the captioning drivers shard clips over ranks and never communicate)."""
+    import contextlib
+    import io
+    import types
+    from lavila.models import models
+    with warnings.catch_warnings(), contextlib.redirect_stdout(io.StringIO()):
+        warnings.simplefilter('ignore')
+        torch.manual_seed(0)
+        model = models.VCLM_OPENAI_TIMESFORMER_BASE_GPT2(gated_xattn=True, num_frames=args.frames)
+    with torch.no_grad():
+        for b in model.text_decoder.transformer.h:          # the shipped zeros would switch the image path off
+            b.alpha_cattn.fill_(0.5)
+            b.alpha_dense.fill_(0.5)
+    tok = types.SimpleNamespace(bos_token_id=50256, eos_token_id=50256, pad_token_id=50256)
+    cpu = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        cpu = narrator_cpu_baseline(args, model, tok)
+    model = model.to(device).eval().half()
+    clips = torch.randn(args.batch, 3, args.frames, 224, 224, device=device, generator=None).half()
+    kw = dict(max_text_length=args.length, top_k=None, top_p=0.95, temperature=0.7, num_return_sequences=args.returns)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    decode_ms = []
+
+    def step():
+        with torch.no_grad():
+            img = model.encode_image(clips)
+            ev[0].record()
+            out = model.generate(img, tok, **kw)
+            ev[1].record()
+        return out
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ids, ppl = step()
+        torch.cuda.synchronize()
+        decode_ms.append(ev[0].elapsed_time(ev[1]))
+    fence()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    if rank == 0:
+        rows, steps_tok = args.batch * args.returns, args.length - 1
+        dec = model.text_decoder
+        n_dec = sum(p.numel() for n, p in dec.named_parameters() if not n.startswith('lm_head'))
+        alg = 2 * n_dec + 12 * args.batch * 256 * 1536 * 2 + rows * 12 * (steps_tok / 2) * 1536 * 2 + rows * 50432 * 2
+        step_ms = sum(decode_ms) / len(decode_ms) / steps_tok
+        ach = alg / (step_ms * 1e-3) / 1e9
+        line = {
+            'metric': 'narrator captions/s (whole node), VCLM_OPENAI_TIMESFORMER_BASE_GPT2 4x224^2, encode_image + generate',
+            'value': round(world * rows * args.steps / elapsed, 2), 'unit': 'captions/s', 'n_gpus': world,
+            'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': f'BASELINE configs[4]: {args.batch} clips x {args.returns} nucleus samples (top_p 0.95, '
+                                   f'temperature 0.7) x {args.length} tokens per step, fp16 parameters / clips, bf16 inside, '
+                                   'key/value-cached decode replayed as one hipGraph per token',
+                       'parallelism': f'{world} independent replicas', 'decode_ms_per_token_step': round(step_ms, 4),
+                       'finite_perplexities': bool(torch.isfinite(ppl).all()), 'caption_shape': list(ids.shape)},
+            'roofline': {'bound': 'hbm', 'kernel': 'one decode step = hipGraph replay of 172 kernels (Conv1Ds on '
+                                                   'lvl_linear_skinny, cross / self attention, fused add+LayerNorm, lm_head) '
+                                                   '+ lvl_sample_next_token',
+                         'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
+                         'traffic': json.load(open(_traffic_file('narrator_traffic.json')))['total_bytes_per_token_step']
+                         if (args.batch, args.returns) == (64, 1) and os.path.isfile(_traffic_file('narrator_traffic.json'))
+                         else None,
+                         'avg_ms': round(step_ms, 4), 'launches': len(decode_ms) * steps_tok,
+                         'alg_bytes_per_launch': int(alg),
+                         'note': 'algorithmic bytes of a token step: decoder weights once (bf16), the image keys / values of '
+                                 'the 12 cross-attentions, the self-attention caches at half fill, the logits; the step is '
+                                 'bound by its dependent launches, not by HBM (DESIGN.md section 4)'},
+        }
+        if cpu is not None:
+            line['cpu_baseline'] = cpu
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def _self_launch(args):
     """`python bench.py --gpus N` without a launcher: run the same command line under torch.distributed.run (one process
     per GPU, rendezvous on 127.0.0.1 and a free port) and hand its exit status back. Rank 0 of the child job prints the
@@ -215,6 +336,11 @@ def main():
         else:
             dist.init_process_group(backend)
             rehearsal = f'REHEARSAL: {world} ranks on {ndev} device(s) over {backend} -- not a scaling measurement'
+
+    if args.workload == 'narrator':
+        if args.batch == 256:
+            args.batch = 64                # main_infer_narrator.py:48
+        return narrator_main(args, world, rank, device)
 
     from lavila_amd import ops
     from lavila.models.loss import CLIPLoss
