@@ -224,9 +224,10 @@ int lvl_mq_cross_attn_fwd(const void* q, int64_t q_batch_stride, const void* kv,
 /* lvl_linear_skinny: y[M,N] = act(x[M,K] . w[N,K]^T + bias) for FEW rows -- the decoder's Conv1Ds while decoding
  * (M = captions in flight; gpt2_gated.py:327-334,337,354,392-394) and its lm_head. bf16 x / w / y, f32 bias (nullable)
  * and accumulation; act: -1 none, LVL_ACT_GELU_NEW, LVL_ACT_SQRELU (applied to the f32 sum before the bf16 store).
- * One workgroup per 16 rows x 16 (N < 2048) or 32 columns, its 8 waves splitting K (lvl_linear_tn gives a 256-column
- * panel to one compute unit, which at M <= 64 leaves the chip idle). N % 16 == 0 and K % 32 == 0, else LVL_ENOSYS; any
- * M >= 0 (every 16-row block re-reads its weight strip, from the L2 of the XCD the strip's blocks share). */
+ * Up to 128 rows: one workgroup per 16 rows x 16 (N < 2048) or 32 x 64 columns, its 8 waves splitting K, fragments
+ * straight from memory (lvl_linear_tn gives a 256-column panel to one compute unit, which at M <= 64 leaves the chip idle).
+ * Beyond 128 rows, and for N >= 8192 (lm_head), K % 64 == 0: LDS-staged 64 x 64 / 64 x 128 tiles (whole-line loads, three K
+ * blocks in flight). N % 16 == 0 and K % 32 == 0, else LVL_ENOSYS; any M >= 0. */
 int lvl_linear_skinny(const void* x, const void* w, const float* bias, void* y, int M, int N, int K, int act, void* stream);
 /* lvl_linear_skinny_ln: out[M,N] = act(LayerNorm(res + (*gate) * y) . w^T + bias), res_out = bf16(res + (*gate) * y) --
  * lvl_gated_add_layernorm folded into the prologue of the Conv1D that consumes it (q_attn / c_attn / the two c_fc of a

@@ -19,6 +19,8 @@
 //     run on the SAME XCD (id % 8) within 8 * row-blocks consecutive ids -- the re-reads hit that XCD's L2;
 //   * epilogue: + bias, optional gelu_new / relu^2 (the two MLP activations of the gated GPT-2, gpt2_gated.py:363-396),
 //     bf16 store. Rows >= M are never stored (their loads are clamped to row M-1).
+// Beyond 128 rows, and for the lm_head's 50432 columns, the same entry point runs an LDS-staged tile kernel (mid_kernel
+// below): there the strips' half-used cache lines and re-reads cost more than a barrier per K block.
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 sk_bf16x8;
@@ -354,6 +356,163 @@ int launch_skinny_ln(const void* res, const void* w, const float* bias, void* ou
   return LVL_OK;
 }
 
+// ---- many rows (128 < M <= ~1024: 64 clips x 10 sampled captions): operands through LDS -----------------------------------
+// The strip kernel's fragments come straight from memory: a wave instruction touches 16 rows x 64 bytes -- 16 half-used
+// cache lines -- and a compute unit sustains only ~30 GB/s that way (measured: 17-19 us for the 640-row Conv1Ds where the
+// library GEMM takes 8-12). With hundreds of rows the classic form pays: a workgroup tile of (32 WM) x (32 WN) outputs... 
+// here TMxTN = 128x128 (8 waves, 64x32 each) or 64x64 (4 waves, 32x32 each), K walked in blocks of 64:
+//   * global -> registers with 8 lanes per 128-byte row (whole cache lines), DEPTH blocks in flight per thread, then one
+//     ds_write_b128 per piece into a double-buffered LDS tile whose 16-byte chunks are XOR-swizzled by the row;
+//   * ds_read_b128 fragments in the MFMA layout (weights = operand A, rows of x = operand B, as everywhere in this file),
+//     one barrier per K block; every wave owns its sub-tile for the whole K, so there is no cross-wave reduction;
+//   * epilogue: + bias, gelu_new / relu^2, 8-byte bf16 stores.
+template <int WM, int WN, int RB, int NB, int ACT, int DEPTH>
+__global__ __launch_bounds__(64 * WM * WN) void mid_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w,
+                                                           const float* __restrict__ bias, uint16_t* __restrict__ y, int M,
+                                                           int N, int K, int tiles_n) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr int TM = 16 * RB * WM, TN = 16 * NB * WN;           // workgroup tile
+  constexpr int XP = TM * 8 / NT, WP = TN * 8 / NT;             // 16-byte pieces per thread and K block
+  static_assert(TM * 8 % NT == 0 && TN * 8 % NT == 0, "pieces divide evenly");
+  extern __shared__ __align__(16) unsigned char sk_smem[];
+  // stage s: x tile at s * (TM + TN) * 128, w tile behind it; rows of 128 bytes (64 contraction elements)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int wm = wave / WN, wn = wave % WN;
+  const int tn = blockIdx.x % tiles_n, tm = blockIdx.x / tiles_n;
+  const int m0 = tm * TM, n0 = tn * TN;
+  // global sources of this thread's pieces: piece p -> tile row (p * NT + tid) / 8, 16-byte chunk tid % 8
+  const uint16_t* xsrc[XP];
+  const uint16_t* wsrc[WP];
+  int xdst[XP], wdst[WP];
+#pragma unroll
+  for (int p = 0; p < XP; ++p) {
+    const int r = (p * NT + tid) >> 3, ch = tid & 7;
+    const int row = m0 + r;
+    xsrc[p] = x + (int64_t)(row < M ? row : M - 1) * K + ch * 8;
+    xdst[p] = r * 128 + ((ch ^ (r & 7)) << 4);
+  }
+#pragma unroll
+  for (int p = 0; p < WP; ++p) {
+    const int r = (p * NT + tid) >> 3, ch = tid & 7;
+    const int col = n0 + r;
+    wsrc[p] = w + (int64_t)(col < N ? col : N - 1) * K + ch * 8;
+    wdst[p] = TM * 128 + r * 128 + ((ch ^ (r & 7)) << 4);
+  }
+  constexpr int STAGE = (TM + TN) * 128;
+  sk_f32x4 acc[NB][RB];
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) acc[nb][rb] = sk_f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nblk = K >> 6;
+  static_assert(DEPTH == 3, "the K loop below is written out for three blocks in flight");
+  // three named register sets, filled and drained by macros (arrays handed to lambdas, or indexed by a slot number, end up
+  // in scratch memory and serialise the pipeline on their stores)
+  lvl_u32x4 ra[XP + WP], rb_[XP + WP], rc[XP + WP];
+#define SK_FETCH(R, BLK)                                                                              \
+  do {                                                                                                \
+    const int blk__ = (BLK);                                                                          \
+    _Pragma("unroll") for (int p = 0; p < XP; ++p)                                                    \
+        R[p] = *reinterpret_cast<const lvl_u32x4*>(xsrc[p] + blk__ * 64);                                 \
+    _Pragma("unroll") for (int p = 0; p < WP; ++p)                                                    \
+        R[XP + p] = *reinterpret_cast<const lvl_u32x4*>(wsrc[p] + blk__ * 64);                            \
+  } while (0)
+#define SK_STASH(R, STG)                                                                              \
+  do {                                                                                                \
+    unsigned char* base__ = sk_smem + (STG) * STAGE;                                                  \
+    _Pragma("unroll") for (int p = 0; p < XP; ++p) *reinterpret_cast<lvl_u32x4*>(base__ + xdst[p]) = R[p]; \
+    _Pragma("unroll") for (int p = 0; p < WP; ++p)                                                    \
+        *reinterpret_cast<lvl_u32x4*>(base__ + wdst[p]) = R[XP + p];                                      \
+  } while (0)
+  auto compute = [&](int stage) {
+    const unsigned char* xs = sk_smem + stage * STAGE;
+    const unsigned char* ws = xs + TM * 128;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      uint4 wf[NB], xf[RB];
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb) {
+        const int r = wn * (16 * NB) + nb * 16 + c;
+        wf[nb] = *reinterpret_cast<const uint4*>(ws + r * 128 + (((ks * 4 + g) ^ (r & 7)) << 4));
+      }
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        const int r = wm * (16 * RB) + rb * 16 + c;
+        xf[rb] = *reinterpret_cast<const uint4*>(xs + r * 128 + (((ks * 4 + g) ^ (r & 7)) << 4));
+      }
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) acc[nb][rb] = sk_mfma(wf[nb], xf[rb], acc[nb][rb]);
+    }
+  };
+  // prologue: DEPTH blocks requested, the first one staged. Every fetch and stash below is UNCONDITIONAL (block indices
+  // are clamped to the last block, whose redundant copies nobody reads): the loads of a thread then retire in a fixed
+  // order and the compiler's counted vmcnt waits let DEPTH - 1 blocks stay in flight behind the one being stashed.
+  const int last = nblk - 1;
+  auto clampb = [&](int b) { return b < last ? b : last; };
+  SK_FETCH(ra, 0);
+  SK_FETCH(rb_, clampb(1));
+  SK_FETCH(rc, clampb(2));
+  SK_STASH(ra, 0);
+  __syncthreads();
+  for (int k = 0; k < nblk; k += 3) {
+    SK_FETCH(ra, clampb(k + 3));                           // ra went to LDS one step ago
+    compute(k & 1);
+    SK_STASH(rb_, (k + 1) & 1);
+    __syncthreads();
+    SK_FETCH(rb_, clampb(k + 4));
+    if (k + 1 < nblk) compute((k + 1) & 1);
+    SK_STASH(rc, (k + 2) & 1);
+    __syncthreads();
+    SK_FETCH(rc, clampb(k + 5));
+    if (k + 2 < nblk) compute((k + 2) & 1);
+    SK_STASH(ra, (k + 3) & 1);
+    __syncthreads();
+  }
+#undef SK_FETCH
+#undef SK_STASH
+#pragma unroll
+  for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      const int row = m0 + wm * (16 * RB) + rb * 16 + c, n = n0 + wn * (16 * NB) + nb * 16 + g * 4;
+      if (row < M && n < N) {
+        sk_f32x4 v = acc[nb][rb];
+        if (bias) {
+          const float4 b = *reinterpret_cast<const float4*>(bias + n);
+          v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+        }
+        const uint2 o = make_uint2(f32x2_to_bf16x2(sk_act<ACT>(v[0]), sk_act<ACT>(v[1])),
+                                   f32x2_to_bf16x2(sk_act<ACT>(v[2]), sk_act<ACT>(v[3])));
+        *reinterpret_cast<uint2*>(y + (int64_t)row * N + n) = o;
+      }
+    }
+  }
+}
+
+template <int WM, int WN, int RB, int NB, int DEPTH>
+int launch_mid(const void* x, const void* w, const float* bias, void* y, int M, int N, int K, int act, hipStream_t st) {
+  constexpr int TM = 16 * RB * WM, TN = 16 * NB * WN;
+  const int tiles_n = (N + TN - 1) / TN, tiles_m = (M + TM - 1) / TM;
+  const dim3 grid((unsigned)(tiles_n * tiles_m));
+  constexpr size_t lds = (size_t)2 * (TM + TN) * 128;
+#define LVL_MK(A)                                                                                                   \
+  do {                                                                                                              \
+    if (lds > 64 * 1024)                                                                                            \
+      if (int rc = lvl_allow_lds<mid_kernel<WM, WN, RB, NB, A, DEPTH>>()) return rc;                                \
+    hipLaunchKernelGGL((mid_kernel<WM, WN, RB, NB, A, DEPTH>), grid, dim3(64 * WM * WN), lds, st, (const uint16_t*)x, \
+                       (const uint16_t*)w, bias, (uint16_t*)y, M, N, K, tiles_n);                                   \
+  } while (0)
+  if (act == LVL_ACT_GELU_NEW) LVL_MK(LVL_ACT_GELU_NEW);
+  else if (act == LVL_ACT_SQRELU) LVL_MK(LVL_ACT_SQRELU);
+  else LVL_MK(ACT_NONE);
+#undef LVL_MK
+  LVL_CHECK_LAUNCH("linear_skinny (mid)");
+  return LVL_OK;
+}
+
 std::atomic<int> g_variant{0};      // lvl_debug_skinny_variant: 0 = the shipped choice
 
 }  // namespace
@@ -388,7 +547,21 @@ extern "C" int lvl_linear_skinny(const void* x, const void* w, const float* bias
     case 11: if (N % 64 == 0) return launch_skinny<4, 4, false, 4>(x, w, bias, y, M, N, K, act, st); break;
     case 12: if (N % 64 == 0) return launch_skinny<4, 4, true, 4>(x, w, bias, y, M, N, K, act, st); break;
     case 13: if (N % 32 == 0) return launch_skinny<2, 4, false, 4>(x, w, bias, y, M, N, K, act, st); break;
+    case 14: if (K % 64 == 0) return launch_mid<2, 4, 4, 2, 3>(x, w, bias, y, M, N, K, act, st); break;   // 128 x 128, 3 blocks ahead
+    case 15: if (K % 64 == 0) return launch_mid<2, 4, 2, 2, 3>(x, w, bias, y, M, N, K, act, st); break;   // 64 x 128 (8 waves)
+    case 16: if (K % 64 == 0) return launch_mid<2, 2, 2, 2, 3>(x, w, bias, y, M, N, K, act, st); break;   // 64 x 64 (4 waves)
+    case 17: if (K % 64 == 0) return launch_mid<4, 2, 2, 2, 3>(x, w, bias, y, M, N, K, act, st); break;   // 128 x 64 (8 waves)
+    case 18: if (K % 64 == 0) return launch_mid<2, 2, 4, 4, 3>(x, w, bias, y, M, N, K, act, st); break;   // 128 x 128 on 4 waves
     default: break;
+  }
+  if (K % 64 == 0) {
+    // the LDS-staged kernel where whole-line loads and operand reuse decide (in-graph times, profiles/r03_skinny_variants.json):
+    // lm_head [50432 x 768] at <= 128 rows 17.3 us (strips 40.6, the 256-column-panel kernel 31.6, library 16.3); beyond
+    // 128 rows [3072 x 768] 8.6 us (strips 16.8, library 8.3), [2304 x 768] 8.3 (16.5, 8.0), [768 x 3072] 16.8 (19.3, 12.1)
+    if (N >= 8192 && M <= 128) return launch_mid<2, 4, 2, 2, 3>(x, w, bias, y, M, N, K, act, st);       // 64 x 128 tiles
+    if (M > 128)
+      return N >= 2048 ? launch_mid<2, 4, 2, 2, 3>(x, w, bias, y, M, N, K, act, st)                     // 64 x 128
+                       : launch_mid<2, 2, 2, 2, 3>(x, w, bias, y, M, N, K, act, st);                    // 64 x 64
   }
   if (M > 128) {
     // wide matrices: 64 x 64 outputs with 3 k-steps in flight (199 VGPRs) -- 16.6 vs 23.3 us for [3072 x 768] at 640 rows

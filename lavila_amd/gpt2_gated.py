@@ -269,9 +269,9 @@ class _Pack:
     def logits(self, h2):
         """lm_head (no bias, gpt2_gated.py:1010,1139): [rows, D] -> [rows, vocab] (a view of the padded product)."""
         if self.dtype == torch.bfloat16:
-            # 50432 x 768: enough 256-column panels (197) for the persistent kernel at any row count -- 32 us at 64 rows,
-            # 74 us at 640, where the strip kernel needs 41 / 300 us (profiles/r03_skinny_variants.json)
-            if ops._tn_ok(h2.shape[0], self.head.shape[0], self.D) and self.head.shape[0] >= 8192:
+            # 50432 x 768 (profiles/r03_skinny_variants.json, in-graph): up to 128 rows lvl_linear_skinny's LDS-staged tiles
+            # (17 us; the 256-column-panel kernel 32), beyond that the panel kernel (72 us at 640 rows; tiles 87-120)
+            if h2.shape[0] > 128 and ops._tn_ok(h2.shape[0], self.head.shape[0], self.D) and self.head.shape[0] >= 8192:
                 return ops.linear_tn_raw(h2, self.head, None, C.EPI_BIAS)[:, :self.vocab]
             if h2.shape[0] <= SKINNY_MAX_ROWS and self.D % 32 == 0:
                 return self._skinny(h2, self.head, None, None)[:, :self.vocab]
