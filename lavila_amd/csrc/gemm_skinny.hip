@@ -366,17 +366,21 @@ int launch_skinny_ln(const void* res, const void* w, const float* bias, void* ou
 //   * ds_read_b128 fragments in the MFMA layout (weights = operand A, rows of x = operand B, as everywhere in this file),
 //     one barrier per K block; every wave owns its sub-tile for the whole K, so there is no cross-wave reduction;
 //   * epilogue: + bias, gelu_new / relu^2, 8-byte bf16 stores.
-template <int WM, int WN, int RB, int NB, int ACT, int DEPTH>
-__global__ __launch_bounds__(64 * WM * WN) void mid_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w,
+template <int WM, int WN, int RB, int NB, int ACT, int DEPTH, int KG = 1>
+__global__ __launch_bounds__(64 * WM * WN * KG) void mid_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w,
                                                            const float* __restrict__ bias, uint16_t* __restrict__ y, int M,
                                                            int N, int K, int tiles_n) {
-  constexpr int NT = 64 * WM * WN;
+  // KG = 2: two groups of WM x WN waves work on the SAME output tile, group q on the K blocks q, q + 2, ... with its own
+  // LDS stages (a [768 x 3072] Conv1D at 640 rows is 120 tiles of 48 blocks: the chain, not the chip, is the limit);
+  // their accumulators meet in LDS at the end.
+  constexpr int NT = 64 * WM * WN;                              // threads of one K group
   constexpr int TM = 16 * RB * WM, TN = 16 * NB * WN;           // workgroup tile
   constexpr int XP = TM * 8 / NT, WP = TN * 8 / NT;             // 16-byte pieces per thread and K block
   static_assert(TM * 8 % NT == 0 && TN * 8 % NT == 0, "pieces divide evenly");
   extern __shared__ __align__(16) unsigned char sk_smem[];
   // stage s: x tile at s * (TM + TN) * 128, w tile behind it; rows of 128 bytes (64 contraction elements)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lane = threadIdx.x & 63, wave_all = threadIdx.x >> 6;
+  const int kg = wave_all / (WM * WN), wave = wave_all % (WM * WN), tid = threadIdx.x - kg * NT;
   const int c = lane & 15, g = lane >> 4;
   const int wm = wave / WN, wn = wave % WN;
   const int tn = blockIdx.x % tiles_n, tm = blockIdx.x / tiles_n;
@@ -405,28 +409,31 @@ __global__ __launch_bounds__(64 * WM * WN) void mid_kernel(const uint16_t* __res
   for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) acc[nb][rb] = sk_f32x4{0.f, 0.f, 0.f, 0.f};
-  const int nblk = K >> 6;
-  static_assert(DEPTH == 3, "the K loop below is written out for three blocks in flight");
-  // three named register sets, filled and drained by macros (arrays handed to lambdas, or indexed by a slot number, end up
-  // in scratch memory and serialise the pipeline on their stores)
-  lvl_u32x4 ra[XP + WP], rb_[XP + WP], rc[XP + WP];
+  const int nblk_all = K >> 6;
+  const int nblk = (nblk_all - kg + KG - 1) / KG;              // blocks of this K group: kg, kg + KG, ...
+  const int nloop = (nblk_all + KG - 1) / KG;                  // iterations every wave runs (barriers are workgroup-wide)
+  unsigned char* const stage_base = sk_smem + kg * 2 * STAGE;
+  // DEPTH register sets of XP + WP pieces, filled and drained with compile-time indices only (native vector type: an
+  // array of HIP's uint4 structs, or a set picked by a run-time slot number, ends up in scratch memory and serialises the
+  // pipeline on its stores)
+  lvl_u32x4 ring[DEPTH][XP + WP];
 #define SK_FETCH(R, BLK)                                                                              \
   do {                                                                                                \
     const int blk__ = (BLK);                                                                          \
     _Pragma("unroll") for (int p = 0; p < XP; ++p)                                                    \
-        R[p] = *reinterpret_cast<const lvl_u32x4*>(xsrc[p] + blk__ * 64);                                 \
+        R[p] = *reinterpret_cast<const lvl_u32x4*>(xsrc[p] + (blk__ * KG + kg) * 64);                 \
     _Pragma("unroll") for (int p = 0; p < WP; ++p)                                                    \
-        R[XP + p] = *reinterpret_cast<const lvl_u32x4*>(wsrc[p] + blk__ * 64);                            \
+        R[XP + p] = *reinterpret_cast<const lvl_u32x4*>(wsrc[p] + (blk__ * KG + kg) * 64);            \
   } while (0)
 #define SK_STASH(R, STG)                                                                              \
   do {                                                                                                \
-    unsigned char* base__ = sk_smem + (STG) * STAGE;                                                  \
+    unsigned char* base__ = stage_base + (STG) * STAGE;                                               \
     _Pragma("unroll") for (int p = 0; p < XP; ++p) *reinterpret_cast<lvl_u32x4*>(base__ + xdst[p]) = R[p]; \
     _Pragma("unroll") for (int p = 0; p < WP; ++p)                                                    \
-        *reinterpret_cast<lvl_u32x4*>(base__ + wdst[p]) = R[XP + p];                                      \
+        *reinterpret_cast<lvl_u32x4*>(base__ + wdst[p]) = R[XP + p];                                  \
   } while (0)
   auto compute = [&](int stage) {
-    const unsigned char* xs = sk_smem + stage * STAGE;
+    const unsigned char* xs = stage_base + stage * STAGE;
     const unsigned char* ws = xs + TM * 128;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -450,29 +457,44 @@ __global__ __launch_bounds__(64 * WM * WN) void mid_kernel(const uint16_t* __res
   // prologue: DEPTH blocks requested, the first one staged. Every fetch and stash below is UNCONDITIONAL (block indices
   // are clamped to the last block, whose redundant copies nobody reads): the loads of a thread then retire in a fixed
   // order and the compiler's counted vmcnt waits let DEPTH - 1 blocks stay in flight behind the one being stashed.
-  const int last = nblk - 1;
+  const int last = nblk > 0 ? nblk - 1 : 0;                    // (a group without blocks re-reads block 0 and never computes)
   auto clampb = [&](int b) { return b < last ? b : last; };
-  SK_FETCH(ra, 0);
-  SK_FETCH(rb_, clampb(1));
-  SK_FETCH(rc, clampb(2));
-  SK_STASH(ra, 0);
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) SK_FETCH(ring[d], clampb(d));
+  SK_STASH(ring[0], 0);
   __syncthreads();
-  for (int k = 0; k < nblk; k += 3) {
-    SK_FETCH(ra, clampb(k + 3));                           // ra went to LDS one step ago
-    compute(k & 1);
-    SK_STASH(rb_, (k + 1) & 1);
-    __syncthreads();
-    SK_FETCH(rb_, clampb(k + 4));
-    if (k + 1 < nblk) compute((k + 1) & 1);
-    SK_STASH(rc, (k + 2) & 1);
-    __syncthreads();
-    SK_FETCH(rc, clampb(k + 5));
-    if (k + 2 < nblk) compute((k + 2) & 1);
-    SK_STASH(ra, (k + 3) & 1);
-    __syncthreads();
+  for (int k0 = 0; k0 < nloop; k0 += DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {                      // d is a compile-time constant after unrolling
+      const int k = k0 + d;
+      SK_FETCH(ring[d], clampb(k + DEPTH));                // set d went to LDS one step ago
+      if (k < nblk) compute(k & 1);
+      SK_STASH(ring[(d + 1) % DEPTH], (k + 1) & 1);
+      __syncthreads();
+    }
   }
 #undef SK_FETCH
 #undef SK_STASH
+  if (KG > 1) {                                               // the last barrier of the loop freed the stages
+    sk_f32x4 (*part)[NB * RB][64] = reinterpret_cast<sk_f32x4 (*)[NB * RB][64]>(sk_smem);   // [(kg-1)*waves + wave][block][lane]
+    if (kg > 0) {
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) part[(kg - 1) * (WM * WN) + wave][nb * RB + rb][lane] = acc[nb][rb];
+    }
+    __syncthreads();
+    if (kg > 0) return;
+#pragma unroll
+    for (int q = 1; q < KG; ++q)
+#pragma unroll
+      for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+          const sk_f32x4 t = part[(q - 1) * (WM * WN) + wave][nb * RB + rb][lane];
+          acc[nb][rb][0] += t[0]; acc[nb][rb][1] += t[1]; acc[nb][rb][2] += t[2]; acc[nb][rb][3] += t[3];
+        }
+  }
 #pragma unroll
   for (int nb = 0; nb < NB; ++nb) {
 #pragma unroll
@@ -492,18 +514,20 @@ __global__ __launch_bounds__(64 * WM * WN) void mid_kernel(const uint16_t* __res
   }
 }
 
-template <int WM, int WN, int RB, int NB, int DEPTH>
+template <int WM, int WN, int RB, int NB, int DEPTH, int KG = 1>
 int launch_mid(const void* x, const void* w, const float* bias, void* y, int M, int N, int K, int act, hipStream_t st) {
   constexpr int TM = 16 * RB * WM, TN = 16 * NB * WN;
   const int tiles_n = (N + TN - 1) / TN, tiles_m = (M + TM - 1) / TM;
   const dim3 grid((unsigned)(tiles_n * tiles_m));
-  constexpr size_t lds = (size_t)2 * (TM + TN) * 128;
+  constexpr size_t stages = (size_t)KG * 2 * (TM + TN) * 128;
+  constexpr size_t parts = (size_t)(KG - 1) * WM * WN * NB * RB * 64 * sizeof(sk_f32x4);
+  constexpr size_t lds = stages > parts ? stages : parts;
 #define LVL_MK(A)                                                                                                   \
   do {                                                                                                              \
     if (lds > 64 * 1024)                                                                                            \
-      if (int rc = lvl_allow_lds<mid_kernel<WM, WN, RB, NB, A, DEPTH>>()) return rc;                                \
-    hipLaunchKernelGGL((mid_kernel<WM, WN, RB, NB, A, DEPTH>), grid, dim3(64 * WM * WN), lds, st, (const uint16_t*)x, \
-                       (const uint16_t*)w, bias, (uint16_t*)y, M, N, K, tiles_n);                                   \
+      if (int rc = lvl_allow_lds<mid_kernel<WM, WN, RB, NB, A, DEPTH, KG>>()) return rc;                            \
+    hipLaunchKernelGGL((mid_kernel<WM, WN, RB, NB, A, DEPTH, KG>), grid, dim3(64 * WM * WN * KG), lds, st,          \
+                       (const uint16_t*)x, (const uint16_t*)w, bias, (uint16_t*)y, M, N, K, tiles_n);               \
   } while (0)
   if (act == LVL_ACT_GELU_NEW) LVL_MK(LVL_ACT_GELU_NEW);
   else if (act == LVL_ACT_SQRELU) LVL_MK(LVL_ACT_SQRELU);
@@ -547,11 +571,11 @@ extern "C" int lvl_linear_skinny(const void* x, const void* w, const float* bias
     case 11: if (N % 64 == 0) return launch_skinny<4, 4, false, 4>(x, w, bias, y, M, N, K, act, st); break;
     case 12: if (N % 64 == 0) return launch_skinny<4, 4, true, 4>(x, w, bias, y, M, N, K, act, st); break;
     case 13: if (N % 32 == 0) return launch_skinny<2, 4, false, 4>(x, w, bias, y, M, N, K, act, st); break;
-    case 14: if (K % 64 == 0) return launch_mid<2, 4, 4, 2, 3>(x, w, bias, y, M, N, K, act, st); break;   // 128 x 128, 3 blocks ahead
+    case 14: if (K % 64 == 0) return launch_mid<2, 4, 2, 2, 5>(x, w, bias, y, M, N, K, act, st); break;   // 64 x 128, 5 blocks in flight
     case 15: if (K % 64 == 0) return launch_mid<2, 4, 2, 2, 3>(x, w, bias, y, M, N, K, act, st); break;   // 64 x 128 (8 waves)
     case 16: if (K % 64 == 0) return launch_mid<2, 2, 2, 2, 3>(x, w, bias, y, M, N, K, act, st); break;   // 64 x 64 (4 waves)
-    case 17: if (K % 64 == 0) return launch_mid<4, 2, 2, 2, 3>(x, w, bias, y, M, N, K, act, st); break;   // 128 x 64 (8 waves)
-    case 18: if (K % 64 == 0) return launch_mid<2, 2, 4, 4, 3>(x, w, bias, y, M, N, K, act, st); break;   // 128 x 128 on 4 waves
+    case 17: if (K % 64 == 0) return launch_mid<2, 2, 2, 2, 6>(x, w, bias, y, M, N, K, act, st); break;   // 64 x 64, 6 blocks in flight
+    case 18: if (K % 64 == 0) return launch_mid<2, 2, 2, 2, 3, 2>(x, w, bias, y, M, N, K, act, st); break;   // 64 x 64, two K groups
     default: break;
   }
   if (K % 64 == 0) {
@@ -559,9 +583,12 @@ extern "C" int lvl_linear_skinny(const void* x, const void* w, const float* bias
     // lm_head [50432 x 768] at <= 128 rows 17.3 us (strips 40.6, the 256-column-panel kernel 31.6, library 16.3); beyond
     // 128 rows [3072 x 768] 8.6 us (strips 16.8, library 8.3), [2304 x 768] 8.3 (16.5, 8.0), [768 x 3072] 16.8 (19.3, 12.1)
     if (N >= 8192 && M <= 128) return launch_mid<2, 4, 2, 2, 3>(x, w, bias, y, M, N, K, act, st);       // 64 x 128 tiles
-    if (M > 128)
-      return N >= 2048 ? launch_mid<2, 4, 2, 2, 3>(x, w, bias, y, M, N, K, act, st)                     // 64 x 128
-                       : launch_mid<2, 2, 2, 2, 3>(x, w, bias, y, M, N, K, act, st);                    // 64 x 64
+    if (M > 128) {
+      if (N >= 2048) return launch_mid<2, 4, 2, 2, 3>(x, w, bias, y, M, N, K, act, st);                 // 64 x 128
+      // narrow matrices: 64 x 64 tiles; long contractions on two K groups per tile (16.2 vs 18.5 us for [768 x 3072])
+      return K >= 2048 ? launch_mid<2, 2, 2, 2, 3, 2>(x, w, bias, y, M, N, K, act, st)
+                       : launch_mid<2, 2, 2, 2, 3>(x, w, bias, y, M, N, K, act, st);
+    }
   }
   if (M > 128) {
     // wide matrices: 64 x 64 outputs with 3 k-steps in flight (199 VGPRs) -- 16.6 vs 23.3 us for [3072 x 768] at 640 rows

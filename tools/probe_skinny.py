@@ -1,7 +1,7 @@
 """Times lvl_linear_skinny's tilings (lvl_debug_skinny_variant) on the decoder's Conv1D shapes, next to lvl_linear_tn and
 the library GEMM: python tools/probe_skinny.py [--out file]. Variants (rows x columns per workgroup): 0 shipped; 1 32x32 paired k-steps; 2 64x32; 3 64x64; 4 64x32 paired; 5 16x32
 paired; 6 16x16 paired; 7 32x64; 8 32x32; 9 16x16; 10 / 11 64x64 with 3 / 4 k-steps ahead; 12 the same paired; 13 64x32 with 4; 14-18 the LDS-staged
-kernel: 128x128 with 3 / 4 K blocks in flight, 64x64 with 3 / 4, 128x128 on 4 waves."""
+kernel: 128x128, 64x128, 64x64, 128x64 tiles; 18 = 64x64 with two K groups."""
 import argparse
 import json
 import os
@@ -77,7 +77,7 @@ def main():
         def shipped():
             C.check(C.lib().lvl_linear_skinny(C.ptr(x), C.ptr(w), C.ptr(b), C.ptr(y), M, N, K, -1, C.stream_ptr()), 'skinny')
         row['in_graph_skinny_v0'] = round(graph_timed(shipped), 2)
-        for v in (14, 15, 16, 17):
+        for v in (14, 15, 16, 17, 18):
             C.lib().lvl_debug_skinny_variant(v)
             row[f'in_graph_skinny_v{v}'] = round(graph_timed(shipped), 2)
         C.lib().lvl_debug_skinny_variant(0)
