@@ -119,7 +119,8 @@ __global__ __launch_bounds__(256) void act_inplace_kernel(T* __restrict__ u, int
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       if (ACT == LVL_ACT_GELU_NEW) {
-        const float t = tanhf(0.7978845608028654f * (x[k] + 0.044715f * x[k] * x[k] * x[k]));
+        const float z = 0.7978845608028654f * (x[k] + 0.044715f * x[k] * x[k] * x[k]);
+        const float t = 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * z) + 1.f);      // tanh(z), see gemm_skinny.hip
         x[k] = 0.5f * x[k] * (1.f + t);
       } else {
         const float t = fmaxf(x[k], 0.f);
