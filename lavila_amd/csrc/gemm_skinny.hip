@@ -579,18 +579,22 @@ extern "C" int lvl_linear_skinny(const void* x, const void* w, const float* bias
     case 16: if (K % 64 == 0) return launch_mid<2, 2, 2, 2, 3>(x, w, bias, y, M, N, K, act, st); break;   // 64 x 64 (4 waves)
     case 17: if (K % 64 == 0) return launch_mid<2, 2, 2, 2, 6>(x, w, bias, y, M, N, K, act, st); break;   // 64 x 64, 6 blocks in flight
     case 18: if (K % 64 == 0) return launch_mid<2, 2, 2, 2, 3, 2>(x, w, bias, y, M, N, K, act, st); break;   // 64 x 64, two K groups
+    case 19: if (K % 64 == 0) return launch_mid<2, 2, 1, 2, 3, 1>(x, w, bias, y, M, N, K, act, st); break;   // 32 x 64
+    case 20: if (K % 128 == 0) return launch_mid<2, 2, 1, 2, 3, 2>(x, w, bias, y, M, N, K, act, st); break;  // 32 x 64, two K groups
+    case 21: if (K % 128 == 0) return launch_mid<2, 2, 2, 1, 3, 2>(x, w, bias, y, M, N, K, act, st); break;  // 64 x 32, two K groups
     default: break;
   }
   if (K % 64 == 0) {
     // the LDS-staged kernel where whole-line loads and operand reuse decide (in-graph times, profiles/r03_skinny_variants.json):
     // lm_head [50432 x 768] at <= 128 rows 17.3 us (strips 40.6, the 256-column-panel kernel 31.6, library 16.3); beyond
-    // 128 rows [3072 x 768] 8.6 us (strips 16.8, library 8.3), [2304 x 768] 8.3 (16.5, 8.0), [768 x 3072] 16.8 (19.3, 12.1)
+    // 128 rows [3072 x 768] 8.6 us (strips 16.8, library 8.3), [2304 x 768] 8.3 (16.5, 8.0), [768 x 3072] 12.3 (19.3, 11.8)
     if (N >= 8192 && M <= 128) return launch_mid<2, 4, 2, 2, 3>(x, w, bias, y, M, N, K, act, st);       // 64 x 128 tiles
     if (M > 128) {
       if (N >= 2048) return launch_mid<2, 4, 2, 2, 3>(x, w, bias, y, M, N, K, act, st);                 // 64 x 128
-      // narrow matrices: 64 x 64 tiles; long contractions on two K groups per tile (16.2 vs 18.5 us for [768 x 3072])
-      return K >= 2048 ? launch_mid<2, 2, 2, 2, 3, 2>(x, w, bias, y, M, N, K, act, st)
-                       : launch_mid<2, 2, 2, 2, 3>(x, w, bias, y, M, N, K, act, st);
+      // narrow matrices: 32 x 64 tiles (240 workgroups for [640 x 768]), two K groups per tile: 5.3 us for [768 x 768]
+      // (64 x 64 tiles 6.9, library 5.7), 12.3 us for [768 x 3072] (18.5 / 11.8)
+      return K % 128 == 0 ? launch_mid<2, 2, 1, 2, 3, 2>(x, w, bias, y, M, N, K, act, st)
+                          : launch_mid<2, 2, 1, 2, 3>(x, w, bias, y, M, N, K, act, st);
     }
   }
   if (M > 128) {

@@ -127,7 +127,8 @@ def test_cross_attention_rows(dt, contexts, qrep, H, T):
 @pytest.mark.parametrize('act', [None, 'gelu_new', 'sqrelu'])
 @pytest.mark.parametrize('M,N,K', [(1, 768, 768), (7, 2304, 768), (64, 768, 3072), (65, 192, 192), (200, 1600, 1600),
                                    (16, 48, 32), (64, 50432, 768), (130, 3072, 768), (150, 48, 64), (640, 768, 3072),
-                                   (129, 2304, 768), (150, 64, 96), (333, 1600, 1600), (131, 128, 64)])
+                                   (129, 2304, 768), (150, 64, 96), (333, 1600, 1600), (131, 128, 64), (150, 96, 128),
+                                   (257, 768, 768)])
 def test_skinny_gemm(M, N, K, act):
     """lvl_linear_skinny against the f32 product of the same bf16 operands: one bf16 rounding of the result (2^-9
     relative) plus f32 accumulation-order noise; every row / column / k-step remainder of the 16- and 32-row blocks, 16-

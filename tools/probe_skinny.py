@@ -1,7 +1,8 @@
 """Times lvl_linear_skinny's tilings (lvl_debug_skinny_variant) on the decoder's Conv1D shapes, next to lvl_linear_tn and
 the library GEMM: python tools/probe_skinny.py [--out file]. Variants (rows x columns per workgroup): 0 shipped; 1 32x32 paired k-steps; 2 64x32; 3 64x64; 4 64x32 paired; 5 16x32
 paired; 6 16x16 paired; 7 32x64; 8 32x32; 9 16x16; 10 / 11 64x64 with 3 / 4 k-steps ahead; 12 the same paired; 13 64x32 with 4; 14-18 the LDS-staged
-kernel: 128x128, 64x128, 64x64, 128x64 tiles; 18 = 64x64 with two K groups."""
+kernel: 128x128, 64x128, 64x64, 128x64 tiles; 18 = 64x64 with two K groups; 19-21 = 32x64, 32x64 with two K groups,
+64x32 with two K groups."""
 import argparse
 import json
 import os
@@ -60,7 +61,7 @@ def main():
         y = torch.empty(M, N, dtype=torch.bfloat16, device='cuda')
         want = (x.float() @ w.float().t() + b)
         row = {}
-        for v in range(19):
+        for v in range(22):
             C.lib().lvl_debug_skinny_variant(v)
 
             def run():
@@ -77,7 +78,7 @@ def main():
         def shipped():
             C.check(C.lib().lvl_linear_skinny(C.ptr(x), C.ptr(w), C.ptr(b), C.ptr(y), M, N, K, -1, C.stream_ptr()), 'skinny')
         row['in_graph_skinny_v0'] = round(graph_timed(shipped), 2)
-        for v in (14, 15, 16, 17, 18):
+        for v in (15, 16, 18, 19, 20, 21):
             C.lib().lvl_debug_skinny_variant(v)
             row[f'in_graph_skinny_v{v}'] = round(graph_timed(shipped), 2)
         C.lib().lvl_debug_skinny_variant(0)
