@@ -240,12 +240,7 @@ class _Pack:
 
     # ---- primitives --------------------------------------------------------------------------------
     def _skinny(self, x2, w, b, act):
-        M, K = x2.shape
-        y = torch.empty(M, w.shape[0], dtype=torch.bfloat16, device=x2.device)
-        C.require_device(x2, w, b)
-        C.check(C.lib().lvl_linear_skinny(C.ptr(x2), C.ptr(w), C.ptr(b), C.ptr(y), M, w.shape[0], K,
-                                          -1 if act is None else act, C.stream_ptr()), 'lvl_linear_skinny')
-        return y
+        return ops.linear_skinny_raw(x2, w, b, act)
 
     def gemm(self, x2, entry, act=None):
         """Conv1D (+ activation). bf16: few rows (decoding) -> lvl_linear_skinny with the activation in its epilogue;

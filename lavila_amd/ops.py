@@ -347,10 +347,32 @@ def linear_tn_raw(x, w, bias=None, epilogue=C.EPI_BIAS, aux_in=None):
     return y
 
 
+def linear_skinny_raw(x, w, bias=None, act=None):
+    """One lvl_linear_skinny call on bf16 tensors: y[M,N] = act(x[M,K] . w[N,K]^T + bias) -- few rows: strips, many rows
+    or 50432 columns: LDS-staged tiles (gemm_skinny.hip). act: None, C.ACT_GELU_NEW or C.ACT_SQRELU."""
+    C.require_device(x, w, bias)
+    M, K = x.shape
+    y = torch.empty(M, w.shape[0], dtype=torch.bfloat16, device=x.device)
+    C.check(C.lib().lvl_linear_skinny(C.ptr(x), C.ptr(w), C.ptr(bias), C.ptr(y), M, w.shape[0], K,
+                                      -1 if act is None else act, C.stream_ptr()), 'lvl_linear_skinny')
+    return y
+
+
 def linear(x, weight, bias=None):
     """nn.Linear forward with hand-written forward / input-gradient / weight-gradient GEMMs behind it.
     Activation dtype = x.dtype (the autocast dtype when autocast is on; fp16 -> bf16); parameters stay masters."""
-    return _LinearFn.apply(_act(x), weight, bias)
+    x = _act(x)
+    if x.dtype == torch.bfloat16 and x.is_cuda and not (torch.is_grad_enabled() and (
+            x.requires_grad or weight.requires_grad or (bias is not None and bias.requires_grad))):
+        # inference, widths the 256-column-panel kernel does not tile (the narrator's pooling projection to_kv
+        # [128 x 768], coca.py:78): the strip / LDS-tile kernel of the decoder (lvl_linear_skinny) instead of the library
+        rows, n_in, n_out = x.numel() // x.shape[-1], x.shape[-1], weight.shape[0]
+        if (rows > 0 and not _tn_ok(rows, n_out, n_in) and n_out % 16 == 0 and n_in % 64 == 0
+                and rows * max(n_in, n_out) * 2 < (1 << 31)):
+            x2 = x.reshape(-1, n_in)
+            return linear_skinny_raw(x2 if x2.is_contiguous() else x2.contiguous(), weight_copies(weight)[0],
+                                     _f32(bias)).reshape(*x.shape[:-1], n_out)
+    return _LinearFn.apply(x, weight, bias)
 
 
 # --------------------------------------------------------------------------------------------------

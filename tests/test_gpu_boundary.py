@@ -271,6 +271,24 @@ def _narrator(fx):
     return m.to(DEV).eval(), c
 
 
+def test_narrator_encode_image_has_no_library_gemm_in_bf16(monkeypatch):
+    """The pooling projections of VCLM_HF.encode_image (to_q / to_kv / to_out, coca.py:76-82) at the real widths: to_kv is
+    [128 x 768], which the 256-column-panel kernel does not tile -- under no_grad it runs on lvl_linear_skinny's tiles."""
+    import torch.nn.functional as F
+    from lavila_amd.narrator import CrossAttention
+    pool = CrossAttention(dim=768, context_dim=768, dim_head=64, heads=12, norm_context=True).to(DEV).eval()
+    g = torch.Generator().manual_seed(0)
+    queries = torch.randn(256, 768, generator=g).to(DEV)
+    ctx = torch.randn(8, 785, 768, generator=g).to(DEV)
+    with torch.no_grad():
+        want = pool(queries, ctx)                                           # f32: library GEMMs
+        monkeypatch.setattr(F, 'linear', lambda *a, **k: (_ for _ in ()).throw(AssertionError('library GEMM')))
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            got = pool(queries, ctx)
+    assert got.dtype == torch.bfloat16
+    assert _rel(got, want.cpu()) < 2e-2
+
+
 @pytest.mark.parametrize('mode', ['f32', 'bf16', 'half'])
 def test_narrator_encode_image_matches_reference(mode):
     """narrator.py:63-90 on the reference's own outputs (tests/golden/narrator_pool.pt): float32 within 1e-3, bf16
