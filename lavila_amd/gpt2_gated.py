@@ -26,6 +26,7 @@ arguments, pruning, model parallelism, the other heads) raises NotImplementedErr
 calling it with gradients enabled on parameters that require them raises.
 """
 import copy
+import os
 import types
 
 import torch
@@ -36,8 +37,10 @@ from . import _cabi as C
 from . import ops
 
 # rows up to which a Conv1D goes to lvl_linear_skinny (one workgroup per 16/32 weight columns) instead of the
-# 256x256-tile kernel: a decode step of 64 captions measured 32 us per GEMM on the latter (one CU per 256-column panel)
-SKINNY_MAX_ROWS = 1024
+# 256x256-tile kernel: a decode step of 64 captions measured 32 us per GEMM on the latter (one CU per 256-column panel);
+# the upper end is measured on the teacher-forced pass (rows = captions x positions): the reference's recompute schedule for
+# 64 captions x 77 tokens takes 479 / 432 / 345 / 410 ms with the limit at 1024 / 2048 / 8192 / 65536 rows
+SKINNY_MAX_ROWS = int(os.environ.get('LAVILA_SKINNY_MAX_ROWS', '8192'))
 # rows up to which the residual add + LayerNorm in front of a Conv1D is folded into that GEMM (lvl_linear_skinny_ln)
 FUSED_LN_MAX_ROWS = 128
 
