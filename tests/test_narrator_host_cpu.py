@@ -161,3 +161,27 @@ def test_vclm_constructors_and_cpu_is_loud():
         dec(torch.zeros(1, 3, dtype=torch.long))
     with pytest.raises(NotImplementedError):
         m.group_beam_search()
+
+
+@pytest.mark.parametrize('top_k,top_p,temperature', [(None, 0.95, 0.7), (50, None, 1.0), (40, 0.9, 0.8), (None, None, 1.3),
+                                                     (1, None, 1.0), (5, 0.3, 2.0), (None, 0.999, 1.0)])
+def test_warp_equals_transformers_logits_warpers(top_k, top_p, temperature):
+    """VCLM_HF._warp restates the warper list narrator.py:368-389 builds for num_beams=1; checked here against
+    transformers' own TemperatureLogitsWarper / TopKLogitsWarper / TopPLogitsWarper (the classes the reference imports,
+    narrator.py:17-24): same kept set, same values."""
+    lp = pytest.importorskip('transformers.generation.logits_process')
+    from lavila_amd.narrator import VCLM_HF
+    g = torch.Generator().manual_seed(17)
+    logits = 3 * torch.randn(6, 997, generator=g)
+    warpers = lp.LogitsProcessorList()
+    if temperature is not None and temperature != 1.0:
+        warpers.append(lp.TemperatureLogitsWarper(temperature))
+    if top_k:
+        warpers.append(lp.TopKLogitsWarper(top_k=top_k, min_tokens_to_keep=1))
+    if top_p is not None and top_p < 1.0:
+        warpers.append(lp.TopPLogitsWarper(top_p=top_p, min_tokens_to_keep=1))
+    want = warpers(torch.zeros(6, 1, dtype=torch.long), logits.clone())
+    got = VCLM_HF._warp(logits.clone(), top_k, top_p, temperature)
+    assert torch.equal(torch.isfinite(got), torch.isfinite(want))
+    keep = torch.isfinite(want)
+    torch.testing.assert_close(got[keep], want[keep], atol=0, rtol=1e-6)
