@@ -1,7 +1,7 @@
 // y[M,N] = act(x[M,K] . w[N,K]^T + bias) for FEW rows (decoding: M = captions in flight), bf16 operands, gfx950.
 //
 // The persistent 256x256-tile GEMM (gemm_tn_mfma.hip) hands a whole 256-column weight panel to ONE compute unit: at
-// M = 64 a GPT-2 Conv1D then costs ~32 us however small it is (measured, profiles/r03_narrator_decode.txt) -- one CU
+// M = 64 a GPT-2 Conv1D then costs 16-50 us however small it is (measured, profiles/r03_skinny_variants.json) -- one CU
 // streams 0.4..1.5 MB of weights alone while 250 CUs idle. A decode step is ~100 such GEMMs. Here the work is cut into
 // (16 rows) x (16 or 32 columns) outputs, one workgroup each, so that hundreds of compute units pull 50..200 KB each:
 //   * the 8 waves of a workgroup split the CONTRACTION: wave w takes the 32-wide k-steps w, w+8, w+16, ... (adjacent
@@ -12,9 +12,9 @@
 //   * fragments go straight from memory to registers (16-byte loads, up to 6 k-steps in flight per wave before the first
 //     MFMA). The first version of this kernel gave a workgroup all 64 rows of a strip: 0.5 MB through one CU's
 //     texture path, 15 us per GEMM; 16 rows per workgroup cut that to the weights' share;
-//   * beyond 128 rows a workgroup takes 64 rows x 32 columns, wide matrices (N >= 2048) 32 rows x 64 columns: more reuse
-//     of every fragment while there are still hundreds of workgroups (the choice per shape is measured, see the
-//     dispatch at the bottom); a wave's k-steps come in PAIRS where that wins (both 64-byte halves of a 128-byte line);
+//   * wide matrices (N >= 2048) take 32 rows x 64 columns per workgroup: more reuse of every fragment while there are
+//     still hundreds of workgroups (the choice per shape is measured, see the dispatch at the bottom); a wave's k-steps
+//     come in PAIRS where that wins (both 64-byte halves of a 128-byte line);
 //   * the 16-row blocks of one column strip re-read the strip's weights: the workgroup id is laid out so that they
 //     run on the SAME XCD (id % 8) within 8 * row-blocks consecutive ids -- the re-reads hit that XCD's L2;
 //   * epilogue: + bias, optional gelu_new / relu^2 (the two MLP activations of the gated GPT-2, gpt2_gated.py:363-396),
@@ -359,13 +359,15 @@ int launch_skinny_ln(const void* res, const void* w, const float* bias, void* ou
   return LVL_OK;
 }
 
-// ---- many rows (128 < M <= ~1024: 64 clips x 10 sampled captions): operands through LDS -----------------------------------
+// ---- many rows (M > 128: 64 clips x 10 sampled captions, teacher-forced captions up to 8192 rows): operands through LDS ----
 // The strip kernel's fragments come straight from memory: a wave instruction touches 16 rows x 64 bytes -- 16 half-used
 // cache lines -- and a compute unit sustains only ~30 GB/s that way (measured: 17-19 us for the 640-row Conv1Ds where the
-// library GEMM takes 8-12). With hundreds of rows the classic form pays: a workgroup tile of (32 WM) x (32 WN) outputs... 
-// here TMxTN = 128x128 (8 waves, 64x32 each) or 64x64 (4 waves, 32x32 each), K walked in blocks of 64:
-//   * global -> registers with 8 lanes per 128-byte row (whole cache lines), DEPTH blocks in flight per thread, then one
-//     ds_write_b128 per piece into a double-buffered LDS tile whose 16-byte chunks are XOR-swizzled by the row;
+// library GEMM takes 8-12). With hundreds of rows the classic form pays: a workgroup tile of 16 RB WM x 16 NB WN outputs
+// -- 64 x 128 (8 waves of 32 x 32) for wide matrices, 32 x 64 (4 waves of 16 x 32, two K groups) for narrow ones -- with K
+// walked in blocks of 64:
+//   * global -> registers with 8 lanes per 128-byte row (whole cache lines), DEPTH blocks in flight per thread (the
+//     compiler's counted vmcnt waits keep DEPTH - 1 behind the one being written), then one ds_write_b128 per piece into
+//     a double-buffered LDS tile whose 16-byte chunks are XOR-swizzled by the row;
 //   * ds_read_b128 fragments in the MFMA layout (weights = operand A, rows of x = operand B, as everywhere in this file),
 //     one barrier per K block; every wave owns its sub-tile for the whole K, so there is no cross-wave reduction;
 //   * epilogue: + bias, gelu_new / relu^2, 8-byte bf16 stores.
