@@ -169,7 +169,9 @@ __global__ __launch_bounds__(ST) void sample_kernel(const uint16_t* __restrict__
   tick[2] = wall_clock64();
   // ---- 2. top-k: the k-th largest key -----------------------------------------------------------------------------------
   uint32_t kth = 1;                                                        // keep every real entry (padding has key 0)
-  if (top_k > 0 && top_k < V) {
+  if (top_k == 1) {
+    kth = kmax > 1 ? kmax : 1;                                            // greedy: the maximum (and its ties) is all that stays
+  } else if (top_k > 0 && top_k < V) {
     for (int i = tid; i < L1B; i += ST) hcnt[i] = 0;
     __syncthreads();
     for (int i = tid; i < V; i += ST) atomicAdd(&hcnt[keys[i] >> 5], 1u);
