@@ -263,6 +263,7 @@ int lvl_debug_cross_attn_waves(int waves);
  *   next_token[r] ~ softmax(warp(l_r)): l / temperature; keep the top_k largest (0 = off; ties with the k-th stay);
  *                drop the ascending-probability tail whose cumulative mass is <= 1 - top_p (1 = off), always keeping
  *                the largest; inverse CDF over the kept entries in index order at uniform[r] (in [0,1), e.g. torch.rand).
+ *                top_k = 1 is greedy: the first maximum, whatever the uniform.
  * logits: [rows, >= vocab] bf16, row stride row_stride elements (a multiple of 8, rows 16-byte aligned, >= vocab rounded
  * up to 8: the padded product the lm_head GEMM leaves). vocab <= lvl_sample_max_vocab() (the row must fit 160 KB of
  * LDS; GPT-2's 50257 does), else LVL_ENOSYS. target / dbg nullable; dbg [rows,12] f32 = (lowest kept value, ties dropped

@@ -374,7 +374,7 @@ int launch_skinny_ln(const void* res, const void* w, const float* bias, void* ou
 template <int WM, int WN, int RB, int NB, int ACT, int DEPTH, int KG = 1>
 __global__ __launch_bounds__(64 * WM * WN * KG) void mid_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w,
                                                            const float* __restrict__ bias, uint16_t* __restrict__ y, int M,
-                                                           int N, int K, int tiles_n) {
+                                                           int N, int K, int tiles_n, int tiles_m) {
   // KG = 2: two groups of WM x WN waves work on the SAME output tile, group q on the K blocks q, q + 2, ... with its own
   // LDS stages (a [768 x 3072] Conv1D at 640 rows is 120 tiles of 48 blocks: the chain, not the chip, is the limit);
   // their accumulators meet in LDS at the end.
@@ -388,7 +388,13 @@ __global__ __launch_bounds__(64 * WM * WN * KG) void mid_kernel(const uint16_t* 
   const int kg = wave_all / (WM * WN), wave = wave_all % (WM * WN), tid = threadIdx.x - kg * NT;
   const int c = lane & 15, g = lane >> 4;
   const int wm = wave / WN, wn = wave % WN;
-  const int tn = blockIdx.x % tiles_n, tm = blockIdx.x / tiles_n;
+  // Workgroup i runs on XCD i % 8: each XCD takes a CONTIGUOUS range of the column-major tile order, so the row tiles
+  // that share a weight panel sit behind one L2 and the weights cross the fabric about once, not once per XCD (PMC,
+  // profiles/r03_narrator_traffic_n10.json: 22 MB per launch where 8-10 are algorithmic with the round-robin order).
+  const int ntiles = tiles_n * tiles_m, per_xcd = (ntiles + 7) >> 3;
+  const int lin = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if (lin >= ntiles) return;                                   // uniform; the grid is 8 * per_xcd
+  const int tn = lin / tiles_m, tm = lin - tn * tiles_m;
   const int m0 = tm * TM, n0 = tn * TN;
   // global sources of this thread's pieces: piece p -> tile row (p * NT + tid) / 8, 16-byte chunk tid % 8
   const uint16_t* xsrc[XP];
@@ -523,7 +529,7 @@ template <int WM, int WN, int RB, int NB, int DEPTH, int KG = 1>
 int launch_mid(const void* x, const void* w, const float* bias, void* y, int M, int N, int K, int act, hipStream_t st) {
   constexpr int TM = 16 * RB * WM, TN = 16 * NB * WN;
   const int tiles_n = (N + TN - 1) / TN, tiles_m = (M + TM - 1) / TM;
-  const dim3 grid((unsigned)(tiles_n * tiles_m));
+  const dim3 grid((unsigned)(((tiles_n * tiles_m + 7) / 8) * 8));
   constexpr size_t stages = (size_t)KG * 2 * (TM + TN) * 128;
   constexpr size_t parts = (size_t)(KG - 1) * WM * WN * NB * RB * 64 * sizeof(sk_f32x4);
   constexpr size_t lds = stages > parts ? stages : parts;
@@ -532,7 +538,7 @@ int launch_mid(const void* x, const void* w, const float* bias, void* y, int M, 
     if (lds > 64 * 1024)                                                                                            \
       if (int rc = lvl_allow_lds<mid_kernel<WM, WN, RB, NB, A, DEPTH, KG>>()) return rc;                            \
     hipLaunchKernelGGL((mid_kernel<WM, WN, RB, NB, A, DEPTH, KG>), grid, dim3(64 * WM * WN * KG), lds, st,          \
-                       (const uint16_t*)x, (const uint16_t*)w, bias, (uint16_t*)y, M, N, K, tiles_n);               \
+                       (const uint16_t*)x, (const uint16_t*)w, bias, (uint16_t*)y, M, N, K, tiles_n, tiles_m);      \
   } while (0)
   if (act == LVL_ACT_GELU_NEW) LVL_MK(LVL_ACT_GELU_NEW);
   else if (act == LVL_ACT_SQRELU) LVL_MK(LVL_ACT_SQRELU);

@@ -283,7 +283,8 @@ __global__ __launch_bounds__(ST) void sample_kernel(const uint16_t* __restrict__
   const float want = uniform[row] * zk;
   if (tid == 0) sc.ubcast[3] = 0xffffffffu;
   __syncthreads();
-  if (mass > 0.f && want >= before && want < before + mass) {
+  // top_k = 1 is greedy decoding: the FIRST maximum, like torch.argmax (entries tied with it are not drawn among)
+  if (top_k != 1 && mass > 0.f && want >= before && want < before + mass) {
     float run = before, rank = tie_before;
     int pick = -1;
     for (int i = c0; i < c1; ++i) {
@@ -302,8 +303,8 @@ __global__ __launch_bounds__(ST) void sample_kernel(const uint16_t* __restrict__
     sc.ubcast[3] = (unsigned)pick;
   }
   __syncthreads();
-  if (sc.ubcast[3] == 0xffffffffu) {                                        // uniform * zk landed on / beyond the total:
-    for (int i = c0; i < c1; ++i)                                          // take the most probable token
+  if (sc.ubcast[3] == 0xffffffffu) {                                        // greedy, or uniform * zk landed on / beyond the
+    for (int i = c0; i < c1; ++i)                                          // total: the (first) most probable token
       if (keys[i] == kmax) atomicMin(&sc.ubcast[3], (unsigned)i);
   }
   __syncthreads();

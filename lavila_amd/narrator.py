@@ -246,8 +246,11 @@ class VCLM_HF(nn.Module):
                     else:
                         nlls += torch.special.entr(F.softmax(logits, dim=1)).sum(dim=1) * (~reached)
                         num_tokens += (~reached)
-                    probs = F.softmax(self._warp(logits, top_k, top_p, temperature), dim=-1)
-                    next_token = torch.multinomial(probs, num_samples=1)
+                    if top_k == 1:                        # greedy: the first maximum (the reference's multinomial over a
+                        next_token = logits.argmax(dim=-1, keepdim=True)     # one-hot; exact ties are not drawn among)
+                    else:
+                        probs = F.softmax(self._warp(logits, top_k, top_p, temperature), dim=-1)
+                        next_token = torch.multinomial(probs, num_samples=1)
                 reached = reached | (next_token[:, 0] == eos)
                 if early_stopping and bool(torch.all(reached)):
                     break
