@@ -185,3 +185,35 @@ def test_warp_equals_transformers_logits_warpers(top_k, top_p, temperature):
     assert torch.equal(torch.isfinite(got), torch.isfinite(want))
     keep = torch.isfinite(want)
     torch.testing.assert_close(got[keep], want[keep], atol=0, rtol=1e-6)
+
+
+def test_decode_sessions_are_reused_per_shape_and_dropped_on_weight_change(monkeypatch):
+    """generate() is called once per batch by the captioning drivers: the second batch of the same shape re-binds the
+    cached session (buffers + captured graph) instead of building one; a parameter update invalidates it. Host logic only
+    (device primitives emulated)."""
+    _emulate_device_primitives(monkeypatch)
+    m, c, d, v = _model('freq1_gated')
+    dec = m.text_decoder
+    img = v['image_tokens']
+    tok = types.SimpleNamespace(bos_token_id=v['bos'], eos_token_id=-1, pad_token_id=v['pad'])
+    with torch.no_grad():
+        a = m.generate(img, tok, max_text_length=d['max_text_length'], top_k=1, graph=False)
+        first = next(iter(dec._sessions.values()))
+        b = m.generate(img.flip(0), tok, max_text_length=d['max_text_length'], top_k=1, graph=False)
+        assert len(dec._sessions) == 1 and next(iter(dec._sessions.values())) is first      # re-bound, not rebuilt
+        assert torch.equal(a[0], v['free_ids']) and torch.equal(b[0], v['free_ids'].flip(0))
+        m.generate(img[:2], tok, max_text_length=d['max_text_length'], top_k=1, graph=False)  # another shape: a second one
+        assert len(dec._sessions) == 2
+        dec.transformer.ln_f.weight.mul_(1.5)                                                # new parameter state
+        assert first.stale()
+        m.generate(img, tok, max_text_length=d['max_text_length'], top_k=1, graph=False)
+        assert all(not s.stale() for s in dec._sessions.values()) and first not in dec._sessions.values()
+
+
+def test_sample_next_token_declines_what_the_kernel_does_not_take():
+    """f32 logits (the parity configuration), CPU tensors and strided slices go to the framework ops: the fused sampler
+    says so by returning None before touching the library."""
+    from lavila_amd.narrator import sample_next_token
+    assert sample_next_token(torch.randn(3, 50), 1, None, 1.0) is None                       # f32, CPU
+    assert sample_next_token(torch.randn(3, 50).bfloat16(), 1, None, 1.0) is None            # bf16 but not on the device
+    assert sample_next_token(torch.randn(3, 4, 50).bfloat16()[:, -1], None, 0.9, 0.7) is None
