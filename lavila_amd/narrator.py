@@ -14,7 +14,8 @@ the LayerNorms through lvl_layernorm_fwd. The pooling core has no backward kerne
 num_return_sequences) but decodes against a key/value cache, one hipGraph replay per token (gpt2_gated.DecodeSession)
 -- the reference re-runs the whole prefix for every token; `kv_cache=False` runs that schedule for comparison.
 `beam_sample` / `group_beam_search` (narrator.py:149-366, built on transformers' BeamSearchScorer) are not built.
-This module is deliberately not aliased under `lavila.models.narrator`, which keeps resolving to the reference's file.
+The drop-in package re-exports this module as `lavila.models.narrator` (and `lavila_amd.gpt2_gated` as
+`lavila.models.gpt2_gated`, the two coca classes as `lavila.models.coca`).
 """
 import os
 

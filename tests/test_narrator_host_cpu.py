@@ -217,3 +217,16 @@ def test_sample_next_token_declines_what_the_kernel_does_not_take():
     assert sample_next_token(torch.randn(3, 50), 1, None, 1.0) is None                       # f32, CPU
     assert sample_next_token(torch.randn(3, 50).bfloat16(), 1, None, 1.0) is None            # bf16 but not on the device
     assert sample_next_token(torch.randn(3, 4, 50).bfloat16()[:, -1], None, 0.9, 0.7) is None
+
+
+def test_narrator_modules_resolve_under_the_reference_import_paths():
+    """`from lavila.models.narrator import VCLM_HF`, `lavila.models.gpt2_gated`, `lavila.models.coca` (models.py:15-17,
+    narrator.py:26) give the MI355X-native classes."""
+    import lavila.models.coca as coca
+    import lavila.models.gpt2_gated as g
+    import lavila.models.narrator as n
+    import lavila_amd.gpt2_gated
+    import lavila_amd.narrator
+    assert n.VCLM_HF is lavila_amd.narrator.VCLM_HF
+    assert g.GPT2LMHeadModel is lavila_amd.gpt2_gated.GPT2LMHeadModel and callable(g.augment_gpt2_config)
+    assert coca.CrossAttention is lavila_amd.narrator.CrossAttention and coca.LayerNorm is lavila_amd.narrator.LayerNorm
