@@ -134,9 +134,21 @@ def build_model(args, device):
     return model.to(device)
 
 
+def synthetic_batch(batch, frames, img, seed=1234, real_tokens=32, ctx=77):
+    """frames randn [B,3,F,H,W] f32 (stand for mean/std-normalised pixels); tokens [B,77] = SOT,
+    30 random ids, EOT (49407 = the largest id, so argmax finds it: models.py:160) at position 31, zero padding. The
+    bench's own generator (tests/test_oracle_golden.py pins it to the oracle's copy, which the parity tests use)."""
+    g = torch.Generator().manual_seed(seed)
+    video = torch.randn(batch, 3, frames, img, img, generator=g)
+    tokens = torch.zeros(batch, ctx, dtype=torch.long)
+    tokens[:, 0] = 49406
+    tokens[:, 1:real_tokens - 1] = torch.randint(1, 49406, (batch, real_tokens - 2), generator=g)
+    tokens[:, real_tokens - 1] = 49407
+    return video, tokens
+
+
 def synthetic(args, rank, device, img):
-    from oracle import oracle as O      # data generator only (shared with the parity tests)
-    video, tokens = O.synthetic_batch(args.batch, args.frames, img, seed=1234 + rank)
+    video, tokens = synthetic_batch(args.batch, args.frames, img, seed=1234 + rank)
     return video.to(device), tokens.to(device)
 
 
@@ -158,7 +170,7 @@ def cpu_baseline(args, model, img):
     torch.set_num_threads(cores)
     w = {k: v.detach().float().cpu().clone().requires_grad_(v.is_floating_point())
          for k, v in model.state_dict().items()}
-    video, tokens = O.synthetic_batch(args.cpu_batch, args.frames, img, seed=99)
+    video, tokens = synthetic_batch(args.cpu_batch, args.frames, img, seed=99)
     vis_heads = model.visual.blocks[0].attn.num_heads
     txt_heads = model.transformer.resblocks[0].attn.num_heads
     times = []
@@ -190,7 +202,7 @@ def narrator_cpu_baseline(args, model, tok):
     cores = min(32, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     w = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
-    video, _ = O.synthetic_batch(1, args.frames, 224, seed=99)
+    video, _ = synthetic_batch(1, args.frames, 224, seed=99)
     t0 = time.perf_counter()
     with torch.no_grad():
         img = O.narrator_encode_image(video, w, 12, 12).repeat_interleave(args.returns, dim=0)
@@ -344,19 +356,20 @@ def main():
 
     from lavila_amd import ops
     from lavila.models.loss import CLIPLoss
-    timer = KernelTimer()
-    ops.divided_attn_fwd_raw = timer.wrap(ops.divided_attn_fwd_raw, lambda qkv, f, n, h, mode: mode == 0)   # space
-    # every video-tower launch (M = B*T rows) of the two hand-written MFMA GEMM families; the text tower's small
-    # launches overlap on the second stream
-    gtimer = KernelTimer()
-    ops.linear_tn_raw = gtimer.wrap(ops.linear_tn_raw, lambda x, w, *a, **k: x.shape[0] >= 65536,
-                                    work=lambda x, w, *a, **k: 2.0 * x.shape[0] * w.shape[0] * w.shape[1])
-    wtimer = KernelTimer()
-    ops.linear_wgrad_raw = wtimer.wrap(ops.linear_wgrad_raw, lambda dy, x, *a, **k: dy.shape[0] >= 65536,
-                                       work=lambda dy, x, *a, **k: 2.0 * dy.shape[0] * dy.shape[1] * x.shape[1])
-
     model = build_model(args, device)
     img = model.visual.patch_embed.img_size[0]
+    timer = KernelTimer()
+    ops.divided_attn_fwd_raw = timer.wrap(ops.divided_attn_fwd_raw, lambda qkv, f, n, h, mode: mode == 0)   # space
+    # every all-token video-tower launch (M = local batch x tokens per clip rows, whatever the local batch is) of the
+    # two hand-written MFMA GEMM families; the text tower's launches (<= 77 rows per caption, on the second stream) and
+    # the cls-row launches of the last block (one row per clip) are not in the aggregate
+    video_rows = args.batch * (1 + args.frames * model.visual.patches_per_frame)
+    gtimer = KernelTimer()
+    ops.linear_tn_raw = gtimer.wrap(ops.linear_tn_raw, lambda x, w, *a, **k: x.shape[0] == video_rows,
+                                    work=lambda x, w, *a, **k: 2.0 * x.shape[0] * w.shape[0] * w.shape[1])
+    wtimer = KernelTimer()
+    ops.linear_wgrad_raw = wtimer.wrap(ops.linear_wgrad_raw, lambda dy, x, *a, **k: dy.shape[0] == video_rows,
+                                       work=lambda dy, x, *a, **k: 2.0 * dy.shape[0] * dy.shape[1] * x.shape[1])
     net = model
     if world > 1:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev_index], bucket_cap_mb=200,
@@ -392,10 +405,12 @@ def main():
     timer.enabled = wtimer.enabled = gtimer.enabled = not args.no_events
     t0 = time.perf_counter()
     host_s = 0.0
+    host_steps = []                # per-step host time inside step(): an outlier step shows here (no extra syncs)
     for _ in range(args.steps):
         h0 = time.perf_counter()
         loss = step()
-        host_s += time.perf_counter() - h0
+        host_steps.append(time.perf_counter() - h0)
+        host_s += host_steps[-1]
     fence()
     elapsed = time.perf_counter() - t0
     timer.enabled = wtimer.enabled = gtimer.enabled = False
@@ -496,6 +511,7 @@ def main():
                        # host time spent inside step() -- includes the wait of the text tower's caption-length read-back
                        # (models._longest_caption), which returns only when the previous step has drained
                        'host_enqueue_ms_per_step': round(1e3 * host_s / args.steps, 1),
+                       'host_ms_of_each_step': [round(1e3 * h, 1) for h in host_steps[:32]],
                        'text_trim_off': no_trim,
                        'full_last_block': full_last,
                        'exact_work_elimination': 'text positions behind the longest caption (causal: unread) and, in the LAST '

@@ -288,6 +288,11 @@ int lvl_sample_next_token(const void* logits, int64_t row_stride, int rows, int 
  *                            acc = dA = dY . W2 is the input gradient of fc2, y = d(fc1 output)
  * aux_out / aux_in: [M,N] bf16. N % 256 == 0 and K % 64 == 0 (operands < 4 GiB), else LVL_ENOSYS. Workspace (QUICKGELU_BWD only):
  * lvl_workspace_floats("linear_tn", M, N) floats.
+ * dtype = LVL_F32 selects the F32-CLASS MODE of the same kernel (the parity configuration, north_star "within 1e-3
+ * fp32"): x [M, 3K0] and w [N, 3K0] are the bf16 term images lvl_split_bf16x3 writes (role 0 for x, role 1 for w;
+ * K = 3*K0, K0 % 64 == 0), so that one pass accumulates xh.wh + xh.wl + xl.wh in f32 (~2^-17 relative per product);
+ * y, aux_out and aux_in are FLOAT32 [M,N] and the QuickGELU epilogues see the unrounded pre-activation. Same tiling,
+ * LDS-DMA ring, MFMA schedule, bias path and tile schedule as the bf16 mode.
  * sched (nullable): the launch's TILE-COUNTER block, 16 x uint32 (64-byte aligned), ZERO on entry; the kernel leaves it
  * zero again when its last workgroup exits, so a caller may hand the same block to the next launch on the SAME stream
  * (launches that can run concurrently -- other streams, graph branches -- need distinct blocks). With it the persistent
@@ -309,7 +314,8 @@ int lvl_linear_tn(const void* x, const void* w, const float* bias, void* y, void
  * row chunks handed out by device counters: a workgroup works through its own unit and then takes unclaimed chunks of
  * the other splits of its tile, so a compute unit held by another kernel delays the launch by a fraction of a unit
  * instead of a second round. With all CUs available nobody steals and the result is bit-identical to the static plan
- * (NULL). */
+ * (NULL). f32-class weight gradients use the same entry with row-STACKED term images (lvl_split_bf16x3 with
+ * dst_term_stride = rows_padded * cols): dy3 [3M,N] = (h; h; l), x3 [3M,K] = (h; l; h); dw is float32 either way. */
 int lvl_linear_wgrad(const void* dy, const void* x, float* dw, float* dbias, float* ws, uint32_t* sched, int64_t M,
                      int N, int K, int dtype, void* stream);
 
@@ -327,6 +333,16 @@ int lvl_qkv_bias_grad(const void* dqkv, const void* dout, float* dbias, float* w
  * (main_pretrain.py:491 `amp.autocast`) plus the transposed copy the input-gradient GEMM wants, in one pass.
  * src: [N,K] f32; dst: [N,K] bf16; dst_t: [K,N] bf16. */
 int lvl_cast_transpose(const float* src, void* dst, void* dst_t, int N, int K, void* stream);
+
+/* ---- f32-class operands for the MFMA GEMMs (parity configuration) ----------------------------------------------
+ * Writes a float32 matrix src [rows, cols] (row stride src_row_stride elements) as three bf16 TERM images:
+ * h = bf16(x), l = bf16(x - h) (x = h + l up to 2^-18 |x|); image t of element (r, c) goes to
+ * dst[r * dst_row_stride + t * dst_term_stride + c], t = 0..2, with the terms (h, h, l) for role 0 (the x / dy side of a
+ * product) and (h, l, h) for role 1 (the w / x side): contracting image against image gives h.h' + h.l' + l.h'.
+ * Replaces nothing in the reference: it is what lets `F.linear` on float32 tensors (the reference's CPU / fp32 path,
+ * timesformer.py:47-58,95-99) run on lvl_linear_tn / lvl_linear_wgrad instead of a library GEMM. cols % 4 == 0. */
+int lvl_split_bf16x3(const float* src, void* dst, int64_t rows, int cols, int64_t src_row_stride,
+                     int64_t dst_row_stride, int64_t dst_term_stride, int role, void* stream);
 
 #ifdef __cplusplus
 }

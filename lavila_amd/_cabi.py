@@ -45,6 +45,7 @@ SIGNATURES = {
     'lvl_linear_tn': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
     'lvl_linear_wgrad': (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P]),
     'lvl_cast_transpose': (_I, [_P, _P, _P, _I, _I, _P]),
+    'lvl_split_bf16x3': (_I, [_P, _P, _L, _I, _L, _L, _L, _I, _P]),
     'lvl_cls_attn_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'lvl_cls_attn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'lvl_mq_cross_attn_fwd': (_I, [_P, _L, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -281,6 +281,38 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
   }
 }
 
+// f32-class operands of the MFMA GEMMs: a float32 matrix as three bf16 TERM images. x = h + l + O(2^-18 |x|) with
+// h = bf16(x) (round to nearest even) and l = bf16(x - h) (the subtraction is exact in f32). Image t of element (r, c)
+// goes to dst[r * dst_row_stride + t * dst_term_stride + c]:
+//   role 0 (the x / dy side of a product):  terms (h, h, l)
+//   role 1 (the w / x side):                terms (h, l, h)
+// so that contracting image-by-image accumulates h.h' + h.l' + l.h' -- the product to ~2^-17 relative, every partial
+// product exact in the f32 accumulator. Along K (dst_term_stride = cols, dst_row_stride = 3 cols) this is the operand of
+// lvl_linear_tn's f32-class mode; stacked along the rows (dst_row_stride = cols, dst_term_stride = rows_padded * cols)
+// the operand of lvl_linear_wgrad, whose contraction runs over rows.
+__global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst,
+                                                           int64_t rows, int cols, int64_t src_row_stride,
+                                                           int64_t dst_row_stride, int64_t dst_term_stride, int role) {
+  const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c4 * 4 >= cols) return;
+  for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
+    const float4 a = *reinterpret_cast<const float4*>(src + r * src_row_stride + c4 * 4);
+    const float x[4] = {a.x, a.y, a.z, a.w};
+    float l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float h = bf16_to_f32(f32_to_bf16(x[e]));
+      l[e] = (fabsf(h) <= 3.38e38f) ? x[e] - h : 0.f;      // inf / nan stay in the h image only
+    }
+    const uint2 hv = make_uint2(f32x2_to_bf16x2(x[0], x[1]), f32x2_to_bf16x2(x[2], x[3]));
+    const uint2 lv = make_uint2(f32x2_to_bf16x2(l[0], l[1]), f32x2_to_bf16x2(l[2], l[3]));
+    uint16_t* d = dst + r * dst_row_stride + c4 * 4;
+    *reinterpret_cast<uint2*>(d) = hv;
+    *reinterpret_cast<uint2*>(d + dst_term_stride) = role == 0 ? hv : lv;
+    *reinterpret_cast<uint2*>(d + 2 * dst_term_stride) = role == 0 ? lv : hv;
+  }
+}
+
 }  // namespace
 
 extern "C" int lvl_bias_quickgelu_fwd(const void* u, const float* bias, void* a, int64_t rows, int cols, int dtype,
@@ -368,6 +400,23 @@ extern "C" int lvl_cast_transpose(const float* src, void* dst, void* dst_t, int 
   hipLaunchKernelGGL(cast_transpose_kernel, dim3((K + 63) / 64, (N + 63) / 64), dim3(256), 0, (hipStream_t)stream, src,
                      (uint16_t*)dst, (uint16_t*)dst_t, N, K);
   LVL_CHECK_LAUNCH("cast_transpose");
+  return LVL_OK;
+}
+
+extern "C" int lvl_split_bf16x3(const float* src, void* dst, int64_t rows, int cols, int64_t src_row_stride,
+                                int64_t dst_row_stride, int64_t dst_term_stride, int role, void* stream) {
+  LVL_REQUIRE(src && dst, "split_bf16x3: null pointer");
+  LVL_REQUIRE(rows >= 0 && cols > 0 && cols % 4 == 0, "split_bf16x3: cols=%d must be a multiple of 4", cols);
+  LVL_REQUIRE(role == 0 || role == 1, "split_bf16x3: role %d", role);
+  LVL_REQUIRE(src_row_stride % 4 == 0 && dst_row_stride % 4 == 0 && dst_term_stride % 4 == 0 && lvl_aligned16(src) &&
+                  (reinterpret_cast<uintptr_t>(dst) & 7) == 0,
+              "split_bf16x3: strides must be multiples of 4 elements, src 16-byte and dst 8-byte aligned");
+  if (rows == 0) return LVL_OK;
+  const unsigned gx = (unsigned)((cols / 4 + 255) / 256);
+  const unsigned gy = (unsigned)(rows < 16384 ? rows : 16384);
+  hipLaunchKernelGGL(split_bf16x3_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, src, (uint16_t*)dst, rows,
+                     cols, src_row_stride, dst_row_stride, dst_term_stride, role);
+  LVL_CHECK_LAUNCH("split_bf16x3");
   return LVL_OK;
 }
 

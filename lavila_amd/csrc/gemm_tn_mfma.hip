@@ -12,6 +12,15 @@
 //   2  y = acc * quickgelu'(aux_in) ; column sums of y -> partial slab     backward of the same: fc2's input gradient
 //                                                                          becomes d(fc1 output); sums = d(fc1 bias)
 //
+// f32-CLASS MODE (template F32O, C-ABI dtype LVL_F32): the SAME kernel -- tile walk, LDS-DMA ring, swizzle, MFMA phases,
+// bias image, epilogue arithmetic -- with float32 results. The operands are bf16 TERM IMAGES of float32 matrices
+// (lvl_split_bf16x3, elementwise.hip): x = xh + xl (+ O(2^-18 x)), xh = bf16(x), xl = bf16(x - xh), laid out along the
+// contraction as X3 = [xh | xh | xl], W3 = [wh | wl | wh], so that one pass over K' = 3K accumulates
+// xh.wh + xh.wl + xl.wh in the f32 accumulators: every product is exact, what is dropped is xl.wl and the second-order
+// remainders (~2^-17 relative per product). y / aux_out / aux_in are float32; the QuickGELU epilogues see the unrounded
+// f32 pre-activation. This is the parity configuration's GEMM (north_star: "within 1e-3 fp32"): it puts the benched
+// kernel itself, not a library GEMM, under the f32 tolerance.
+//
 // Shape of the problem on this path: M = B*T ~ 2e5 rows, N,K in {768, 2304, 3072}. Measured facts that shaped it
 // (profiles/r02_pmc_gemm_tn_v1_qkv.txt, tools/probe_gemm_trace.py): (1) what the L2 can serve is a number of
 // REQUESTS, so every request must be a full 128-byte line (a K step of 32 = 64-byte rows doubled the requests and
@@ -99,14 +108,18 @@ __device__ __forceinline__ uint4 widen_pair(uint2 a, uint2 b) {
   return make_uint4(r0[0], r1[0], r0[1], r1[1]);
 }
 
-template <int EPI>
+template <int EPI, bool F32O>
 __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
-                                                      const float* __restrict__ bias, uint16_t* __restrict__ Y,
-                                                      uint16_t* __restrict__ aux_out,
-                                                      const uint16_t* __restrict__ aux_in,
+                                                      const float* __restrict__ bias, void* __restrict__ Yv,
+                                                      void* __restrict__ aux_out_v,
+                                                      const void* __restrict__ aux_in_v,
                                                       float* __restrict__ colpart, int64_t M, int N, int K,
                                                       int tiles_n, int ntiles, unsigned* __restrict__ sched,
                                                       int late_mod) {
+  using out_t = std::conditional_t<F32O, float, uint16_t>;      // element type of y / aux_out / aux_in
+  out_t* __restrict__ const Y = static_cast<out_t*>(Yv);
+  out_t* __restrict__ const aux_out = static_cast<out_t*>(aux_out_v);
+  const out_t* __restrict__ const aux_in = static_cast<const out_t*>(aux_in_v);
   extern __shared__ __attribute__((aligned(1024))) uint8_t smem[];      // [NSLOT][128 rows][128 B]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -305,7 +318,7 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
     uint2 ub_next[EPI == 2 ? 8 : 1];
     auto load_u = [&](int j) {
       const int64_t m = m0 + (j >> 1) * 128 + wm * 64 + (j & 1) * 32 + r5;
-      const uint16_t* urow = aux_in + (m < M ? m : M - 1) * (int64_t)N + n0 + wn * 64 + 4 * hi;
+      const uint16_t* urow = reinterpret_cast<const uint16_t*>(aux_in) + (m < M ? m : M - 1) * (int64_t)N + n0 + wn * 64 + 4 * hi;
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -314,8 +327,47 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
     if (EPI == 2) {
 #pragma unroll
       for (int c = 0; c < 32; ++c) csum[c] = 0.f;
-      load_u(0);
+      if constexpr (!F32O) load_u(0);
     }
+    if constexpr (F32O) {
+      // float32 results (f32-class mode): an accumulator quad IS 4 consecutive output columns of one row -> one
+      // 16-byte store per quad (and one 16-byte aux access for the QuickGELU epilogues); same arithmetic as below
+      // without the bf16 roundings
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t m = m0 + (j >> 1) * 128 + wm * 64 + (j & 1) * 32 + r5;
+        const bool valid = m < M;
+        const int64_t rowoff = (valid ? m : M - 1) * (int64_t)N + n0 + wn * 64 + 4 * hi;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const gm_f32x16& a16 = acc[j >> 1][i][j & 1];
+#pragma unroll
+          for (int rq = 0; rq < 4; ++rq) {
+            const int64_t o = rowoff + i * 32 + 8 * rq;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = a16[4 * rq + e];
+            if (EPI == 1) {
+              if (valid) *reinterpret_cast<float4*>(aux_out + o) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
+            }
+            if (EPI == 2) {
+              const float4 u = *reinterpret_cast<const float4*>(aux_in + o);
+              v[0] *= quick_gelu_grad(u.x);
+              v[1] *= quick_gelu_grad(u.y);
+              v[2] *= quick_gelu_grad(u.z);
+              v[3] *= quick_gelu_grad(u.w);
+              if (valid) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) csum[i * 16 + rq * 4 + e] += v[e];
+              }
+            }
+            if (valid) *reinterpret_cast<float4*>(Y + o) = make_float4(v[0], v[1], v[2], v[3]);
+          }
+        }
+      }
+    } else {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {          // row group (qm, mt): 32 rows
       const int64_t mg = m0 + (j >> 1) * 128 + wm * 64 + (j & 1) * 32;
@@ -332,7 +384,6 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
         uint2 ypk[4], upk[4];
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
-          const int nl = wn * 64 + i * 32 + 8 * rq + 4 * hi;       // column inside the tile
           float v[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = a16[4 * rq + e];
@@ -378,6 +429,7 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
             if (EPI == 1) *reinterpret_cast<uint4*>(aux_out + o) = uv[i][jj];
           }
       }
+    }
     }
     if (EPI == 2) {
       // column sums over the wave's 128 rows: 32 values per lane, summed over the 32 lanes of each half-wave by a
@@ -487,7 +539,9 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
   // barrier waits for was still filled BEFORE that epilogue -- the epilogue's NS result stores sit between the
   // awaited fills and the newer ones and may stay in flight (waiting for them to be acknowledged would cost every
   // tile ~2 us of idle matrix pipe).
-  constexpr int NS = EPI == 1 ? 32 : 16;
+  // (f32-class mode: its 32 / 64 wider stores would overflow the 6-bit vmcnt field together with the fills -- no
+  // allowance there: the first blocks of the next tile also wait for the previous tile's stores)
+  constexpr int NS = F32O ? 0 : (EPI == 1 ? 32 : 16);
   auto k_block = [&](auto a0_, auto a1_) {
     constexpr int A0 = decltype(a0_)::value, A1 = decltype(a1_)::value;
     const uint8_t* sb = smem + par * SLOT;
@@ -577,11 +631,11 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
 
 int num_cus() { return lvl_persistent_cus(); }      // one persistent workgroup per compute unit
 
-template <int EPI>
+template <int EPI, bool F32O = false>
 int launch_tn(const void* x, const void* w, const float* bias, void* y, void* aux_out, const void* aux_in,
               float* colpart, int64_t M, int N, int K, unsigned* sched, hipStream_t st) {
   constexpr int shmem = SMEM_B;
-  const int rc = lvl_allow_lds<gemm_tn_kernel<EPI>>();
+  const int rc = lvl_allow_lds<gemm_tn_kernel<EPI, F32O>>();
   if (rc != LVL_OK) return rc;
   const int tiles_n = N / TN;
   const int64_t tiles_m = (M + TM - 1) / TM;
@@ -590,8 +644,8 @@ int launch_tn(const void* x, const void* w, const float* bias, void* y, void* au
   int grid = (int)(ntiles < num_cus() ? ntiles : num_cus());
   if (grid >= 8) grid -= grid % 8;          // whole XCD rounds (the kernel maps workgroup b to XCD b % 8)
   if (K / BK < DYN_MIN_NB) sched = nullptr; // too few K blocks per tile for the counter hand-off: static schedule
-  hipLaunchKernelGGL((gemm_tn_kernel<EPI>), dim3((unsigned)grid), dim3(512), shmem, st, (const uint16_t*)x,
-                     (const uint16_t*)w, bias, (uint16_t*)y, (uint16_t*)aux_out, (const uint16_t*)aux_in, colpart, M,
+  hipLaunchKernelGGL((gemm_tn_kernel<EPI, F32O>), dim3((unsigned)grid), dim3(512), shmem, st, (const uint16_t*)x,
+                     (const uint16_t*)w, bias, y, aux_out, aux_in, colpart, M,
                      N, K, tiles_n, (int)ntiles, sched, sched ? lvl_debug_late_mod() : 0);
   LVL_CHECK_LAUNCH("linear_tn");
   return LVL_OK;
@@ -614,7 +668,7 @@ extern "C" int lvl_linear_tn(const void* x, const void* w, const float* bias, vo
                              const void* aux_in, float* colsum, float* ws, uint32_t* sched, int64_t M, int N, int K,
                              int epilogue, int dtype, void* stream) {
   LVL_REQUIRE(x && w && y, "linear_tn: null pointer");
-  LVL_REQUIRE(dtype == LVL_BF16, "linear_tn: bf16 operands only (dtype=%d)", dtype);
+  LVL_REQUIRE(dtype == LVL_BF16 || dtype == LVL_F32, "linear_tn: unknown dtype %d", dtype);
   LVL_REQUIRE(M > 0 && N > 0 && K > 0, "linear_tn: empty problem");
   if (N % TN != 0 || K % BK != 0)
     return lvl_fail(LVL_ENOSYS, "linear_tn: no tiling for N=%d K=%d (N %% 256 == 0 and K %% 64 == 0 needed)", N, K);
@@ -624,6 +678,26 @@ extern "C" int lvl_linear_tn(const void* x, const void* w, const float* bias, vo
                   lvl_aligned16(aux_out) && lvl_aligned16(aux_in),
               "linear_tn: pointers must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
+  if (dtype == LVL_F32) {      // f32-class mode: bf16 term images in (K = 3 x the layer's width), float32 out
+    LVL_REQUIRE(K % (3 * BK) == 0, "linear_tn (f32 class): K = %d is not 3 x a multiple of 64", K);
+    switch (epilogue) {
+      case LVL_EPI_BIAS:
+        return launch_tn<0, true>(x, w, bias, y, nullptr, nullptr, nullptr, M, N, K, sched, st);
+      case LVL_EPI_BIAS_QUICKGELU:
+        LVL_REQUIRE(aux_out != nullptr, "linear_tn: the QuickGELU epilogue writes the pre-activation to aux_out");
+        return launch_tn<1, true>(x, w, bias, y, aux_out, nullptr, nullptr, M, N, K, sched, st);
+      case LVL_EPI_QUICKGELU_BWD: {
+        LVL_REQUIRE(aux_in != nullptr && colsum != nullptr && ws != nullptr && lvl_aligned16(ws),
+                    "linear_tn: the QuickGELU-backward epilogue needs aux_in, colsum and a workspace");
+        const int rc = launch_tn<2, true>(x, w, nullptr, y, nullptr, aux_in, ws, M, N, K, sched, st);
+        if (rc != LVL_OK) return rc;
+        const int P = (int)(2 * ((M + TM - 1) / TM));
+        return lvl_launch_column_reduce(ws, P, N, N, ws + (size_t)P * N, colsum, nullptr, nullptr, st);
+      }
+      default:
+        return lvl_fail(LVL_EINVAL, "linear_tn: unknown epilogue %d", epilogue);
+    }
+  }
   switch (epilogue) {
     case LVL_EPI_BIAS:
       return launch_tn<0>(x, w, bias, y, nullptr, nullptr, nullptr, M, N, K, sched, st);

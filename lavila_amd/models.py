@@ -141,7 +141,7 @@ class CLIP(nn.Module):
                 return _half_out(x, image, self.image_projection)
             if x.dtype != self.image_projection.dtype and not torch.is_autocast_enabled():
                 x = x.to(self.image_projection.dtype)        # fp16 clip into an f32 model, or the reverse
-            return _half_out(x @ self.image_projection, image, self.image_projection)
+            return _half_out(ops.project(x, self.image_projection), image, self.image_projection)
 
     def _eot_rows(self, text):
         """(EOT row of every caption, their maximum as a device scalar or None): enqueued without a host read."""
@@ -168,7 +168,7 @@ class CLIP(nn.Module):
             x = self.transformer.forward_batch_major(x, self.ln_final, use_checkpoint=use_checkpoint, rows=rows)
             if x.dtype != self.text_projection.dtype and not torch.is_autocast_enabled():
                 x = x.to(self.text_projection.dtype)
-            return _half_out(x @ self.text_projection, self.text_projection)
+            return _half_out(ops.project(x, self.text_projection), self.text_projection)
 
     def forward(self, image, text, use_checkpoint=False, norm_embed=False):
         with ops.model_forward():

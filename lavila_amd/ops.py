@@ -122,6 +122,35 @@ except ImportError:         # older torch: the per-forward trigger alone
     pass
 
 
+# float32 activations (the parity configuration, north_star "within 1e-3 fp32"): the SAME MFMA GEMM kernels in their
+# f32-class mode -- operands as bf16 term images (split3 / lvl_split_bf16x3), float32 results; ~2^-17 relative per
+# product instead of bf16's 2^-9. LAVILA_F32_MFMA=0 sends float32 Linears to the library GEMM instead (A/B only).
+F32_MFMA = os.environ.get('LAVILA_F32_MFMA', '1') != '0'
+
+
+def split3(x2: torch.Tensor, role: int, stack: bool = False) -> torch.Tensor:
+    """float32 [R, C] -> its three bf16 term images (h, h, l) (role 0: the x / dy side of a product) or (h, l, h)
+    (role 1: the w / x side): side by side along the contraction, [R, 3C] (operand of lvl_linear_tn's f32-class mode),
+    or -- stack=True -- one under the other, [3*Rp, C] (operands of lvl_linear_wgrad, which contracts over rows; rows
+    padded with zeros so that the kernel sees at least one 32-row step)."""
+    C.require_device(x2)
+    R, Cc = x2.shape
+    if stack:
+        Rp = max(R, 11)
+        out = (torch.zeros if Rp != R else torch.empty)(3 * Rp, Cc, dtype=torch.bfloat16, device=x2.device)
+        rs, ts = Cc, Rp * Cc
+    else:
+        out = torch.empty(R, 3 * Cc, dtype=torch.bfloat16, device=x2.device)
+        rs, ts = 3 * Cc, Cc
+    C.check(C.lib().lvl_split_bf16x3(C.ptr(x2), C.ptr(out), R, Cc, Cc, rs, ts, role, C.stream_ptr()), 'lvl_split_bf16x3')
+    return out
+
+
+def _split_pair(src):
+    src = src.float().contiguous()
+    return split3(src, 1), split3(src.t().contiguous(), 1)
+
+
 def _cast_pair(src):
     if src.dtype == torch.float32 and src.is_contiguous():
         w = torch.empty_like(src, dtype=torch.bfloat16)
@@ -134,27 +163,30 @@ def _cast_pair(src):
     return w, wt
 
 
-def weight_copies(weight: torch.Tensor):
-    """(w, wt): the bf16 copy [out,in] the forward GEMM reads and the transposed bf16 copy [in,out] the input-gradient
+def weight_copies(weight: torch.Tensor, f32: bool = False):
+    """f32=True: the f32-class operands instead -- (w3 [out, 3 in], wt3 [in, 3 out]) term images of the weight and of its
+    transpose (split3 role 1) -- cached under the same rules.
+    (w, wt): the bf16 copy [out,in] the forward GEMM reads and the transposed bf16 copy [in,out] the input-gradient
     GEMM reads (both operands of lvl_linear_tn are contraction-contiguous). One lvl_cast_transpose pass per optimizer
     step: the pair is cached per parameter and keyed by (version counter, storage pointer, cache generation), so
     activation checkpointing's second forward and every backward reuse it; see invalidate_weight_cache for what bumps
     the generation. Under hipGraph capture the cache is bypassed: the cast is recorded INTO the graph (into
     graph-owned buffers), so a replay after a weight update reads the updated weights."""
     src = weight.detach()
+    make = _split_pair if f32 else _cast_pair
     if src.is_cuda and torch.cuda.is_current_stream_capturing():
-        return _cast_pair(src)
+        return make(src)
     # keyed by the identity of the parameter (a 2-D view of one -- the Conv2d weight of the patch embedding -- keys on
     # its base); a weakref finaliser drops the entry with the parameter, nothing is attached to the parameter itself
     # (pickling / deepcopy of the model see no extra state)
     holder = weight._base if weight._base is not None else weight
-    ver, key = weight._version, (id(holder), tuple(weight.shape))
+    ver, key = weight._version, (id(holder), tuple(weight.shape), tuple(weight.stride()), f32)
     c = _copies.get(key)
     if c is not None and c[0] == ver and c[3] == weight.data_ptr() and c[4] == _generation:
         return c[1], c[2]
     if c is None:
         weakref.finalize(holder, _copies.pop, key, None)
-    w, wt = _cast_pair(src)
+    w, wt = make(src)
     _copies[key] = (ver, w, wt, weight.data_ptr(), _generation)
     return w, wt
 
@@ -179,12 +211,28 @@ def _wgrad(dy2, x2, wdt):
     return (dy2.t() @ x2).to(wdt)
 
 
+def _wgrad_f32(dy2, x2, wdt):
+    """dW = dy^T x for float32 operands: lvl_linear_wgrad on row-stacked term images (f32-class, see split3)."""
+    n_out, n_in = dy2.shape[1], x2.shape[1]
+    ws_floats = C.lib().lvl_workspace_floats(b'linear_wgrad', n_out, n_in) if (F32_MFMA and dy2.is_cuda) else -1
+    if ws_floats < 0 or dy2.shape[0] * max(n_in, n_out) * 6 >= (1 << 32):
+        return (dy2.t() @ x2).to(wdt)
+    dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
+    x2 = x2 if x2.is_contiguous() else x2.contiguous()
+    return linear_wgrad_raw(split3(dy2, 0, stack=True), split3(x2, 1, stack=True), False, int(ws_floats))[0].to(wdt)
+
+
+def _tn_ok_f32(rows: int, n_out: int, n_in: int) -> bool:
+    return F32_MFMA and _tn_ok(rows, n_out, 3 * n_in)
+
+
 class _LinearFn(torch.autograd.Function):
     """y = x W^T (+ b) for token-major activations [rows, in].
 
     bf16: forward and input gradient are lvl_linear_tn calls (the input gradient multiplies by the cached transposed
     weight copy, so both GEMMs read contraction-contiguous operands), the weight gradient is lvl_linear_wgrad. f32
-    (the parity configuration) and widths the kernels do not tile use the library GEMM."""
+    (the parity configuration): the same three kernels in f32-class mode (bf16 term images in, float32 out: split3).
+    Widths the kernels do not tile use the library GEMM."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -194,6 +242,14 @@ class _LinearFn(torch.autograd.Function):
                and (not ctx.needs_input_grad[0] or _tn_ok(rows, n_in, n_out)))     # the input gradient swaps N and K
         ctx.own = own
         ctx.meta = (weight.dtype, None if bias is None else bias.dtype, x.shape)
+        ctx.f32own = (not own and x.dtype == torch.float32 and x.is_cuda and _tn_ok_f32(rows, n_out, n_in)
+                      and (not ctx.needs_input_grad[0] or _tn_ok_f32(rows, n_in, n_out)))
+        if ctx.f32own:          # f32-class mode of the same kernels (the parity configuration)
+            w3, wt3 = weight_copies(weight, f32=True)
+            x2 = x2 if x2.is_contiguous() else x2.contiguous()
+            ctx.save_for_backward(x2, wt3)
+            y = linear_tn_raw(split3(x2, 0), w3, _f32(bias), C.EPI_BIAS, f32=True)
+            return y.reshape(*x.shape[:-1], n_out)
         if own:
             w, wt = weight_copies(weight)
             ctx.save_for_backward(x2 if x2.is_contiguous() else x2.contiguous(), wt)
@@ -217,10 +273,19 @@ class _LinearFn(torch.autograd.Function):
             dy2 = dy2.contiguous()
         dx = dw = db = None
         with torch.autocast('cuda', enabled=False):
+            if ctx.f32own:
+                dy2 = dy2.float()
+                if ctx.needs_input_grad[0]:
+                    dx = linear_tn_raw(split3(dy2, 0), w, None, C.EPI_BIAS, f32=True).reshape(xshape)
+                if ctx.needs_input_grad[1]:
+                    dw = _wgrad_f32(dy2, x2, wdt)
+                if bdt is not None and ctx.needs_input_grad[2]:
+                    db = dy2.sum(0).to(bdt)
+                return dx, dw, db
             if ctx.needs_input_grad[0]:
                 dx = (linear_tn_raw(dy2, w, None, C.EPI_BIAS) if ctx.own else dy2 @ w).reshape(xshape)
             if ctx.needs_input_grad[1]:
-                dw = _wgrad(dy2, x2, wdt)
+                dw = _wgrad(dy2, x2, wdt) if (ctx.own or x2.dtype != torch.float32) else _wgrad_f32(dy2, x2, wdt)
             if bdt is not None and ctx.needs_input_grad[2]:
                 db = dy2.sum(0, dtype=torch.float32).to(bdt)      # f32 accumulation AND f32 result
         return dx, dw, db
@@ -238,10 +303,11 @@ class _MlpFn(torch.autograd.Function):
         x2 = x.reshape(-1, x.shape[-1])
         if not x2.is_contiguous():
             x2 = x2.contiguous()
-        w1b, w1t = weight_copies(w1)
-        w2b, w2t = weight_copies(w2)
-        a, u = linear_tn_raw(x2, w1b, _f32(b1), C.EPI_BIAS_QUICKGELU)
-        y = linear_tn_raw(a, w2b, None, C.EPI_BIAS)
+        f32 = ctx.f32 = x.dtype == torch.float32        # f32-class mode: term images in, float32 u / a / y
+        w1b, w1t = weight_copies(w1, f32)
+        w2b, w2t = weight_copies(w2, f32)
+        a, u = linear_tn_raw(split3(x2, 0) if f32 else x2, w1b, _f32(b1), C.EPI_BIAS_QUICKGELU, f32=f32)
+        y = linear_tn_raw(split3(a, 0) if f32 else a, w2b, None, C.EPI_BIAS, f32=f32)
         ctx.save_for_backward(x2, u, a, w1t, w2t)
         ctx.meta = (w1.dtype, None if b1 is None else b1.dtype, w2.dtype, x.shape)
         return y.reshape(*x.shape[:-1], w2.shape[0])
@@ -253,6 +319,14 @@ class _MlpFn(torch.autograd.Function):
         dy2 = dy.reshape(-1, dy.shape[-1])
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
+        if ctx.f32:
+            dy2 = dy2.float()
+            du, db1 = linear_tn_raw(split3(dy2, 0), w2t, None, C.EPI_QUICKGELU_BWD, aux_in=u, f32=True)
+            dw2 = _wgrad_f32(dy2, a, w2dt) if ctx.needs_input_grad[3] else None
+            dx = (linear_tn_raw(split3(du, 0), w1t, None, C.EPI_BIAS, f32=True).reshape(xshape)
+                  if ctx.needs_input_grad[0] else None)
+            dw1 = _wgrad_f32(du, x2, w1dt) if ctx.needs_input_grad[1] else None
+            return dx, dw1, (db1.to(b1dt) if (b1dt is not None and ctx.needs_input_grad[2]) else None), dw2
         du, db1 = linear_tn_raw(dy2, w2t, None, C.EPI_QUICKGELU_BWD, aux_in=u)
         dw2 = _wgrad(dy2, a, w2dt) if ctx.needs_input_grad[3] else None
         dx = linear_tn_raw(du, w1t, None, C.EPI_BIAS).reshape(xshape) if ctx.needs_input_grad[0] else None
@@ -268,6 +342,10 @@ def mlp_quickgelu(x, w1, b1, w2):
             and _tn_ok(rows, w1.shape[1], w1.shape[0]) and _tn_ok(rows, w2.shape[0], w2.shape[1])
             and _tn_ok(rows, w2.shape[1], w2.shape[0])):
         return _MlpFn.apply(x, w1, b1, w2)
+    if (x.dtype == torch.float32 and x.is_cuda and b1 is not None and w1.dtype == torch.float32
+            and _tn_ok_f32(rows, w1.shape[0], w1.shape[1]) and _tn_ok_f32(rows, w1.shape[1], w1.shape[0])
+            and _tn_ok_f32(rows, w2.shape[0], w2.shape[1]) and _tn_ok_f32(rows, w2.shape[1], w2.shape[0])):
+        return _MlpFn.apply(x, w1, b1, w2)          # the same fused epilogues in f32-class mode
     return linear(bias_quick_gelu(linear(x, w1), b1), w2)
 
 
@@ -324,13 +402,14 @@ def sched_block(device, words=16):
     return pool[0][pool[1]]
 
 
-def linear_tn_raw(x, w, bias=None, epilogue=C.EPI_BIAS, aux_in=None):
+def linear_tn_raw(x, w, bias=None, epilogue=C.EPI_BIAS, aux_in=None, f32=False):
     """One lvl_linear_tn call on bf16 tensors: y[M,N] = epilogue(x[M,K] . w[N,K]^T).
-    Returns y (EPI_BIAS), (y, u) (EPI_BIAS_QUICKGELU) or (y, colsum) (EPI_QUICKGELU_BWD)."""
+    Returns y (EPI_BIAS), (y, u) (EPI_BIAS_QUICKGELU) or (y, colsum) (EPI_QUICKGELU_BWD).
+    f32=True: the kernel's f32-class mode -- x, w are bf16 term images (split3), y / u / aux_in float32."""
     C.require_device(x, w, bias, aux_in)
     M, K = x.shape
     N = w.shape[0]
-    y = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
+    y = torch.empty(M, N, dtype=torch.float32 if f32 else torch.bfloat16, device=x.device)
     aux_out = colsum = ws = None
     if epilogue == C.EPI_BIAS_QUICKGELU:
         aux_out = torch.empty_like(y)
@@ -338,8 +417,8 @@ def linear_tn_raw(x, w, bias=None, epilogue=C.EPI_BIAS, aux_in=None):
         colsum = torch.empty(N, dtype=torch.float32, device=x.device)
         ws = C.workspace('linear_tn', M, N, x.device)
     C.check(C.lib().lvl_linear_tn(C.ptr(x), C.ptr(w), C.ptr(bias), C.ptr(y), C.ptr(aux_out), C.ptr(aux_in),
-                                  C.ptr(colsum), C.ptr(ws), C.ptr(sched_block(x.device)), M, N, K, epilogue, C.LVL_BF16,
-                                  C.stream_ptr()), 'lvl_linear_tn')
+                                  C.ptr(colsum), C.ptr(ws), C.ptr(sched_block(x.device)), M, N, K, epilogue,
+                                  C.LVL_F32 if f32 else C.LVL_BF16, C.stream_ptr()), 'lvl_linear_tn')
     if epilogue == C.EPI_BIAS_QUICKGELU:
         return y, aux_out
     if epilogue == C.EPI_QUICKGELU_BWD:
@@ -356,6 +435,12 @@ def linear_skinny_raw(x, w, bias=None, act=None):
     C.check(C.lib().lvl_linear_skinny(C.ptr(x), C.ptr(w), C.ptr(bias), C.ptr(y), M, w.shape[0], K,
                                       -1 if act is None else act, C.stream_ptr()), 'lvl_linear_skinny')
     return y
+
+
+def project(x, proj):
+    """x @ proj for the [width, embed_dim] projection parameters (models.py:146,161): the Linear kernels against the
+    transposed view (its gradient flows back to `proj` through the view)."""
+    return linear(x, proj.t())
 
 
 def linear(x, weight, bias=None):

@@ -213,3 +213,17 @@ def test_narrator_decoder_oracle_matches_reference(variant):
             ids, ppl = O.narrator_generate_greedy(img.repeat_interleave(2, dim=0), eos=v['eos'], max_text_length=8, **kw)
             assert torch.equal(ids, v['rep_ids'])
             torch.testing.assert_close(ppl, v['rep_ppl'], atol=0, rtol=2e-4)
+
+
+def test_bench_generator_equals_the_oracles():
+    """bench.py carries its own synthetic-batch generator (the product bench does not import oracle/ for its inputs);
+    it must produce exactly the batches the parity tests draw from oracle.synthetic_batch."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location('bench_module', os.path.join(os.path.dirname(__file__), '..', 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for args in [(3, 2, 32, 7), (2, 4, 48, 1234)]:
+        v0, t0 = O.synthetic_batch(*args[:3], seed=args[3])
+        v1, t1 = bench.synthetic_batch(*args[:3], seed=args[3])
+        assert torch.equal(v0, v1) and torch.equal(t0, t1)
