@@ -348,6 +348,13 @@ def main():
         else:
             dist.init_process_group(backend)
             rehearsal = f'REHEARSAL: {world} ranks on {ndev} device(s) over {backend} -- not a scaling measurement'
+            # Ranks that SHARE a device keep both towers on one stream: with the text tower on a second HIP stream each
+            # process owns two compute queues, and a queue waiting for an event of its sibling burns whole time slices of
+            # the hardware scheduler while the other process holds the device -- single steps then take 3-20 s at
+            # random (profiles/r04_2rank_rehearsal_bisect.json: 8523 ms / step with, 185 ms without; the caption trim and
+            # the tile counters make no difference). One process per device (every real run) is unaffected.
+            os.environ.setdefault('LAVILA_TEXT_STREAM', '0')
+            rehearsal += '; ranks share a device: both towers on one stream (LAVILA_TEXT_STREAM=0)'
 
     if args.workload == 'narrator':
         if args.batch == 256:

@@ -128,6 +128,17 @@ int lvl_divided_attn_bwd(const void* qkv, const void* out, const void* dout, con
  * backward), 0 if it falls to the shape-generic kernels (any shape, correct, much slower). mode: LVL_ATTN_SPACE /
  * LVL_ATTN_TIME with (F, N, H), or LVL_ATTN_CAUSAL with N = L. The Python layer logs one warning per slow shape. */
 int lvl_attention_fast_path(int mode, int F, int N, int H);
+/* The same query for FLOAT32 tensors (the parity configuration, north_star "within 1e-3 fp32"): 1 if the call runs on
+ * the f32-class instantiations of the fast kernels -- the MFMA kernels with every operand as hi/lo bf16 images and three
+ * MFMAs per product (space groups up to 272 / 288 keys forward / backward, causal text up to 272 / 256 tokens), the
+ * register-tiled time kernels with float32 rows (1-4, 8, 16 frames) -- 0 if it falls to the shape-generic kernels.
+ * lvl_debug_f32_generic(1) (or LAVILA_F32_GENERIC=1 in the environment) sends every float32 attention call to the
+ * generic kernels: the A/B switch of the parity tests. */
+int lvl_attention_fast_path_f32(int mode, int F, int N, int H);
+int lvl_debug_f32_generic(int on);
+/* Test hook: how many lvl_divided_attn_* / lvl_causal_attn_* calls of this process were served by the shape-generic
+ * kernels so far (reset != 0: read and clear). */
+int lvl_debug_generic_attention_calls(int reset);
 
 /* ---- causal self-attention core of the text tower -------------------------------------------------------
  * nn.MultiheadAttention core with the additive causal mask (openai_model.py:196-198,

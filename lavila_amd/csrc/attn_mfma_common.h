@@ -71,59 +71,226 @@ __device__ __forceinline__ uint2 tile_frag_tr(const uint16_t* img, int tile, int
   return __builtin_bit_cast(uint2, v);
 }
 
-// Cooperative staging of two row sets A and B (`nrows` rows of 64 bf16 each) into swizzled row-major images;
+// ---------------------------------------------------------------------------------------------------------------
+// Precision policies. Every MFMA attention kernel is a template over one of them; the kernel text -- group decode,
+// staging order, tile loops, masks, softmax, cls handling, stores -- is shared, only the operand plumbing differs.
+//   PrecBf16   the benched path: bf16 tensors, one bf16 LDS image per operand, one MFMA per product.
+//   PrecSplit  the f32-class path (the parity configuration: float32 tensors, north_star "within 1e-3 fp32"): every
+//              operand x is carried as TWO bf16 images h = bf16(x), l = bf16(x - h) (x = h + l to 2^-18 |x|), the lo
+//              image `lo_off` elements behind the hi image in LDS, and every product is three MFMAs into the same f32
+//              accumulator: l.h' + h.l' + h.h' (~2^-17 relative per product, the partial products exact). Probabilities
+//              and score gradients, computed in f32 registers, are split the same way before they become operands.
+//              Inputs and outputs are float32.
+// ---------------------------------------------------------------------------------------------------------------
+struct Op2 { uint4 h, l; };      // split operand: 8 contraction elements, hi and lo parts
+struct Tr2 { uint2 h, l; };      // split half operand from a transpose read (4 elements)
+struct Raw2 { float4 a, b; };    // 8 consecutive float32 channels as loaded from HBM
+
+__device__ __forceinline__ f32x4 mfma(const Op2& a, const Op2& b, f32x4 c) {
+  c = mfma(a.l, b.h, c);           // small terms first
+  c = mfma(a.h, b.l, c);
+  return mfma(a.h, b.h, c);
+}
+
+__device__ __forceinline__ void split8(const float (&x)[8], uint4& h, uint4& l) {
+  float r[8];
+  uint32_t hw[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    hw[i] = f32x2_to_bf16x2(x[2 * i], x[2 * i + 1]);
+    r[2 * i] = x[2 * i] - __uint_as_float(hw[i] << 16);
+    r[2 * i + 1] = x[2 * i + 1] - __uint_as_float(hw[i] & 0xffff0000u);
+  }
+  h = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+  l = make_uint4(f32x2_to_bf16x2(r[0], r[1]), f32x2_to_bf16x2(r[2], r[3]), f32x2_to_bf16x2(r[4], r[5]),
+                 f32x2_to_bf16x2(r[6], r[7]));
+}
+
+struct PrecBf16 {
+  static constexpr bool kSplit = false;
+  static constexpr int kImages = 1;       // LDS images per staged operand
+  using io_t = uint16_t;
+  using Op = uint4;
+  using Tr = uint2;
+  using Raw = uint4;
+  static __device__ __forceinline__ Raw load_raw(const io_t* p) { return *reinterpret_cast<const uint4*>(p); }
+  static __device__ __forceinline__ Raw zero_raw() { return make_uint4(0, 0, 0, 0); }
+  static __device__ __forceinline__ Op op_of(const Raw& r) { return r; }
+  static __device__ __forceinline__ Op load_op(const io_t* p) { return *reinterpret_cast<const uint4*>(p); }
+  static __device__ __forceinline__ Op zero_op() { return make_uint4(0, 0, 0, 0); }
+  static __device__ __forceinline__ void stage(uint16_t* img, int, int off, const Raw& r) {
+    *reinterpret_cast<uint4*>(img + off) = r;
+  }
+  static __device__ __forceinline__ Op tile_op(const uint16_t* img, int, int tile, int off) {
+    return tile_frag(img, tile, off);
+  }
+  static __device__ __forceinline__ Tr tile_tr(const uint16_t* img, int, int tile, int off) {
+    return tile_frag_tr(img, tile, off);
+  }
+  static __device__ __forceinline__ Tr zero_tr() { return make_uint2(0, 0); }
+  static __device__ __forceinline__ Op join(const Tr& lo, const Tr& hi) { return make_uint4(lo.x, lo.y, hi.x, hi.y); }
+  // 8 f32 values (a: contraction elements 0..3, b: 4..7) -> operand; A = float[4] or f32x4
+  template <typename A>
+  static __device__ __forceinline__ Op pack(const A& a, const A& b) {
+    return make_uint4(pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]), pack_bf16x2(b[2], b[3]));
+  }
+  template <typename A>
+  static __device__ __forceinline__ Op pack_lo(const A& a) {          // elements 4..7 zero
+    return make_uint4(pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), 0u, 0u);
+  }
+  static __device__ __forceinline__ void to_f32(const Op& o, float (&v)[8]) {
+    Elem<bf16_t>::load8(reinterpret_cast<const bf16_t*>(&o), v);
+  }
+  static __device__ __forceinline__ float to_f32_1(io_t v) { return bf16_to_f32(v); }
+  static __device__ __forceinline__ io_t from_f32(float v) { return f32_to_bf16(v); }
+  static __device__ __forceinline__ void store4(io_t* p, float a, float b, float c, float d) {
+    *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, d));
+  }
+};
+
+struct PrecSplit {
+  static constexpr bool kSplit = true;
+  static constexpr int kImages = 2;
+  using io_t = float;
+  using Op = Op2;
+  using Tr = Tr2;
+  using Raw = Raw2;
+  static __device__ __forceinline__ Raw load_raw(const io_t* p) {
+    return Raw2{*reinterpret_cast<const float4*>(p), *reinterpret_cast<const float4*>(p + 4)};
+  }
+  static __device__ __forceinline__ Raw zero_raw() { return Raw2{make_float4(0, 0, 0, 0), make_float4(0, 0, 0, 0)}; }
+  static __device__ __forceinline__ Op op_of(const Raw& r) {
+    const float x[8] = {r.a.x, r.a.y, r.a.z, r.a.w, r.b.x, r.b.y, r.b.z, r.b.w};
+    Op2 o;
+    split8(x, o.h, o.l);
+    return o;
+  }
+  static __device__ __forceinline__ Op load_op(const io_t* p) { return op_of(load_raw(p)); }
+  static __device__ __forceinline__ Op zero_op() { return Op2{make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)}; }
+  static __device__ __forceinline__ void stage(uint16_t* img, int lo_off, int off, const Raw& r) {
+    const Op2 o = op_of(r);
+    *reinterpret_cast<uint4*>(img + off) = o.h;
+    *reinterpret_cast<uint4*>(img + lo_off + off) = o.l;
+  }
+  static __device__ __forceinline__ Op tile_op(const uint16_t* img, int lo_off, int tile, int off) {
+    return Op2{tile_frag(img, tile, off), tile_frag(img + lo_off, tile, off)};
+  }
+  static __device__ __forceinline__ Tr tile_tr(const uint16_t* img, int lo_off, int tile, int off) {
+    return Tr2{tile_frag_tr(img, tile, off), tile_frag_tr(img + lo_off, tile, off)};
+  }
+  static __device__ __forceinline__ Tr zero_tr() { return Tr2{make_uint2(0, 0), make_uint2(0, 0)}; }
+  static __device__ __forceinline__ Op join(const Tr& lo, const Tr& hi) {
+    return Op2{make_uint4(lo.h.x, lo.h.y, hi.h.x, hi.h.y), make_uint4(lo.l.x, lo.l.y, hi.l.x, hi.l.y)};
+  }
+  template <typename A>
+  static __device__ __forceinline__ Op pack(const A& a, const A& b) {
+    const float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    Op2 o;
+    split8(x, o.h, o.l);
+    return o;
+  }
+  template <typename A>
+  static __device__ __forceinline__ Op pack_lo(const A& a) {
+    const float x[8] = {a[0], a[1], a[2], a[3], 0.f, 0.f, 0.f, 0.f};
+    Op2 o;
+    split8(x, o.h, o.l);
+    return o;
+  }
+  static __device__ __forceinline__ void to_f32(const Op& o, float (&v)[8]) {
+    float hv[8], lv[8];
+    Elem<bf16_t>::load8(reinterpret_cast<const bf16_t*>(&o.h), hv);
+    Elem<bf16_t>::load8(reinterpret_cast<const bf16_t*>(&o.l), lv);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = hv[i] + lv[i];
+  }
+  static __device__ __forceinline__ float to_f32_1(io_t v) { return v; }
+  static __device__ __forceinline__ io_t from_f32(float v) { return v; }
+  static __device__ __forceinline__ void store4(io_t* p, float a, float b, float c, float d) {
+    *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+  }
+};
+
+// Cooperative staging of two row sets A and B (`nrows` rows of 64 channels each) into swizzled row-major images
+// (PrecSplit: hi and lo image each, the lo image lo_off elements behind);
 // rows in [nrows, rows_pad) are zero-filled. NT threads, 8 lanes per row, MAXP >= ceil(rows_pad / (NT/8))
 // passes. Row r of set X lives at pX + r * strideX (elements), except row 0 when p0X != nullptr (the cls token
 // in front of a frame's patch rows). One pointer per thread + a constant stride per pass keeps the address
 // arithmetic out of the way, and ALL global loads are issued before the first LDS write so that the passes
 // overlap in flight instead of paying one HBM latency each.
-template <int NT, int MAXP>
-__device__ __forceinline__ void stage_rows2(uint16_t* imgA, const uint16_t* pA, size_t strideA, const uint16_t* p0A,
-                                            uint16_t* imgB, const uint16_t* pB, size_t strideB, const uint16_t* p0B,
-                                            int rows_pad, int nrows, int tid) {
+template <typename P, int NT, int MAXP>
+__device__ __forceinline__ void stage_rows2(uint16_t* imgA, const typename P::io_t* pA, size_t strideA,
+                                            const typename P::io_t* p0A, uint16_t* imgB, const typename P::io_t* pB,
+                                            size_t strideB, const typename P::io_t* p0B, int rows_pad, int nrows,
+                                            int tid, int lo_off) {
+  using io_t = typename P::io_t;
   constexpr int RPP = NT / 8;
   const int c8 = tid & 7, r_in = tid >> 3;
-  const uint16_t* ra = pA + (size_t)r_in * strideA + c8 * 8;
-  const uint16_t* rb = pB + (size_t)r_in * strideB + c8 * 8;
-  uint4 va[MAXP], vb[MAXP];
+  const io_t* ra = pA + (size_t)r_in * strideA + c8 * 8;
+  const io_t* rb = pB + (size_t)r_in * strideB + c8 * 8;
+  typename P::Raw va[MAXP], vb[MAXP];
 #pragma unroll
   for (int p = 0; p < MAXP; ++p) {
     const int r = p * RPP + r_in;
     const bool first = p == 0 && r_in == 0;
-    const uint16_t* sa = (first && p0A != nullptr) ? p0A + c8 * 8 : ra + (size_t)p * RPP * strideA;
-    const uint16_t* sb = (first && p0B != nullptr) ? p0B + c8 * 8 : rb + (size_t)p * RPP * strideB;
-    va[p] = make_uint4(0, 0, 0, 0);
-    vb[p] = make_uint4(0, 0, 0, 0);
+    const io_t* sa = (first && p0A != nullptr) ? p0A + c8 * 8 : ra + (size_t)p * RPP * strideA;
+    const io_t* sb = (first && p0B != nullptr) ? p0B + c8 * 8 : rb + (size_t)p * RPP * strideB;
+    va[p] = P::zero_raw();
+    vb[p] = P::zero_raw();
     if (r < nrows) {
-      va[p] = *reinterpret_cast<const uint4*>(sa);
-      vb[p] = *reinterpret_cast<const uint4*>(sb);
+      va[p] = P::load_raw(sa);
+      vb[p] = P::load_raw(sb);
     }
   }
 #pragma unroll
   for (int p = 0; p < MAXP; ++p) {
     const int r = p * RPP + r_in;
     if (r < rows_pad) {
-      *reinterpret_cast<uint4*>(imgA + img_off(r, c8)) = va[p];
-      *reinterpret_cast<uint4*>(imgB + img_off(r, c8)) = vb[p];
+      P::stage(imgA, lo_off, img_off(r, c8), va[p]);
+      P::stage(imgB, lo_off, img_off(r, c8), vb[p]);
     }
   }
 }
 
-// writes a 16x64 f32 tile held in the MFMA C layout (o[dt][r] = X[row g*4+r][col dt*16+c]) as bf16 rows:
-// row i of the tile goes to dst(i) (64 contiguous bf16) if valid(i). Per-wave LDS scratch `ot` ([16][OS]).
-template <typename DstFn, typename ValidFn>
+// writes a 16x64 f32 tile held in the MFMA C layout (o[dt][r] = X[row g*4+r][col dt*16+c]) as rows of the tensor's
+// element type: row i of the tile goes to dst(i) (64 contiguous elements) if valid(i). bf16: through the per-wave LDS
+// scratch `ot` ([16][OS] bf16) into 16-byte row pieces; float32 (PrecSplit): the same transposition with the scratch
+// read as [16][OS/2] floats is not needed -- a lane holds 4 rows x 1 column per dt, so it goes through `ot` as f32 in
+// two halves of 8 rows.
+template <typename P, typename DstFn, typename ValidFn>
 __device__ __forceinline__ void store_tile_rows(uint16_t* ot, const f32x4 (&o)[4], float mul, int lane, DstFn dst,
                                                 ValidFn valid) {
   const int c = lane & 15, g = lane >> 4;
+  if constexpr (!P::kSplit) {
 #pragma unroll
-  for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) ot[(g * 4 + r) * OS + dt * 16 + c] = f32_to_bf16(o[dt][r] * mul);
+      for (int dt = 0; dt < 4; ++dt) ot[(g * 4 + r) * OS + dt * 16 + c] = f32_to_bf16(o[dt][r] * mul);
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int row = (lane >> 3) + 8 * k, ch = lane & 7;
-    const uint4 v = *reinterpret_cast<const uint4*>(ot + row * OS + ch * 8);
-    if (valid(row)) *reinterpret_cast<uint4*>(dst(row) + ch * 8) = v;
+    for (int k = 0; k < 2; ++k) {
+      const int row = (lane >> 3) + 8 * k, ch = lane & 7;
+      const uint4 v = *reinterpret_cast<const uint4*>(ot + row * OS + ch * 8);
+      if (valid(row)) *reinterpret_cast<uint4*>(dst(row) + ch * 8) = v;
+    }
+  } else {
+    // the [16][OS] bf16 scratch holds 8 rows of 64 floats (stride OS floats = 288 B): rows g*4+r with (g*4+r) & 8 == hh
+    float* of = reinterpret_cast<float*>(ot);
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      if ((g >> 1) == hh) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) of[((g & 1) * 4 + r) * OS + dt * 16 + c] = o[dt][r] * mul;
+      }
+      // same wave wrote and reads (LDS operations of one wave complete in order)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int lr = (lane >> 4) + 4 * k, ch = lane & 15;          // 16 lanes x 4 floats per row
+        const float4 v = *reinterpret_cast<const float4*>(of + lr * OS + ch * 4);
+        const int row = hh * 8 + lr;
+        if (valid(row)) *reinterpret_cast<float4*>(dst(row) + ch * 4) = v;
+      }
+    }
   }
 }
 

@@ -18,6 +18,8 @@
 //               query's rank-1 contributions to dK/dV (it attends to every key, timesformer.py:116-119) and
 //               accumulates d(cls q) and d(cls k,v) -- which receive gradient from every frame -- with f32
 //               atomics into a workspace finalised by a tiny kernel.
+// PRECISION POLICY (template P, attn_mfma_common.h): PrecBf16 = the benched kernels; PrecSplit = the same kernel text on
+// float32 tensors, operands as hi/lo bf16 images, 3 MFMAs per product (f32-class: what the parity configuration runs).
 #include "attn_mfma_common.h"
 
 namespace {
@@ -29,23 +31,29 @@ constexpr float kExp2 = 0.125f * kLog2e;          // exp(s * scale) = exp2(s * k
 // ------------------------------------------------------------------------------------------------------------
 // dQ kernel
 // ------------------------------------------------------------------------------------------------------------
-template <int NKT, int NW> struct DqLds {
+template <int NKT, int NW, int IMAGES = 1> struct DqLds {
   static constexpr int KROWS = NKT * 16;
   static constexpr int ks_off = 0;
   static constexpr int vs_off = ks_off + KROWS * RS * 2;
-  static constexpr int ot_off = vs_off + KROWS * RS * 2;
+  static constexpr int lo_off = 2 * KROWS * RS;                 // elements, hi image -> lo image (PrecSplit)
+  static constexpr int ot_off = IMAGES * (vs_off + KROWS * RS * 2);
   static constexpr int total = ot_off + NW * 16 * OS * 2;
 };
 
 // NW = 8 waves (two workgroups per CU) up to 272 keys; NW = 4 (one workgroup per CU, one wave per SIMD) for the
 // large groups whose K and V images fill the LDS (TSF-L/14 at 336: 577 keys). MASKALL: NKT is an upper bound of the
 // tile count, every tile is masked against nkeys.
-template <int NKT, bool TEXT, int NW, bool MASKALL>
-__global__ __launch_bounds__(NW * 64, (NW == 4 ? 1 : (NKT <= 13 ? 4 : 2))) void space_bwd_dq_kernel(
-    const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out, const uint16_t* __restrict__ dout,
-    const float* __restrict__ lse, uint16_t* __restrict__ dqkv, float* __restrict__ delta, int F, int N, int H) {
+template <typename P, int NKT, bool TEXT, int NW, bool MASKALL>
+__global__ __launch_bounds__(NW * 64, (NW == 4 ? 1 : ((NKT <= 13 && !P::kSplit) ? 4 : 2))) void space_bwd_dq_kernel(
+    const typename P::io_t* __restrict__ qkv, const typename P::io_t* __restrict__ out,
+    const typename P::io_t* __restrict__ dout, const float* __restrict__ lse, typename P::io_t* __restrict__ dqkv,
+    float* __restrict__ delta, int F, int N, int H) {
+  using io_t = typename P::io_t;
+  using Op = typename P::Op;
+  using Tr = typename P::Tr;
   constexpr int NT = NW * 64;
-  using L = DqLds<NKT, NW>;
+  using L = DqLds<NKT, NW, P::kImages>;
+  constexpr int LO = L::lo_off;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint16_t* Ks = reinterpret_cast<uint16_t*>(smem + L::ks_off);
   uint16_t* Vs = reinterpret_cast<uint16_t*>(smem + L::vs_off);
@@ -55,35 +63,35 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 1 : (NKT <= 13 ? 4 : 2))) void 
   const int h = blockIdx.x % H, f = (blockIdx.x / H) % F, b = blockIdx.x / (H * F);
   const int D = H * 64, T = TEXT ? N : 1 + F * N, nkeys = TEXT ? N : N + 1, tok0 = TEXT ? 0 : 1 + f * N;
   const size_t ts = (size_t)3 * D;
-  const uint16_t* base = qkv + (size_t)b * T * ts + h * 64;
-  const uint16_t* obase = out + (size_t)b * T * D + h * 64;
-  const uint16_t* dobase = dout + (size_t)b * T * D + h * 64;
+  const io_t* base = qkv + (size_t)b * T * ts + h * 64;
+  const io_t* obase = out + (size_t)b * T * D + h * 64;
+  const io_t* dobase = dout + (size_t)b * T * D + h * 64;
 
   // fragments of this wave's first query tile: issued before the staging so that both are in flight together
   const int c = lane & 15, g = lane >> 4;
   auto tok_of = [&](int qt) { const int qr = qt * 16 + c; return tok0 + (qr < N ? qr : N - 1); };
-  uint4 nq0, nq1, ng0, ng1, ny0, ny1;
+  Op nq0, nq1, ng0, ng1, ny0, ny1;
   auto load_frags = [&](int qt) {
     const int tk = tok_of(qt);
-    const uint16_t* qp = base + (size_t)tk * ts + g * 8;
-    nq0 = *reinterpret_cast<const uint4*>(qp); nq1 = *reinterpret_cast<const uint4*>(qp + 32);
-    ng0 = *reinterpret_cast<const uint4*>(dobase + (size_t)tk * D + g * 8);
-    ng1 = *reinterpret_cast<const uint4*>(dobase + (size_t)tk * D + g * 8 + 32);
-    ny0 = *reinterpret_cast<const uint4*>(obase + (size_t)tk * D + g * 8);
-    ny1 = *reinterpret_cast<const uint4*>(obase + (size_t)tk * D + g * 8 + 32);
+    const io_t* qp = base + (size_t)tk * ts + g * 8;
+    nq0 = P::load_op(qp); nq1 = P::load_op(qp + 32);
+    ng0 = P::load_op(dobase + (size_t)tk * D + g * 8);
+    ng1 = P::load_op(dobase + (size_t)tk * D + g * 8 + 32);
+    ny0 = P::load_op(obase + (size_t)tk * D + g * 8);
+    ny1 = P::load_op(obase + (size_t)tk * D + g * 8 + 32);
   };
   load_frags(wave * 16 < N ? wave : 0);
 
   {   // key row r = token tok0 + r - 1 (r >= 1) or the cls token (r = 0); text: token r
-    const uint16_t* krow0 = base + (size_t)(TEXT ? 0 : tok0 - 1) * ts + D;
+    const io_t* krow0 = base + (size_t)(TEXT ? 0 : tok0 - 1) * ts + D;
     constexpr int RPP = NT / 8, GROUP = 8 * RPP;        // at most 8 passes (16 loads per thread) in flight
     constexpr int MAXP = (L::KROWS < GROUP ? L::KROWS + RPP - 1 : GROUP) / RPP;
 #pragma unroll 1
     for (int r0 = 0; r0 < L::KROWS; r0 += GROUP) {
       const int pad = L::KROWS - r0 < GROUP ? L::KROWS - r0 : GROUP;
-      stage_rows2<NT, MAXP>(Ks + r0 * RS, krow0 + (size_t)r0 * ts, ts, (TEXT || r0 != 0) ? nullptr : base + D,
-                            Vs + r0 * RS, krow0 + D + (size_t)r0 * ts, ts, (TEXT || r0 != 0) ? nullptr : base + 2 * D,
-                            pad, nkeys - r0, tid);
+      stage_rows2<P, NT, MAXP>(Ks + r0 * RS, krow0 + (size_t)r0 * ts, ts, (TEXT || r0 != 0) ? nullptr : base + D,
+                               Vs + r0 * RS, krow0 + D + (size_t)r0 * ts, ts,
+                               (TEXT || r0 != 0) ? nullptr : base + 2 * D, pad, nkeys - r0, tid, LO);
     }
   }
   __syncthreads();
@@ -94,17 +102,17 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 1 : (NKT <= 13 ? 4 : 2))) void 
   for (int qt = wave; qt * 16 < N; qt += NW) {
     const int qrow = qt * 16 + c;
     const int tok = tok_of(qt);
-    const uint4 q0 = nq0, q1 = nq1, g0 = ng0, g1 = ng1;
+    const Op q0 = nq0, q1 = nq1, g0 = ng0, g1 = ng1;
     float dl;
     {
       float a[8], bb[8];
-      Elem<bf16_t>::load8(reinterpret_cast<const bf16_t*>(&ng0), a);
-      Elem<bf16_t>::load8(reinterpret_cast<const bf16_t*>(&ny0), bb);
+      P::to_f32(ng0, a);
+      P::to_f32(ny0, bb);
       dl = 0.f;
 #pragma unroll
       for (int i = 0; i < 8; ++i) dl = fmaf(a[i], bb[i], dl);
-      Elem<bf16_t>::load8(reinterpret_cast<const bf16_t*>(&ng1), a);
-      Elem<bf16_t>::load8(reinterpret_cast<const bf16_t*>(&ny1), bb);
+      P::to_f32(ng1, a);
+      P::to_f32(ny1, bb);
 #pragma unroll
       for (int i = 0; i < 8; ++i) dl = fmaf(a[i], bb[i], dl);
       dl += __shfl_xor(dl, 16, 64);
@@ -117,24 +125,24 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 1 : (NKT <= 13 ? 4 : 2))) void 
 
     // Key tiles in pairs: S^T = K.Q^T and dP^T = V.dO^T (four independent accumulate chains per pair), then
     // dS^T packed straight into the A fragment of the dQ contraction -- the f32 tiles never pile up.
-    uint4 pa[(NKT + 1) / 2];
+    Op pa[(NKT + 1) / 2];
 #pragma unroll
     for (int j = 0; j < (NKT + 1) / 2; ++j) {
       constexpr int last = NKT - 1;
       const int k0 = 2 * j, k1 = 2 * j + 1 <= last ? 2 * j + 1 : last;
       const bool two = 2 * j + 1 <= last;
       f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
-      s0 = mfma(tile_frag(Ks, k0, fo.a[0]), q0, s0);
-      p0 = mfma(tile_frag(Vs, k0, fo.a[0]), g0, p0);
+      s0 = mfma(P::tile_op(Ks, LO, k0, fo.a[0]), q0, s0);
+      p0 = mfma(P::tile_op(Vs, LO, k0, fo.a[0]), g0, p0);
       if (two) {
-        s1 = mfma(tile_frag(Ks, k1, fo.a[0]), q0, s1);
-        p1 = mfma(tile_frag(Vs, k1, fo.a[0]), g0, p1);
+        s1 = mfma(P::tile_op(Ks, LO, k1, fo.a[0]), q0, s1);
+        p1 = mfma(P::tile_op(Vs, LO, k1, fo.a[0]), g0, p1);
       }
-      s0 = mfma(tile_frag(Ks, k0, fo.a[1]), q1, s0);
-      p0 = mfma(tile_frag(Vs, k0, fo.a[1]), g1, p0);
+      s0 = mfma(P::tile_op(Ks, LO, k0, fo.a[1]), q1, s0);
+      p0 = mfma(P::tile_op(Vs, LO, k0, fo.a[1]), g1, p0);
       if (two) {
-        s1 = mfma(tile_frag(Ks, k1, fo.a[1]), q1, s1);
-        p1 = mfma(tile_frag(Vs, k1, fo.a[1]), g1, p1);
+        s1 = mfma(P::tile_op(Ks, LO, k1, fo.a[1]), q1, s1);
+        p1 = mfma(P::tile_op(Vs, LO, k1, fo.a[1]), g1, p1);
       }
       float d0[4], d1[4];
 #pragma unroll
@@ -153,8 +161,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 1 : (NKT <= 13 ? 4 : 2))) void 
         d0[r] = e0 * (p0[r] - dl);
         d1[r] = two ? e1 * (p1[r] - dl) : 0.f;
       }
-      pa[j] = make_uint4(pack_bf16x2(d0[0], d0[1]), pack_bf16x2(d0[2], d0[3]), pack_bf16x2(d1[0], d1[1]),
-                         pack_bf16x2(d1[2], d1[3]));
+      pa[j] = P::pack(d0, d1);
     }
     // dQ = dS . K: B fragments are transpose reads of the K image (4 consecutive keys per half)
     f32x4 o[4];
@@ -165,13 +172,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 1 : (NKT <= 13 ? 4 : 2))) void 
       constexpr int last = NKT - 1;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        const uint2 lo = tile_frag_tr(Ks, 2 * j, fo.tr[dt]);
-        uint2 hi = make_uint2(0, 0);
-        if (2 * j + 1 <= last) hi = tile_frag_tr(Ks, 2 * j + 1, fo.tr[dt]);
-        o[dt] = mfma(pa[j], make_uint4(lo.x, lo.y, hi.x, hi.y), o[dt]);
+        const Tr lo = P::tile_tr(Ks, LO, 2 * j, fo.tr[dt]);
+        Tr hi = P::zero_tr();
+        if (2 * j + 1 <= last) hi = P::tile_tr(Ks, LO, 2 * j + 1, fo.tr[dt]);
+        o[dt] = mfma(pa[j], P::join(lo, hi), o[dt]);
       }
     }
-    store_tile_rows(ot, o, 0.125f, lane,
+    store_tile_rows<P>(ot, o, 0.125f, lane,
                     [&](int row) { return dqkv + (size_t)b * T * ts + (size_t)(tok0 + qt * 16 + row) * ts + h * 64; },
                     [&](int row) { return qt * 16 + row < N; });
   }
@@ -183,14 +190,16 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 1 : (NKT <= 13 ? 4 : 2))) void 
 struct DkvGeom {
   int QROWS;                                                     // queries padded to a multiple of 32
   int qs_off, dos_off, lse_off, del_off, vec_off, ot_off, total;  // bytes
+  int lo_off;                                                    // ELEMENTS from a hi image to its lo image (PrecSplit)
 };
 
-inline DkvGeom dkv_geometry(int N, int nw = 8) {
+inline DkvGeom dkv_geometry(int N, int nw = 8, int images = 1) {
   DkvGeom g{};
   g.QROWS = (N + 31) / 32 * 32;
   g.qs_off = 0;
   g.dos_off = g.qs_off + g.QROWS * RS * 2;
-  g.lse_off = g.dos_off + g.QROWS * RS * 2;
+  g.lo_off = 2 * g.QROWS * RS;
+  g.lse_off = images * (g.dos_off + g.QROWS * RS * 2);
   g.del_off = g.lse_off + g.QROWS * 4;
   g.vec_off = g.del_off + g.QROWS * 4;          // f32: qc[64], doc[64], dqc[64], scalars[8]
   g.ot_off = g.vec_off + (3 * 64 + 8) * 4;
@@ -198,11 +207,15 @@ inline DkvGeom dkv_geometry(int N, int nw = 8) {
   return g;
 }
 
-template <bool TEXT, int NW>
-__global__ __launch_bounds__(NW * 64, (NW == 4 ? 1 : 4)) void space_bwd_dkv_kernel(
-    const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out, const uint16_t* __restrict__ dout,
-    const float* __restrict__ lse, const float* __restrict__ delta, uint16_t* __restrict__ dqkv,
-    float* __restrict__ atom_ws, int F, int N, int H, DkvGeom G) {
+template <typename P, bool TEXT, int NW>
+__global__ __launch_bounds__(NW * 64, (NW == 4 ? 1 : (P::kSplit ? 2 : 4))) void space_bwd_dkv_kernel(
+    const typename P::io_t* __restrict__ qkv, const typename P::io_t* __restrict__ out,
+    const typename P::io_t* __restrict__ dout, const float* __restrict__ lse, const float* __restrict__ delta,
+    typename P::io_t* __restrict__ dqkv, float* __restrict__ atom_ws, int F, int N, int H, DkvGeom G) {
+  using io_t = typename P::io_t;
+  using Op = typename P::Op;
+  using Tr = typename P::Tr;
+  const int LO = G.lo_off;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint16_t* Qs = reinterpret_cast<uint16_t*>(smem + G.qs_off);
   uint16_t* dOs = reinterpret_cast<uint16_t*>(smem + G.dos_off);
@@ -220,24 +233,24 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 1 : 4)) void space_bwd_dkv_kern
   const int D = H * 64, T = TEXT ? N : 1 + F * N, nkeys = TEXT ? N : N + 1, tok0 = TEXT ? 0 : 1 + f * N;
   const int QROWS = G.QROWS;
   const size_t ts = (size_t)3 * D;
-  const uint16_t* base = qkv + (size_t)b * T * ts + h * 64;
-  const uint16_t* dobase = dout + (size_t)b * T * D + h * 64;
+  const io_t* base = qkv + (size_t)b * T * ts + h * 64;
+  const io_t* dobase = dout + (size_t)b * T * D + h * 64;
   const float* lrow = lse + ((size_t)b * H + h) * T;
   const float* drow = delta + ((size_t)b * H + h) * T;
   const int c = lane & 15, g = lane >> 4;
   const int nkt = (nkeys + 15) / 16;
 
   // K/V fragments of this wave's first key tile: issued before the staging
-  uint4 nk0, nk1, nv0, nv1;
+  Op nk0, nk1, nv0, nv1;
   auto load_kv = [&](int kt) {
     const int krow = kt * 16 + c;
-    nk0 = make_uint4(0, 0, 0, 0); nk1 = nk0; nv0 = nk0; nv1 = nk0;
+    nk0 = P::zero_op(); nk1 = nk0; nv0 = nk0; nv1 = nk0;
     if (krow < nkeys) {
-      const uint16_t* kp = base + (size_t)(TEXT ? krow : (krow == 0 ? 0 : tok0 + krow - 1)) * ts + D + g * 8;
-      nk0 = *reinterpret_cast<const uint4*>(kp);
-      nk1 = *reinterpret_cast<const uint4*>(kp + 32);
-      nv0 = *reinterpret_cast<const uint4*>(kp + D);
-      nv1 = *reinterpret_cast<const uint4*>(kp + D + 32);
+      const io_t* kp = base + (size_t)(TEXT ? krow : (krow == 0 ? 0 : tok0 + krow - 1)) * ts + D + g * 8;
+      nk0 = P::load_op(kp);
+      nk1 = P::load_op(kp + 32);
+      nv0 = P::load_op(kp + D);
+      nv1 = P::load_op(kp + D + 32);
     }
   };
   load_kv(wave < nkt ? wave : 0);
@@ -247,8 +260,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 1 : 4)) void space_bwd_dkv_kern
 #pragma unroll 1
     for (int r0 = 0; r0 < QROWS; r0 += GROUP) {
       const int pad = QROWS - r0 < GROUP ? QROWS - r0 : GROUP;
-      stage_rows2<NT, 4>(Qs + r0 * RS, base + (size_t)(tok0 + r0) * ts, ts, nullptr, dOs + r0 * RS,
-                         dobase + (size_t)(tok0 + r0) * D, (size_t)D, nullptr, pad, N - r0, tid);
+      stage_rows2<P, NT, 4>(Qs + r0 * RS, base + (size_t)(tok0 + r0) * ts, ts, nullptr, dOs + r0 * RS,
+                            dobase + (size_t)(tok0 + r0) * D, (size_t)D, nullptr, pad, N - r0, tid, LO);
     }
   }
   for (int q = tid; q < QROWS; q += NT) {
@@ -256,11 +269,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 1 : 4)) void space_bwd_dkv_kern
     del_s[q] = q < N ? drow[tok0 + q] : 0.f;
   }
   if (!TEXT && tid < 64) {
-    qc[tid] = bf16_to_f32(base[tid]);
-    const float go = bf16_to_f32(dobase[tid]);
+    qc[tid] = P::to_f32_1(base[tid]);
+    const float go = P::to_f32_1(dobase[tid]);
     doc[tid] = go;
     dqc[tid] = 0.f;
-    const float dsum = wave_sum(go * bf16_to_f32(out[(size_t)b * T * D + h * 64 + tid]));
+    const float dsum = wave_sum(go * P::to_f32_1(out[(size_t)b * T * D + h * 64 + tid]));
     if (tid == 0) { scal[0] = lrow[0] * kLog2e; scal[1] = dsum; }
   }
   __syncthreads();
@@ -273,7 +286,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 1 : 4)) void space_bwd_dkv_kern
   for (int kt = wave; kt < nkt; kt += NW) {
     const int krow = kt * 16 + c;
     if (kt != wave) load_kv(kt);          // first tile's fragments were loaded before the staging
-    const uint4 k0 = nk0, k1 = nk1, v0 = nv0, v1 = nv1;
+    const Op k0 = nk0, k1 = nk1, v0 = nv0, v1 = nv1;
     f32x4 adk[4], adv[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) { adk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; adv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -284,14 +297,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 1 : 4)) void space_bwd_dkv_kern
       const uint16_t* Qp = Qs + qp * 32 * RS;         // 32-query slab of the two images
       const uint16_t* Gp = dOs + qp * 32 * RS;
       f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, p0 = s0, p1 = s0;
-      s0 = mfma(tile_frag(Qp, 0, fo.a[0]), k0, s0);
-      s1 = mfma(tile_frag(Qp, 1, fo.a[0]), k0, s1);
-      p0 = mfma(tile_frag(Gp, 0, fo.a[0]), v0, p0);
-      p1 = mfma(tile_frag(Gp, 1, fo.a[0]), v0, p1);
-      s0 = mfma(tile_frag(Qp, 0, fo.a[1]), k1, s0);
-      s1 = mfma(tile_frag(Qp, 1, fo.a[1]), k1, s1);
-      p0 = mfma(tile_frag(Gp, 0, fo.a[1]), v1, p0);
-      p1 = mfma(tile_frag(Gp, 1, fo.a[1]), v1, p1);
+      s0 = mfma(P::tile_op(Qp, LO, 0, fo.a[0]), k0, s0);
+      s1 = mfma(P::tile_op(Qp, LO, 1, fo.a[0]), k0, s1);
+      p0 = mfma(P::tile_op(Gp, LO, 0, fo.a[0]), v0, p0);
+      p1 = mfma(P::tile_op(Gp, LO, 1, fo.a[0]), v0, p1);
+      s0 = mfma(P::tile_op(Qp, LO, 0, fo.a[1]), k1, s0);
+      s1 = mfma(P::tile_op(Qp, LO, 1, fo.a[1]), k1, s1);
+      p0 = mfma(P::tile_op(Gp, LO, 0, fo.a[1]), v1, p0);
+      p1 = mfma(P::tile_op(Gp, LO, 1, fo.a[1]), v1, p1);
       float e0[4], e1[4], d0[4], d1[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -305,26 +318,24 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 1 : 4)) void space_bwd_dkv_kern
         d0[r] = e0[r] * (p0[r] - del_s[q0i]);
         d1[r] = e1[r] * (p1[r] - del_s[q1i]);
       }
-      const uint4 pa = make_uint4(pack_bf16x2(e0[0], e0[1]), pack_bf16x2(e0[2], e0[3]), pack_bf16x2(e1[0], e1[1]),
-                                  pack_bf16x2(e1[2], e1[3]));
-      const uint4 da = make_uint4(pack_bf16x2(d0[0], d0[1]), pack_bf16x2(d0[2], d0[3]), pack_bf16x2(d1[0], d1[1]),
-                                  pack_bf16x2(d1[2], d1[3]));
+      const Op pa = P::pack(e0, e1);
+      const Op da = P::pack(d0, d1);
       // dV += P^T dO, dK += dS^T Q: B fragments = transpose reads (4 consecutive queries per half)
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        const uint2 g_lo = tile_frag_tr(Gp, 0, fo.tr[dt]), g_hi = tile_frag_tr(Gp, 1, fo.tr[dt]);
-        const uint2 q_lo = tile_frag_tr(Qp, 0, fo.tr[dt]), q_hi = tile_frag_tr(Qp, 1, fo.tr[dt]);
-        adv[dt] = mfma(pa, make_uint4(g_lo.x, g_lo.y, g_hi.x, g_hi.y), adv[dt]);
-        adk[dt] = mfma(da, make_uint4(q_lo.x, q_lo.y, q_hi.x, q_hi.y), adk[dt]);
+        const Tr g_lo = P::tile_tr(Gp, LO, 0, fo.tr[dt]), g_hi = P::tile_tr(Gp, LO, 1, fo.tr[dt]);
+        const Tr q_lo = P::tile_tr(Qp, LO, 0, fo.tr[dt]), q_hi = P::tile_tr(Qp, LO, 1, fo.tr[dt]);
+        adv[dt] = mfma(pa, P::join(g_lo, g_hi), adv[dt]);
+        adk[dt] = mfma(da, P::join(q_lo, q_hi), adk[dt]);
       }
     }
 
-    uint16_t* dkb = dqkv + (size_t)b * T * ts + D + h * 64;
+    io_t* dkb = dqkv + (size_t)b * T * ts + D + h * 64;
     if constexpr (TEXT) {
-      store_tile_rows(ot, adk, 0.125f, lane, [&](int row) { return dkb + (size_t)(kt * 16 + row) * ts; },
-                      [&](int row) { return kt * 16 + row < nkeys; });
-      store_tile_rows(ot, adv, 1.0f, lane, [&](int row) { return dkb + D + (size_t)(kt * 16 + row) * ts; },
-                      [&](int row) { return kt * 16 + row < nkeys; });
+      store_tile_rows<P>(ot, adk, 0.125f, lane, [&](int row) { return dkb + (size_t)(kt * 16 + row) * ts; },
+                         [&](int row) { return kt * 16 + row < nkeys; });
+      store_tile_rows<P>(ot, adv, 1.0f, lane, [&](int row) { return dkb + D + (size_t)(kt * 16 + row) * ts; },
+                         [&](int row) { return kt * 16 + row < nkeys; });
       continue;
     }
     // ---- CLS query (attends to every key): rank-1 terms for this key tile --------------------------------
@@ -333,8 +344,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 1 : 4)) void space_bwd_dkv_kern
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
       float kf[8], vf[8];
-      Elem<bf16_t>::load8(reinterpret_cast<const bf16_t*>(hh ? &k1 : &k0), kf);
-      Elem<bf16_t>::load8(reinterpret_cast<const bf16_t*>(hh ? &v1 : &v0), vf);
+      P::to_f32(hh ? k1 : k0, kf);
+      P::to_f32(hh ? v1 : v0, vf);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         sc = fmaf(qc[hh * 32 + g * 8 + i], kf[i], sc);
@@ -350,7 +361,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 1 : 4)) void space_bwd_dkv_kern
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
       float kf[8];
-      Elem<bf16_t>::load8(reinterpret_cast<const bf16_t*>(hh ? &k1 : &k0), kf);
+      P::to_f32(hh ? k1 : k0, kf);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         float v = dsc * kf[i];
@@ -377,10 +388,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 1 : 4)) void space_bwd_dkv_kern
         atomicAdd(kv0 + 64 + dt * 16 + c, adv[dt][0]);
       }
     }
-    store_tile_rows(ot, adk, 0.125f, lane, [&](int row) { return dkb + (size_t)(tok0 + kt * 16 + row - 1) * ts; },
-                    [&](int row) { const int kr = kt * 16 + row; return kr >= 1 && kr < nkeys; });
-    store_tile_rows(ot, adv, 1.0f, lane, [&](int row) { return dkb + D + (size_t)(tok0 + kt * 16 + row - 1) * ts; },
-                    [&](int row) { const int kr = kt * 16 + row; return kr >= 1 && kr < nkeys; });
+    store_tile_rows<P>(ot, adk, 0.125f, lane, [&](int row) { return dkb + (size_t)(tok0 + kt * 16 + row - 1) * ts; },
+                       [&](int row) { const int kr = kt * 16 + row; return kr >= 1 && kr < nkeys; });
+    store_tile_rows<P>(ot, adv, 1.0f, lane, [&](int row) { return dkb + D + (size_t)(tok0 + kt * 16 + row - 1) * ts; },
+                       [&](int row) { const int kr = kt * 16 + row; return kr >= 1 && kr < nkeys; });
   }
 
   if constexpr (TEXT) return;
@@ -404,21 +415,22 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 1 : 4)) void space_bwd_dkv_kern
 //            32 keys: every Q/dO fragment and every transpose read feeds two key tiles.
 // All gradient tiles are accumulated TRANSPOSED (channels x rows: the weight-like operand goes first), so a lane ends
 // up with 4 consecutive channels of one token and stores them directly -- no LDS transposition of the results.
-template <int NKP> struct FusedLds {
+template <int NKP, int IMAGES = 1> struct FusedLds {
   static constexpr int R = NKP * 32;                       // image rows: keys padded to whole pairs of tiles
   static constexpr int img0_off = 0;
   static constexpr int img1_off = R * RS * 2;
-  static constexpr int lse_off = 2 * R * RS * 2;
+  static constexpr int lo_off = 2 * R * RS;                // ELEMENTS from a hi image to its lo image (PrecSplit)
+  static constexpr int lse_off = IMAGES * 2 * R * RS * 2;
   static constexpr int del_off = lse_off + R * 4;
   static constexpr int total = del_off + R * 4;
 };
 
-// o[dt][r] = X^T[channel dt*16 + g*4 + r][token lane&15] -> 4 x 8-byte stores of one token row
-__device__ __forceinline__ void store_token_channels(uint16_t* row, const f32x4 (&o)[4], float mul, int g) {
+// o[dt][r] = X^T[channel dt*16 + g*4 + r][token lane&15] -> 4 stores of 4 consecutive channels of one token row
+template <typename P>
+__device__ __forceinline__ void store_token_channels(typename P::io_t* row, const f32x4 (&o)[4], float mul, int g) {
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt)
-    *reinterpret_cast<uint2*>(row + dt * 16 + g * 4) =
-        make_uint2(pack_bf16x2(o[dt][0] * mul, o[dt][1] * mul), pack_bf16x2(o[dt][2] * mul, o[dt][3] * mul));
+    P::store4(row + dt * 16 + g * 4, o[dt][0] * mul, o[dt][1] * mul, o[dt][2] * mul, o[dt][3] * mul);
 }
 __device__ __forceinline__ void atomic_token_channels(float* dst, const f32x4 (&o)[4], float mul, int g) {
 #pragma unroll
@@ -427,12 +439,17 @@ __device__ __forceinline__ void atomic_token_channels(float* dst, const f32x4 (&
     for (int r = 0; r < 4; ++r) atomicAdd(dst + dt * 16 + g * 4 + r, o[dt][r] * mul);
 }
 
-template <int NKP>
-__global__ __launch_bounds__(256, 2) void space_bwd_fused_kernel(
-    const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out, const uint16_t* __restrict__ dout,
-    const float* __restrict__ lse, uint16_t* __restrict__ dqkv, float* __restrict__ atom_ws, int F, int N, int H) {
+template <typename P, int NKP>
+__global__ __launch_bounds__(256, (P::kSplit ? 1 : 2)) void space_bwd_fused_kernel(
+    const typename P::io_t* __restrict__ qkv, const typename P::io_t* __restrict__ out,
+    const typename P::io_t* __restrict__ dout, const float* __restrict__ lse, typename P::io_t* __restrict__ dqkv,
+    float* __restrict__ atom_ws, int F, int N, int H) {
+  using io_t = typename P::io_t;
+  using Op = typename P::Op;
+  using Tr = typename P::Tr;
   constexpr int NW = 4, NT = 256, R = NKP * 32;
-  using L = FusedLds<NKP>;
+  using L = FusedLds<NKP, P::kImages>;
+  constexpr int LO = L::lo_off;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint16_t* img0 = reinterpret_cast<uint16_t*>(smem + L::img0_off);      // K, then Q
   uint16_t* img1 = reinterpret_cast<uint16_t*>(smem + L::img1_off);      // V, then dO
@@ -444,9 +461,9 @@ __global__ __launch_bounds__(256, 2) void space_bwd_fused_kernel(
   const int D = H * 64, T = 1 + F * N, nkeys = N + 1, tok0 = 1 + f * N;
   const int nqp = (N + 1 + 31) / 32;                    // query pairs: N patch queries + the cls query (row N)
   const size_t ts = (size_t)3 * D;
-  const uint16_t* base = qkv + (size_t)b * T * ts + h * 64;
-  const uint16_t* obase = out + (size_t)b * T * D + h * 64;
-  const uint16_t* dobase = dout + (size_t)b * T * D + h * 64;
+  const io_t* base = qkv + (size_t)b * T * ts + h * 64;
+  const io_t* obase = out + (size_t)b * T * D + h * 64;
+  const io_t* dobase = dout + (size_t)b * T * D + h * 64;
   const float* lrow = lse + ((size_t)b * H + h) * T;
   float* cls_ws = atom_ws + ((size_t)b * H + h) * 192;  // d cls q | d cls k | d cls v
   const int c = lane & 15, g = lane >> 4;
@@ -455,28 +472,28 @@ __global__ __launch_bounds__(256, 2) void space_bwd_fused_kernel(
   auto tok_of_row = [&](int qr) { return qr < N ? tok0 + qr : (qr == N ? 0 : tok0); };
 
   // ---- phase 1: dQ (and delta) --------------------------------------------------------------------------------
-  uint4 qf[2][2], gf[2][2], yf[2][2];
+  Op qf[2][2], gf[2][2], yf[2][2];
   float lraw[2];
   auto load_qfrags = [&](int qp) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int tk = tok_of_row((2 * qp + t) * 16 + c);
       lraw[t] = lrow[tk];
-      const uint16_t* qptr = base + (size_t)tk * ts + g * 8;
-      qf[t][0] = *reinterpret_cast<const uint4*>(qptr);
-      qf[t][1] = *reinterpret_cast<const uint4*>(qptr + 32);
-      gf[t][0] = *reinterpret_cast<const uint4*>(dobase + (size_t)tk * D + g * 8);
-      gf[t][1] = *reinterpret_cast<const uint4*>(dobase + (size_t)tk * D + g * 8 + 32);
-      yf[t][0] = *reinterpret_cast<const uint4*>(obase + (size_t)tk * D + g * 8);
-      yf[t][1] = *reinterpret_cast<const uint4*>(obase + (size_t)tk * D + g * 8 + 32);
+      const io_t* qptr = base + (size_t)tk * ts + g * 8;
+      qf[t][0] = P::load_op(qptr);
+      qf[t][1] = P::load_op(qptr + 32);
+      gf[t][0] = P::load_op(dobase + (size_t)tk * D + g * 8);
+      gf[t][1] = P::load_op(dobase + (size_t)tk * D + g * 8 + 32);
+      yf[t][0] = P::load_op(obase + (size_t)tk * D + g * 8);
+      yf[t][1] = P::load_op(obase + (size_t)tk * D + g * 8 + 32);
     }
   };
   load_qfrags(wave < nqp ? wave : 0);                    // in flight together with the staging
 
   for (int i = tid; i < R; i += NT) { lse_s[i] = INFINITY; del_s[i] = 0.f; }      // padded queries: exp2(-inf) = 0
   {   // key row r = token tok0 + r - 1 (r >= 1) or the cls token (r = 0)
-    const uint16_t* krow0 = base + (size_t)(tok0 - 1) * ts + D;
-    stage_rows2<NT, NKP>(img0, krow0, ts, base + D, img1, krow0 + D, ts, base + 2 * D, R, nkeys, tid);
+    const io_t* krow0 = base + (size_t)(tok0 - 1) * ts + D;
+    stage_rows2<P, NT, NKP>(img0, krow0, ts, base + D, img1, krow0 + D, ts, base + 2 * D, R, nkeys, tid, LO);
   }
   __syncthreads();
 
@@ -488,12 +505,12 @@ __global__ __launch_bounds__(256, 2) void space_bwd_fused_kernel(
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       float a[8], bb[8], acc = 0.f;
-      Elem<bf16_t>::load8(reinterpret_cast<const bf16_t*>(&gf[t][0]), a);
-      Elem<bf16_t>::load8(reinterpret_cast<const bf16_t*>(&yf[t][0]), bb);
+      P::to_f32(gf[t][0], a);
+      P::to_f32(yf[t][0], bb);
 #pragma unroll
       for (int i = 0; i < 8; ++i) acc = fmaf(a[i], bb[i], acc);
-      Elem<bf16_t>::load8(reinterpret_cast<const bf16_t*>(&gf[t][1]), a);
-      Elem<bf16_t>::load8(reinterpret_cast<const bf16_t*>(&yf[t][1]), bb);
+      P::to_f32(gf[t][1], a);
+      P::to_f32(yf[t][1], bb);
 #pragma unroll
       for (int i = 0; i < 8; ++i) acc = fmaf(a[i], bb[i], acc);
       acc += __shfl_xor(acc, 16, 64);
@@ -513,15 +530,15 @@ __global__ __launch_bounds__(256, 2) void space_bwd_fused_kernel(
 #pragma unroll
     for (int j = 0; j < NKP; ++j) {
       // S^T = K.Q^T and dP^T = V.dO^T for key tiles 2j, 2j+1 x query tiles 0, 1: each K/V fragment feeds two MFMAs
-      uint4 kf[2][2], vf[2][2];
+      Op kf[2][2], vf[2][2];
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
-          kf[kt][hh] = tile_frag(img0, 2 * j + kt, fo.a[hh]);
-          vf[kt][hh] = tile_frag(img1, 2 * j + kt, fo.a[hh]);
+          kf[kt][hh] = P::tile_op(img0, LO, 2 * j + kt, fo.a[hh]);
+          vf[kt][hh] = P::tile_op(img1, LO, 2 * j + kt, fo.a[hh]);
         }
-      uint4 pa[2];
+      Op pa[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
@@ -547,15 +564,14 @@ __global__ __launch_bounds__(256, 2) void space_bwd_fused_kernel(
           d0[r] = e0 * p0[r];
           d1[r] = e1 * p1[r];
         }
-        pa[t] = make_uint4(pack_bf16x2(d0[0], d0[1]), pack_bf16x2(d0[2], d0[3]), pack_bf16x2(d1[0], d1[1]),
-                           pack_bf16x2(d1[2], d1[3]));
+        pa[t] = P::pack(d0, d1);
       }
       // dQ^T += K^T . dS^T for the 32 keys of this pair: A fragments are transpose reads of the K image
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        const uint2 lo = tile_frag_tr(img0, 2 * j, fo.tr[dt]);
-        const uint2 hi = tile_frag_tr(img0, 2 * j + 1, fo.tr[dt]);
-        const uint4 kb = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        const Tr lo = P::tile_tr(img0, LO, 2 * j, fo.tr[dt]);
+        const Tr hi = P::tile_tr(img0, LO, 2 * j + 1, fo.tr[dt]);
+        const Op kb = P::join(lo, hi);
         o[0][dt] = mfma(kb, pa[0], o[0][dt]);
         o[1][dt] = mfma(kb, pa[1], o[1][dt]);
       }
@@ -564,25 +580,25 @@ __global__ __launch_bounds__(256, 2) void space_bwd_fused_kernel(
     for (int t = 0; t < 2; ++t) {
       const int qrow = (2 * qp + t) * 16 + c;
       if (qrow < N)
-        store_token_channels(dqkv + (size_t)b * T * ts + (size_t)(tok0 + qrow) * ts + h * 64, o[t], 0.125f, g);
+        store_token_channels<P>(dqkv + (size_t)b * T * ts + (size_t)(tok0 + qrow) * ts + h * 64, o[t], 0.125f, g);
       else if (qrow == N)
         atomic_token_channels(cls_ws, o[t], 0.125f, g);          // this frame's share of d(cls q)
     }
   }
 
   // ---- phase 2: dK, dV ----------------------------------------------------------------------------------------
-  uint4 kk[2][2], vv[2][2];
+  Op kk[2][2], vv[2][2];
   auto load_kv = [&](int kp) {
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int krow = (2 * kp + t) * 16 + c;
-      kk[t][0] = make_uint4(0, 0, 0, 0); kk[t][1] = kk[t][0]; vv[t][0] = kk[t][0]; vv[t][1] = kk[t][0];
+      kk[t][0] = P::zero_op(); kk[t][1] = kk[t][0]; vv[t][0] = kk[t][0]; vv[t][1] = kk[t][0];
       if (krow < nkeys) {
-        const uint16_t* kptr = base + (size_t)(krow == 0 ? 0 : tok0 + krow - 1) * ts + D + g * 8;
-        kk[t][0] = *reinterpret_cast<const uint4*>(kptr);
-        kk[t][1] = *reinterpret_cast<const uint4*>(kptr + 32);
-        vv[t][0] = *reinterpret_cast<const uint4*>(kptr + D);
-        vv[t][1] = *reinterpret_cast<const uint4*>(kptr + D + 32);
+        const io_t* kptr = base + (size_t)(krow == 0 ? 0 : tok0 + krow - 1) * ts + D + g * 8;
+        kk[t][0] = P::load_op(kptr);
+        kk[t][1] = P::load_op(kptr + 32);
+        vv[t][0] = P::load_op(kptr + D);
+        vv[t][1] = P::load_op(kptr + D + 32);
       }
     }
   };
@@ -591,23 +607,23 @@ __global__ __launch_bounds__(256, 2) void space_bwd_fused_kernel(
       // phase 1, the images are overwritten after the barrier
     constexpr int RPP = NT / 8;
     const int c8 = tid & 7, r_in = tid >> 3;
-    uint4 va[NKP], vb[NKP];
+    typename P::Raw va[NKP], vb[NKP];
 #pragma unroll
     for (int p = 0; p < NKP; ++p) {
       const int qr = p * RPP + r_in;
-      va[p] = make_uint4(0, 0, 0, 0);
+      va[p] = P::zero_raw();
       vb[p] = va[p];
       if (qr <= N) {
         const int tk = qr < N ? tok0 + qr : 0;
-        va[p] = *reinterpret_cast<const uint4*>(base + (size_t)tk * ts + c8 * 8);
-        vb[p] = *reinterpret_cast<const uint4*>(dobase + (size_t)tk * D + c8 * 8);
+        va[p] = P::load_raw(base + (size_t)tk * ts + c8 * 8);
+        vb[p] = P::load_raw(dobase + (size_t)tk * D + c8 * 8);
       }
     }
     __syncthreads();                                      // every wave is done with the K, V images
 #pragma unroll
     for (int p = 0; p < NKP; ++p) {
-      *reinterpret_cast<uint4*>(img0 + img_off(p * RPP + r_in, c8)) = va[p];
-      *reinterpret_cast<uint4*>(img1 + img_off(p * RPP + r_in, c8)) = vb[p];
+      P::stage(img0, LO, img_off(p * RPP + r_in, c8), va[p]);
+      P::stage(img1, LO, img_off(p * RPP + r_in, c8), vb[p]);
     }
   }
   __syncthreads();
@@ -626,13 +642,13 @@ __global__ __launch_bounds__(256, 2) void space_bwd_fused_kernel(
     for (int qp = 0; qp < nqp; ++qp) {
       const uint16_t* Qp = img0 + qp * 32 * RS;          // 32-query slab of the two images
       const uint16_t* Gp = img1 + qp * 32 * RS;
-      uint4 qa[2][2], ga[2][2];
+      Op qa[2][2], ga[2][2];
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
-          qa[qt][hh] = tile_frag(Qp, qt, fo.a[hh]);
-          ga[qt][hh] = tile_frag(Gp, qt, fo.a[hh]);
+          qa[qt][hh] = P::tile_op(Qp, LO, qt, fo.a[hh]);
+          ga[qt][hh] = P::tile_op(Gp, LO, qt, fo.a[hh]);
         }
       const float4 ls0 = *reinterpret_cast<const float4*>(lse_s + qp * 32 + g * 4);
       const float4 ls1 = *reinterpret_cast<const float4*>(lse_s + qp * 32 + 16 + g * 4);
@@ -642,7 +658,7 @@ __global__ __launch_bounds__(256, 2) void space_bwd_fused_kernel(
       const float dea[8] = {de0.x, de0.y, de0.z, de0.w, de1.x, de1.y, de1.z, de1.w};
       // (cls query, cls key) outside frame 0 is not attended: one element of key tile 0
       const bool kill_pair = f != 0 && kp == 0 && qp == cls_qp && c == 0;
-      uint4 pa[2], da[2];
+      Op pa[2], da[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
@@ -667,17 +683,15 @@ __global__ __launch_bounds__(256, 2) void space_bwd_fused_kernel(
           d0[r] = e0[r] * p0[r];
           d1[r] = e1[r] * p1[r];
         }
-        pa[t] = make_uint4(pack_bf16x2(e0[0], e0[1]), pack_bf16x2(e0[2], e0[3]), pack_bf16x2(e1[0], e1[1]),
-                           pack_bf16x2(e1[2], e1[3]));
-        da[t] = make_uint4(pack_bf16x2(d0[0], d0[1]), pack_bf16x2(d0[2], d0[3]), pack_bf16x2(d1[0], d1[1]),
-                           pack_bf16x2(d1[2], d1[3]));
+        pa[t] = P::pack(e0, e1);
+        da[t] = P::pack(d0, d1);
       }
       // dV^T += dO^T P, dK^T += Q^T dS: every transpose read feeds both key tiles
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        const uint2 g_lo = tile_frag_tr(Gp, 0, fo.tr[dt]), g_hi = tile_frag_tr(Gp, 1, fo.tr[dt]);
-        const uint2 q_lo = tile_frag_tr(Qp, 0, fo.tr[dt]), q_hi = tile_frag_tr(Qp, 1, fo.tr[dt]);
-        const uint4 gb = make_uint4(g_lo.x, g_lo.y, g_hi.x, g_hi.y), qb = make_uint4(q_lo.x, q_lo.y, q_hi.x, q_hi.y);
+        const Tr g_lo = P::tile_tr(Gp, LO, 0, fo.tr[dt]), g_hi = P::tile_tr(Gp, LO, 1, fo.tr[dt]);
+        const Tr q_lo = P::tile_tr(Qp, LO, 0, fo.tr[dt]), q_hi = P::tile_tr(Qp, LO, 1, fo.tr[dt]);
+        const Op gb = P::join(g_lo, g_hi), qb = P::join(q_lo, q_hi);
         adv[0][dt] = mfma(gb, pa[0], adv[0][dt]);
         adk[0][dt] = mfma(qb, da[0], adk[0][dt]);
         adv[1][dt] = mfma(gb, pa[1], adv[1][dt]);
@@ -685,14 +699,14 @@ __global__ __launch_bounds__(256, 2) void space_bwd_fused_kernel(
       }
     }
 
-    uint16_t* dkb = dqkv + (size_t)b * T * ts + D + h * 64;
+    io_t* dkb = dqkv + (size_t)b * T * ts + D + h * 64;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int krow = (2 * kp + t) * 16 + c;
       if (krow >= 1 && krow < nkeys) {
-        uint16_t* row = dkb + (size_t)(tok0 + krow - 1) * ts;
-        store_token_channels(row, adk[t], 0.125f, g);
-        store_token_channels(row + D, adv[t], 1.0f, g);
+        io_t* row = dkb + (size_t)(tok0 + krow - 1) * ts;
+        store_token_channels<P>(row, adk[t], 0.125f, g);
+        store_token_channels<P>(row + D, adv[t], 1.0f, g);
       } else if (krow == 0) {          // the cls KEY collects gradient from every frame: f32 atomics
         atomic_token_channels(cls_ws + 64, adk[t], 0.125f, g);
         atomic_token_channels(cls_ws + 128, adv[t], 1.0f, g);
@@ -701,26 +715,27 @@ __global__ __launch_bounds__(256, 2) void space_bwd_fused_kernel(
   }
 }
 
-template <int NKP>
+template <typename P, int NKP>
 int launch_fused(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* atom_ws,
                  int B, int F, int N, int H, hipStream_t st) {
-  using L = FusedLds<NKP>;
+  using L = FusedLds<NKP, P::kImages>;
+  using io_t = typename P::io_t;
   static_assert(L::total <= 160 * 1024, "LDS per CU");
   if (L::total > 64 * 1024)
-    if (int rc = lvl_allow_lds<space_bwd_fused_kernel<NKP>>()) return rc;
-  hipLaunchKernelGGL((space_bwd_fused_kernel<NKP>), dim3((unsigned)(B * F * H)), dim3(256), L::total, st,
-                     (const uint16_t*)qkv, (const uint16_t*)out, (const uint16_t*)dout, lse, (uint16_t*)dqkv, atom_ws,
-                     F, N, H);
+    if (int rc = lvl_allow_lds<space_bwd_fused_kernel<P, NKP>>()) return rc;
+  hipLaunchKernelGGL((space_bwd_fused_kernel<P, NKP>), dim3((unsigned)(B * F * H)), dim3(256), L::total, st,
+                     (const io_t*)qkv, (const io_t*)out, (const io_t*)dout, lse, (io_t*)dqkv, atom_ws, F, N, H);
   LVL_CHECK_LAUNCH("space_bwd_fused");
   return LVL_OK;
 }
 
-constexpr int kFusedPairs = 9;         // fused kernel: up to 288 keys per group
+constexpr int kFusedPairs = 9;         // fused kernel: up to 288 keys per group (bf16 and f32-class alike)
 
+template <typename P>
 int dispatch_fused(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* atom_ws,
                    int B, int F, int N, int H, hipStream_t st) {
   switch ((N + 1 + 31) / 32) {
-#define SPACE_FUSED_CASE(K) case K: return launch_fused<K>(qkv, out, dout, lse, dqkv, atom_ws, B, F, N, H, st);
+#define SPACE_FUSED_CASE(K) case K: return launch_fused<P, K>(qkv, out, dout, lse, dqkv, atom_ws, B, F, N, H, st);
     SPACE_FUSED_CASE(1) SPACE_FUSED_CASE(2) SPACE_FUSED_CASE(3) SPACE_FUSED_CASE(4) SPACE_FUSED_CASE(5)
     SPACE_FUSED_CASE(6) SPACE_FUSED_CASE(7) SPACE_FUSED_CASE(8) SPACE_FUSED_CASE(9)
 #undef SPACE_FUSED_CASE
@@ -729,105 +744,124 @@ int dispatch_fused(const void* qkv, const void* out, const void* dout, const flo
 }
 
 // dqkv[b, token 0, :] = (d cls q | d cls k | d cls v) from the f32 atomic workspace
+template <typename P>
 __global__ __launch_bounds__(192) void cls_grad_finalize_kernel(const float* __restrict__ atom_ws,
-                                                                uint16_t* __restrict__ dqkv, int T, int H) {
+                                                                typename P::io_t* __restrict__ dqkv, int T, int H) {
   const int h = blockIdx.x % H, b = blockIdx.x / H, t = threadIdx.x;      // t in [0,192): part = t/64
   const int D = H * 64;
-  dqkv[(size_t)b * T * 3 * D + (t >> 6) * D + h * 64 + (t & 63)] = f32_to_bf16(atom_ws[((size_t)b * H + h) * 192 + t]);
+  dqkv[(size_t)b * T * 3 * D + (t >> 6) * D + h * 64 + (t & 63)] = P::from_f32(atom_ws[((size_t)b * H + h) * 192 + t]);
 }
 
-template <int NKT, bool TEXT = false, int NW = 8, bool MASKALL = false>
+template <typename P, int NKT, bool TEXT = false, int NW = 8, bool MASKALL = false>
 int launch_dq(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* delta, int B,
               int F, int N, int H, hipStream_t st) {
-  using L = DqLds<NKT, NW>;
+  using L = DqLds<NKT, NW, P::kImages>;
+  using io_t = typename P::io_t;
   static_assert(L::total <= 160 * 1024, "LDS per CU");
   if (L::total > 64 * 1024)
-    if (int rc = lvl_allow_lds<space_bwd_dq_kernel<NKT, TEXT, NW, MASKALL>>()) return rc;
-  hipLaunchKernelGGL((space_bwd_dq_kernel<NKT, TEXT, NW, MASKALL>), dim3((unsigned)(B * F * H)), dim3(NW * 64),
-                     L::total, st, (const uint16_t*)qkv, (const uint16_t*)out, (const uint16_t*)dout, lse,
-                     (uint16_t*)dqkv, delta, F, N, H);
+    if (int rc = lvl_allow_lds<space_bwd_dq_kernel<P, NKT, TEXT, NW, MASKALL>>()) return rc;
+  hipLaunchKernelGGL((space_bwd_dq_kernel<P, NKT, TEXT, NW, MASKALL>), dim3((unsigned)(B * F * H)), dim3(NW * 64),
+                     L::total, st, (const io_t*)qkv, (const io_t*)out, (const io_t*)dout, lse, (io_t*)dqkv, delta, F, N,
+                     H);
   LVL_CHECK_LAUNCH("space_bwd_dq");
   return LVL_OK;
 }
 
 constexpr int kBigTiles = 37;          // large-group variant: up to 592 keys, 4 waves, one workgroup per CU
 
-template <bool TEXT>
+template <typename P, bool TEXT>
 int launch_dkv(const void* qkv, const void* out, const void* dout, const float* lse, const float* delta, void* dqkv,
                float* atom_ws, int B, int F, int N, int H, hipStream_t st) {
+  using io_t = typename P::io_t;
   const bool big = !TEXT && N + 1 > 272;
-  const DkvGeom G = dkv_geometry(N, big ? 4 : 8);
+  const DkvGeom G = dkv_geometry(N, big ? 4 : 8, P::kImages);
   if (big) {
-    if (int rc = lvl_allow_lds<space_bwd_dkv_kernel<TEXT, 4>>()) return rc;
-    hipLaunchKernelGGL((space_bwd_dkv_kernel<TEXT, 4>), dim3((unsigned)(B * F * H)), dim3(256), G.total, st,
-                       (const uint16_t*)qkv, (const uint16_t*)out, (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv,
-                       atom_ws, F, N, H, G);
+    if (int rc = lvl_allow_lds<space_bwd_dkv_kernel<P, TEXT, 4>>()) return rc;
+    hipLaunchKernelGGL((space_bwd_dkv_kernel<P, TEXT, 4>), dim3((unsigned)(B * F * H)), dim3(256), G.total, st,
+                       (const io_t*)qkv, (const io_t*)out, (const io_t*)dout, lse, delta, (io_t*)dqkv, atom_ws, F, N, H,
+                       G);
   } else {
     if (G.total > 64 * 1024)
-      if (int rc = lvl_allow_lds<space_bwd_dkv_kernel<TEXT, 8>>()) return rc;
-    hipLaunchKernelGGL((space_bwd_dkv_kernel<TEXT, 8>), dim3((unsigned)(B * F * H)), dim3(512), G.total, st,
-                       (const uint16_t*)qkv, (const uint16_t*)out, (const uint16_t*)dout, lse, delta, (uint16_t*)dqkv,
-                       atom_ws, F, N, H, G);
+      if (int rc = lvl_allow_lds<space_bwd_dkv_kernel<P, TEXT, 8>>()) return rc;
+    hipLaunchKernelGGL((space_bwd_dkv_kernel<P, TEXT, 8>), dim3((unsigned)(B * F * H)), dim3(512), G.total, st,
+                       (const io_t*)qkv, (const io_t*)out, (const io_t*)dout, lse, delta, (io_t*)dqkv, atom_ws, F, N, H,
+                       G);
   }
   LVL_CHECK_LAUNCH("space_bwd_dkv");
   return LVL_OK;
 }
 
-template <bool TEXT>
+template <typename P, bool TEXT>
 int dispatch_dq(int nkeys, const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
                 float* delta, int B, int F, int N, int H, hipStream_t st) {
   if constexpr (TEXT) switch ((nkeys + 15) / 16) {      // exact tile count: the kernel masks only the last key tile
-#define SPACE_DQ_CASE(K) case K: return launch_dq<K, TEXT>(qkv, out, dout, lse, dqkv, delta, B, F, N, H, st);
+#define SPACE_DQ_CASE(K) case K: return launch_dq<P, K, TEXT>(qkv, out, dout, lse, dqkv, delta, B, F, N, H, st);
     SPACE_DQ_CASE(1) SPACE_DQ_CASE(2) SPACE_DQ_CASE(3) SPACE_DQ_CASE(4) SPACE_DQ_CASE(5) SPACE_DQ_CASE(6) SPACE_DQ_CASE(7)
     SPACE_DQ_CASE(8) SPACE_DQ_CASE(9) SPACE_DQ_CASE(10) SPACE_DQ_CASE(11) SPACE_DQ_CASE(12) SPACE_DQ_CASE(13)
     SPACE_DQ_CASE(14) SPACE_DQ_CASE(15) SPACE_DQ_CASE(16) SPACE_DQ_CASE(17)
 #undef SPACE_DQ_CASE
   }
-  if (!TEXT) {
+  if constexpr (!TEXT && !P::kSplit) {
     if ((nkeys + 15) / 16 == kBigTiles)
-      return launch_dq<kBigTiles, false, 4, false>(qkv, out, dout, lse, dqkv, delta, B, F, N, H, st);
+      return launch_dq<P, kBigTiles, false, 4, false>(qkv, out, dout, lse, dqkv, delta, B, F, N, H, st);
     if (nkeys <= kBigTiles * 16)
-      return launch_dq<kBigTiles, false, 4, true>(qkv, out, dout, lse, dqkv, delta, B, F, N, H, st);
+      return launch_dq<P, kBigTiles, false, 4, true>(qkv, out, dout, lse, dqkv, delta, B, F, N, H, st);
   }
   return lvl_fail(LVL_ENOSYS, "space_mfma_bwd: %d keys per group not supported", nkeys);
 }
 
 }  // namespace
 
-void lvl_launch_cls_grad_finalize(const float* atom_ws, void* dqkv, int B, int T, int H, hipStream_t st) {
-  hipLaunchKernelGGL(cls_grad_finalize_kernel, dim3((unsigned)(B * H)), dim3(192), 0, st, atom_ws, (uint16_t*)dqkv, T, H);
+void lvl_launch_cls_grad_finalize(const float* atom_ws, void* dqkv, int B, int T, int H, int dtype, hipStream_t st) {
+  if (dtype == LVL_F32)
+    hipLaunchKernelGGL(cls_grad_finalize_kernel<PrecSplit>, dim3((unsigned)(B * H)), dim3(192), 0, st, atom_ws,
+                       (float*)dqkv, T, H);
+  else
+    hipLaunchKernelGGL(cls_grad_finalize_kernel<PrecBf16>, dim3((unsigned)(B * H)), dim3(192), 0, st, atom_ws,
+                       (uint16_t*)dqkv, T, H);
 }
 
-bool lvl_space_mfma_bwd_supported(int F, int N) {
+// float32 (f32-class, PrecSplit): the fused kernel only (up to 288 keys; its four images fit the LDS)
+bool lvl_space_mfma_bwd_supported(int F, int N, int dtype) {
   if (N < 1 || F > 64) return false;
   if (N + 1 <= kFusedPairs * 32) return true;                                      // fused kernel
+  if (dtype == LVL_F32) return false;
   return N + 1 <= kBigTiles * 16 && dkv_geometry(N, 4).total <= 160 * 1024;      // large groups: 4-wave kernels
 }
 
 // ws layout: delta [B*H*T] f32, then atomics [B*H*192] f32 (d cls q | d cls k | d cls v)
 int lvl_space_mfma_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* ws,
-                       int B, int F, int N, int H, hipStream_t st) {
+                       int B, int F, int N, int H, int dtype, hipStream_t st) {
   const int T = 1 + F * N;
   float* delta = ws;
   float* atom_ws = ws + (size_t)B * H * T;
   hipError_t e = hipMemsetAsync(atom_ws, 0, (size_t)B * H * 192 * sizeof(float), st);
   if (e != hipSuccess) return lvl_fail(LVL_EHIP, "space_bwd memset: %s", hipGetErrorString(e));
   if (N + 1 <= kFusedPairs * 32) {
-    if (int rc = dispatch_fused(qkv, out, dout, lse, dqkv, atom_ws, B, F, N, H, st)) return rc;
+    if (int rc = dtype == LVL_F32 ? dispatch_fused<PrecSplit>(qkv, out, dout, lse, dqkv, atom_ws, B, F, N, H, st)
+                                  : dispatch_fused<PrecBf16>(qkv, out, dout, lse, dqkv, atom_ws, B, F, N, H, st))
+      return rc;
   } else {
-    if (int rc = dispatch_dq<false>(N + 1, qkv, out, dout, lse, dqkv, delta, B, F, N, H, st)) return rc;
-    if (int rc = launch_dkv<false>(qkv, out, dout, lse, delta, dqkv, atom_ws, B, F, N, H, st)) return rc;
+    if (dtype == LVL_F32) return lvl_fail(LVL_ENOSYS, "space_mfma_bwd (f32 class): %d keys per group", N + 1);
+    if (int rc = dispatch_dq<PrecBf16, false>(N + 1, qkv, out, dout, lse, dqkv, delta, B, F, N, H, st)) return rc;
+    if (int rc = launch_dkv<PrecBf16, false>(qkv, out, dout, lse, delta, dqkv, atom_ws, B, F, N, H, st)) return rc;
   }
-  lvl_launch_cls_grad_finalize(atom_ws, dqkv, B, T, H, st);
+  lvl_launch_cls_grad_finalize(atom_ws, dqkv, B, T, H, dtype, st);
   LVL_CHECK_LAUNCH("cls_grad_finalize");
   return LVL_OK;
 }
 
-bool lvl_text_mfma_bwd_supported(int L) { return L >= 1 && L <= 256 && dkv_geometry(L).total <= 160 * 1024; }
+bool lvl_text_mfma_bwd_supported(int L, int dtype) {
+  return L >= 1 && L <= 256 && dkv_geometry(L, 8, dtype == LVL_F32 ? 2 : 1).total <= 160 * 1024;
+}
 
 // ws: delta [B*H*L] f32
 int lvl_text_mfma_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* ws,
-                      int B, int L, int H, hipStream_t st) {
-  if (int rc = dispatch_dq<true>(L, qkv, out, dout, lse, dqkv, ws, B, 1, L, H, st)) return rc;
-  return launch_dkv<true>(qkv, out, dout, lse, ws, dqkv, nullptr, B, 1, L, H, st);
+                      int B, int L, int H, int dtype, hipStream_t st) {
+  if (dtype == LVL_F32) {
+    if (int rc = dispatch_dq<PrecSplit, true>(L, qkv, out, dout, lse, dqkv, ws, B, 1, L, H, st)) return rc;
+    return launch_dkv<PrecSplit, true>(qkv, out, dout, lse, ws, dqkv, nullptr, B, 1, L, H, st);
+  }
+  if (int rc = dispatch_dq<PrecBf16, true>(L, qkv, out, dout, lse, dqkv, ws, B, 1, L, H, st)) return rc;
+  return launch_dkv<PrecBf16, true>(qkv, out, dout, lse, ws, dqkv, nullptr, B, 1, L, H, st);
 }

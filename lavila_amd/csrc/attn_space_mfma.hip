@@ -23,6 +23,10 @@
 // 148 KiB of the CU's 160 KiB LDS, one workgroup of 4 waves per CU (one per SIMD, up to 512 registers each: the 37
 // score tiles of a query tile stay in registers), no online-softmax rescaling and no second pass over K/V.
 //
+// PRECISION POLICY (template P, attn_mfma_common.h): PrecBf16 is the benched kernel; PrecSplit is the same kernel text on
+// float32 tensors with every operand as hi/lo bf16 images and 3 MFMAs per product (f32-class: the parity configuration
+// runs THIS kernel, not the shape-generic one); groups of up to 272 keys (four images fill the LDS beyond that).
+//
 // Roofline: algorithmic HBM bytes per (b,f,h) = 4 * N * 64 * 2 (q,k,v in, o out); MFMA work is ~1/3 of
 // the HBM time at 8 TB/s on TSF-B, so the kernel is built to stream: 2
 // workgroups (16 waves) per CU (<= 80 KB LDS each) overlap one group's staging with the other's MFMA phase.
@@ -34,23 +38,28 @@ using namespace attn_mfma;
 constexpr int CLS_REC = 66;       // cls partial record: m, l, acc[64]
 constexpr int kBigTiles = 37;     // large-group variant: up to 592 keys (TSF-L/14 at 336: 577)
 
-template <int NKT, int NW> struct SpaceLds {
+template <int NKT, int NW, int IMAGES = 1> struct SpaceLds {
   static constexpr int KROWS = NKT * 16;
   static constexpr int ks_off = 0;                                       // bytes
   static constexpr int vs_off = ks_off + KROWS * RS * 2;
-  static constexpr int ot_off = vs_off + KROWS * RS * 2;                 // NW waves x [16][OS] bf16
+  static constexpr int lo_off = 2 * KROWS * RS;                          // ELEMENTS from a hi image to its lo image (PrecSplit)
+  static constexpr int ot_off = IMAGES * (vs_off + KROWS * RS * 2);      // NW waves x [16][OS] bf16
   static constexpr int total = ot_off + NW * 16 * OS * 2;
 };
 
 // TEXT = true reuses the kernel for the causal text tower (openai_model.py:196-198): one group per (b, h),
 // L queries x L keys, no cls row, key j visible to query i iff j <= i, no CLS partial.
 // MASKALL: the tile count is an upper bound of ceil(nkeys/16) (every tile is masked), for the large-group variant.
-template <int NKT, bool TEXT, int NW, bool MASKALL>
-__global__ __launch_bounds__(NW * 64, (NW == 4 ? 1 : (NKT <= 13 ? 4 : 2))) void space_fwd_kernel(
-    const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, float* __restrict__ lse,
+template <typename P, int NKT, bool TEXT, int NW, bool MASKALL>
+__global__ __launch_bounds__(NW * 64, (NW == 4 ? 1 : ((NKT <= 13 && !P::kSplit) ? 4 : 2))) void space_fwd_kernel(
+    const typename P::io_t* __restrict__ qkv, typename P::io_t* __restrict__ out, float* __restrict__ lse,
     float* __restrict__ cls_ws, int F, int N, int H) {
+  using io_t = typename P::io_t;
+  using Op = typename P::Op;
+  using Tr = typename P::Tr;
   constexpr int NT = NW * 64;
-  using L = SpaceLds<NKT, NW>;
+  using L = SpaceLds<NKT, NW, P::kImages>;
+  constexpr int LO = L::lo_off;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint16_t* Ks = reinterpret_cast<uint16_t*>(smem + L::ks_off);
   uint16_t* Vs = reinterpret_cast<uint16_t*>(smem + L::vs_off);
@@ -60,7 +69,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 1 : (NKT <= 13 ? 4 : 2))) void 
   const int h = blockIdx.x % H, f = (blockIdx.x / H) % F, b = blockIdx.x / (H * F);
   const int D = H * 64, T = TEXT ? N : 1 + F * N, nkeys = TEXT ? N : N + 1;
   const size_t tstride = (size_t)3 * D;
-  const uint16_t* base = qkv + (size_t)b * T * tstride + h * 64;      // + token*3D (+D: k, +2D: v)
+  const io_t* base = qkv + (size_t)b * T * tstride + h * 64;          // + token*3D (+D: k, +2D: v)
   const int tok0 = TEXT ? 0 : 1 + f * N;                               // token of query 0 (and of key row 1)
   const int c = lane & 15, g = lane >> 4;
   // query tiles: nqt patch tiles; in the space/time towers one more "tile" holds the CLS query (token 0), whose
@@ -74,20 +83,20 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 1 : (NKT <= 13 ? 4 : 2))) void 
     return base + (size_t)tok * tstride + g * 8;
   };
   const int qt_first = wave < ntiles ? wave : 0;
-  uint4 qn0 = *reinterpret_cast<const uint4*>(q_ptr(qt_first)), qn1 = *reinterpret_cast<const uint4*>(q_ptr(qt_first) + 32);
+  Op qn0 = P::load_op(q_ptr(qt_first)), qn1 = P::load_op(q_ptr(qt_first) + 32);
 
   // K and V rows -> LDS images. Key row r is token tok0 + r - 1 (r >= 1) or the cls token (r = 0).
   {
-    const uint16_t* krow0 = base + (size_t)(TEXT ? 0 : tok0 - 1) * tstride + D;
+    const io_t* krow0 = base + (size_t)(TEXT ? 0 : tok0 - 1) * tstride + D;
     // at most 8 passes (16 loads per thread) in flight at a time
     constexpr int RPP = NT / 8, GROUP = 8 * RPP;
 #pragma unroll 1
     for (int r0 = 0; r0 < L::KROWS; r0 += GROUP) {
       const int pad = L::KROWS - r0 < GROUP ? L::KROWS - r0 : GROUP;
       constexpr int MAXP = (L::KROWS < GROUP ? L::KROWS + RPP - 1 : GROUP) / RPP;
-      stage_rows2<NT, MAXP>(Ks + r0 * RS, krow0 + (size_t)r0 * tstride, tstride,
-                            (TEXT || r0 != 0) ? nullptr : base + D, Vs + r0 * RS, krow0 + D + (size_t)r0 * tstride,
-                            tstride, (TEXT || r0 != 0) ? nullptr : base + 2 * D, pad, nkeys - r0, tid);
+      stage_rows2<P, NT, MAXP>(Ks + r0 * RS, krow0 + (size_t)r0 * tstride, tstride,
+                               (TEXT || r0 != 0) ? nullptr : base + D, Vs + r0 * RS, krow0 + D + (size_t)r0 * tstride,
+                               tstride, (TEXT || r0 != 0) ? nullptr : base + 2 * D, pad, nkeys - r0, tid, LO);
     }
   }
   __syncthreads();
@@ -99,10 +108,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 1 : (NKT <= 13 ? 4 : 2))) void 
   for (int qt = wave; qt < ntiles; qt += NW) {
     const bool cls_tile = !TEXT && qt == nqt;
     const int qrow = qt * 16 + c;
-    const bf16x8 qf0 = as_bf16x8(qn0), qf1 = as_bf16x8(qn1);
+    const Op qf0 = qn0, qf1 = qn1;
     if (qt + NW < ntiles) {             // prefetch the next tile's Q fragments under this tile's MFMAs
-      qn0 = *reinterpret_cast<const uint4*>(q_ptr(qt + NW));
-      qn1 = *reinterpret_cast<const uint4*>(q_ptr(qt + NW) + 32);
+      qn0 = P::load_op(q_ptr(qt + NW));
+      qn1 = P::load_op(q_ptr(qt + NW) + 32);
     }
     // Key tiles are swept in register groups of GS tiles (one group = all tiles for the 8-wave kernels: exact
     // single pass; the large-group variant keeps 12 score tiles in registers at a time and rescales the running
@@ -122,17 +131,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 1 : (NKT <= 13 ? 4 : 2))) void 
       f32x4 acc[GS];
 #pragma unroll
       for (int k = 0; k < GS; ++k) {
-        if (k < gn) {
-          const bf16x8 a0 = as_bf16x8(tile_frag(Ks, t0 + k, fo.a[0]));
-          acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, qf0, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        }
+        if (k < gn) acc[k] = mfma(P::tile_op(Ks, LO, t0 + k, fo.a[0]), qf0, f32x4{0.f, 0.f, 0.f, 0.f});
       }
 #pragma unroll
       for (int k = 0; k < GS; ++k) {
-        if (k < gn) {
-          const bf16x8 a1 = as_bf16x8(tile_frag(Ks, t0 + k, fo.a[1]));
-          acc[k] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, qf1, acc[k], 0, 0, 0);
-        }
+        if (k < gn) acc[k] = mfma(P::tile_op(Ks, LO, t0 + k, fo.a[1]), qf1, acc[k]);
       }
       // acc[k][r] = raw S[query c][key (t0+k)*16 + g*4 + r]. Space groups: NKT = ceil(nkeys/16) exactly, so only
       // the last tile can hold padded keys (compile-time); text: causal mask on every tile. The CLS query sees
@@ -188,17 +191,17 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 1 : (NKT <= 13 ? 4 : 2))) void 
         if (2 * j < gn) {
           const bool two = 2 * j + 1 < gn;
           const int j1 = two ? 2 * j + 1 : 2 * j;
-          uint4 pa;
-          pa.x = pack_bf16x2(acc[2 * j][0], acc[2 * j][1]);
-          pa.y = pack_bf16x2(acc[2 * j][2], acc[2 * j][3]);
-          pa.z = two ? pack_bf16x2(acc[j1][0], acc[j1][1]) : 0u;
-          pa.w = two ? pack_bf16x2(acc[j1][2], acc[j1][3]) : 0u;
+          Op pa;
+          if (two)
+            pa = P::pack(acc[2 * j], acc[j1]);
+          else
+            pa = P::pack_lo(acc[2 * j]);
 #pragma unroll
           for (int dt = 0; dt < 4; ++dt) {
-            const uint2 lo = tile_frag_tr(Vs, t0 + 2 * j, fo.tr[dt]);
-            uint2 hi = make_uint2(0, 0);
-            if (two) hi = tile_frag_tr(Vs, t0 + 2 * j + 1, fo.tr[dt]);
-            o[dt] = mfma(pa, make_uint4(lo.x, lo.y, hi.x, hi.y), o[dt]);
+            const Tr lo = P::tile_tr(Vs, LO, t0 + 2 * j, fo.tr[dt]);
+            Tr hi = P::zero_tr();
+            if (two) hi = P::tile_tr(Vs, LO, t0 + 2 * j + 1, fo.tr[dt]);
+            o[dt] = mfma(pa, P::join(lo, hi), o[dt]);
           }
         }
       }
@@ -217,26 +220,40 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 1 : (NKT <= 13 ? 4 : 2))) void 
       continue;
     }
     // normalise, transpose through LDS, store whole rows
+    if constexpr (!P::kSplit) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float linv = __builtin_amdgcn_rcpf(__shfl(l, g * 4 + r, 64));
+      for (int r = 0; r < 4; ++r) {
+        const float linv = __builtin_amdgcn_rcpf(__shfl(l, g * 4 + r, 64));
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) ot[(g * 4 + r) * OS + dt * 16 + c] = f32_to_bf16(o[dt][r] * linv);
-    }
-    // same wave wrote and reads: LDS ops of one wave complete in order, no barrier needed
+        for (int dt = 0; dt < 4; ++dt) ot[(g * 4 + r) * OS + dt * 16 + c] = f32_to_bf16(o[dt][r] * linv);
+      }
+      // same wave wrote and reads: LDS ops of one wave complete in order, no barrier needed
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int row = (lane >> 3) + 8 * k, ch = lane & 7;
-      const uint4 v = *reinterpret_cast<const uint4*>(ot + row * OS + ch * 8);
-      const int q = qt * 16 + row;
-      if (q < N) *reinterpret_cast<uint4*>(out + ((size_t)b * T + tok0 + q) * D + h * 64 + ch * 8) = v;
+      for (int k = 0; k < 2; ++k) {
+        const int row = (lane >> 3) + 8 * k, ch = lane & 7;
+        const uint4 v = *reinterpret_cast<const uint4*>(ot + row * OS + ch * 8);
+        const int q = qt * 16 + row;
+        if (q < N) *reinterpret_cast<uint4*>(out + ((size_t)b * T + tok0 + q) * D + h * 64 + ch * 8) = v;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float linv = 1.0f / __shfl(l, g * 4 + r, 64);          // f32 class: a true division
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt][r] *= linv;
+      }
+      store_tile_rows<P>(ot, o, 1.0f, lane,
+                         [&](int row) { return out + ((size_t)b * T + tok0 + qt * 16 + row) * D + h * 64; },
+                         [&](int row) { return qt * 16 + row < N; });
     }
     if (g == 0 && qrow < N) lse[((size_t)b * H + h) * T + tok0 + qrow] = m * kScale + __logf(l);
   }
 }
 
 // merges the per-chunk partials of the CLS query: out[b,0,h,:] and lse[b,h,0]
-__global__ __launch_bounds__(64) void cls_combine_kernel(const float* __restrict__ cls_ws, uint16_t* __restrict__ out,
+template <typename P>
+__global__ __launch_bounds__(64) void cls_combine_kernel(const float* __restrict__ cls_ws,
+                                                         typename P::io_t* __restrict__ out,
                                                          float* __restrict__ lse, int nparts, int T, int H) {
   const int h = blockIdx.x % H, b = blockIdx.x / H, d = threadIdx.x;
   const float* rec = cls_ws + ((size_t)b * H + h) * nparts * CLS_REC;
@@ -248,56 +265,87 @@ __global__ __launch_bounds__(64) void cls_combine_kernel(const float* __restrict
     Lsum = fmaf(rec[p * CLS_REC + 1], w, Lsum);
     acc = fmaf(rec[p * CLS_REC + 2 + d], w, acc);
   }
-  out[(size_t)b * T * H * 64 + h * 64 + d] = f32_to_bf16(acc / Lsum);
+  out[(size_t)b * T * H * 64 + h * 64 + d] = P::from_f32(acc / Lsum);
   if (d == 0) lse[((size_t)b * H + h) * T] = M + __logf(Lsum);
 }
 
-template <int NKT, bool TEXT = false, int NW = 8, bool MASKALL = false>
+template <typename P, int NKT, bool TEXT = false, int NW = 8, bool MASKALL = false>
 int launch_space_fwd(const void* qkv, void* out, float* lse, float* ws, int B, int F, int N, int H, hipStream_t st) {
-  using L = SpaceLds<NKT, NW>;
+  using L = SpaceLds<NKT, NW, P::kImages>;
+  using io_t = typename P::io_t;
   static_assert(L::total <= 160 * 1024, "LDS per CU");   // <= 80 KB (NKT <= 13) keeps 2 workgroups per CU
   if (L::total > 64 * 1024)
-    if (int rc = lvl_allow_lds<space_fwd_kernel<NKT, TEXT, NW, MASKALL>>()) return rc;
-  hipLaunchKernelGGL((space_fwd_kernel<NKT, TEXT, NW, MASKALL>), dim3((unsigned)(B * F * H)), dim3(NW * 64), L::total,
-                     st, (const uint16_t*)qkv, (uint16_t*)out, lse, ws, F, N, H);
+    if (int rc = lvl_allow_lds<space_fwd_kernel<P, NKT, TEXT, NW, MASKALL>>()) return rc;
+  hipLaunchKernelGGL((space_fwd_kernel<P, NKT, TEXT, NW, MASKALL>), dim3((unsigned)(B * F * H)), dim3(NW * 64),
+                     L::total, st, (const io_t*)qkv, (io_t*)out, lse, ws, F, N, H);
   LVL_CHECK_LAUNCH("space_fwd_mfma");
   if (TEXT) return LVL_OK;
-  hipLaunchKernelGGL(cls_combine_kernel, dim3((unsigned)(B * H)), dim3(64), 0, st, ws, (uint16_t*)out, lse, F,
+  hipLaunchKernelGGL(cls_combine_kernel<P>, dim3((unsigned)(B * H)), dim3(64), 0, st, ws, (io_t*)out, lse, F,
                      1 + F * N, H);
   LVL_CHECK_LAUNCH("cls_combine");
   return LVL_OK;
 }
 
-}  // namespace
-
-void lvl_launch_cls_combine(const float* ws, void* out, float* lse, int B, int H, int nparts, int T, hipStream_t st) {
-  hipLaunchKernelGGL(cls_combine_kernel, dim3((unsigned)(B * H)), dim3(64), 0, st, ws, (uint16_t*)out, lse, nparts, T, H);
-}
-
-bool lvl_space_mfma_supported(int F, int N) { return N + 1 <= kBigTiles * 16 && N >= 1 && F <= 64; }
-
-int lvl_space_mfma_fwd(const void* qkv, void* out, float* lse, float* ws, int B, int F, int N, int H, hipStream_t st) {
-  const int nkeys = N + 1;
+template <typename P>
+int dispatch_space_fwd_small(int nkeys, const void* qkv, void* out, float* lse, float* ws, int B, int F, int N, int H,
+                             hipStream_t st) {
   switch ((nkeys + 15) / 16) {          // exact tile count: the kernel masks only the last key tile
-#define SPACE_FWD_CASE(K) case K: return launch_space_fwd<K>(qkv, out, lse, ws, B, F, N, H, st);
+#define SPACE_FWD_CASE(K) case K: return launch_space_fwd<P, K>(qkv, out, lse, ws, B, F, N, H, st);
     SPACE_FWD_CASE(1) SPACE_FWD_CASE(2) SPACE_FWD_CASE(3) SPACE_FWD_CASE(4) SPACE_FWD_CASE(5) SPACE_FWD_CASE(6)
     SPACE_FWD_CASE(7) SPACE_FWD_CASE(8) SPACE_FWD_CASE(9) SPACE_FWD_CASE(10) SPACE_FWD_CASE(11) SPACE_FWD_CASE(12)
     SPACE_FWD_CASE(13) SPACE_FWD_CASE(14) SPACE_FWD_CASE(15) SPACE_FWD_CASE(16) SPACE_FWD_CASE(17)
 #undef SPACE_FWD_CASE
   }
+  return 1;       // more than 272 keys
+}
+
+template <typename P>
+int dispatch_text_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, hipStream_t st) {
+  if (L <= 64) return launch_space_fwd<P, 4, true>(qkv, out, lse, nullptr, B, 1, L, H, st);
+  if (L <= 128) return launch_space_fwd<P, 8, true>(qkv, out, lse, nullptr, B, 1, L, H, st);
+  if (L <= 208) return launch_space_fwd<P, 13, true>(qkv, out, lse, nullptr, B, 1, L, H, st);
+  if (L <= 272) return launch_space_fwd<P, 17, true>(qkv, out, lse, nullptr, B, 1, L, H, st);
+  return lvl_fail(LVL_ENOSYS, "text_mfma_fwd: context length %d exceeds the LDS-resident kernel", L);
+}
+
+}  // namespace
+
+void lvl_launch_cls_combine(const float* ws, void* out, float* lse, int B, int H, int nparts, int T, int dtype,
+                            hipStream_t st) {
+  if (dtype == LVL_F32)
+    hipLaunchKernelGGL(cls_combine_kernel<PrecSplit>, dim3((unsigned)(B * H)), dim3(64), 0, st, ws, (float*)out, lse,
+                       nparts, T, H);
+  else
+    hipLaunchKernelGGL(cls_combine_kernel<PrecBf16>, dim3((unsigned)(B * H)), dim3(64), 0, st, ws, (uint16_t*)out, lse,
+                       nparts, T, H);
+}
+
+// bf16: groups of up to 592 keys; float32 (f32-class, PrecSplit: four LDS images): up to 272 keys
+bool lvl_space_mfma_supported(int F, int N, int dtype) {
+  return N + 1 <= (dtype == LVL_F32 ? 17 : kBigTiles) * 16 && N >= 1 && F <= 64;
+}
+
+int lvl_space_mfma_fwd(const void* qkv, void* out, float* lse, float* ws, int B, int F, int N, int H, int dtype,
+                       hipStream_t st) {
+  const int nkeys = N + 1;
+  if (dtype == LVL_F32) {
+    const int rc = dispatch_space_fwd_small<PrecSplit>(nkeys, qkv, out, lse, ws, B, F, N, H, st);
+    return rc == 1 ? lvl_fail(LVL_ENOSYS, "space_mfma_fwd (f32 class): %d keys per group exceed the LDS", nkeys) : rc;
+  }
+  const int rc = dispatch_space_fwd_small<PrecBf16>(nkeys, qkv, out, lse, ws, B, F, N, H, st);
+  if (rc != 1) return rc;
   // large groups: 4 waves, up to 592 keys resident; the exact-tile-count instantiation for 577..592 keys
   // (TSF-L/14 at 336), every tile masked otherwise
-  if ((nkeys + 15) / 16 == kBigTiles) return launch_space_fwd<kBigTiles, false, 4, false>(qkv, out, lse, ws, B, F, N, H, st);
-  if (nkeys <= kBigTiles * 16) return launch_space_fwd<kBigTiles, false, 4, true>(qkv, out, lse, ws, B, F, N, H, st);
+  if ((nkeys + 15) / 16 == kBigTiles)
+    return launch_space_fwd<PrecBf16, kBigTiles, false, 4, false>(qkv, out, lse, ws, B, F, N, H, st);
+  if (nkeys <= kBigTiles * 16)
+    return launch_space_fwd<PrecBf16, kBigTiles, false, 4, true>(qkv, out, lse, ws, B, F, N, H, st);
   return lvl_fail(LVL_ENOSYS, "space_mfma_fwd: %d keys per group exceeds the LDS-resident kernel", nkeys);
 }
 
 bool lvl_text_mfma_supported(int L) { return L >= 1 && L <= 272; }
 
-int lvl_text_mfma_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, hipStream_t st) {
-  if (L <= 64) return launch_space_fwd<4, true>(qkv, out, lse, nullptr, B, 1, L, H, st);
-  if (L <= 128) return launch_space_fwd<8, true>(qkv, out, lse, nullptr, B, 1, L, H, st);
-  if (L <= 208) return launch_space_fwd<13, true>(qkv, out, lse, nullptr, B, 1, L, H, st);
-  if (L <= 272) return launch_space_fwd<17, true>(qkv, out, lse, nullptr, B, 1, L, H, st);
-  return lvl_fail(LVL_ENOSYS, "text_mfma_fwd: context length %d exceeds the LDS-resident kernel", L);
+int lvl_text_mfma_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, int dtype, hipStream_t st) {
+  if (dtype == LVL_F32) return dispatch_text_fwd<PrecSplit>(qkv, out, lse, B, L, H, st);
+  return dispatch_text_fwd<PrecBf16>(qkv, out, lse, B, L, H, st);
 }

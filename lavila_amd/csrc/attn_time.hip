@@ -1,4 +1,4 @@
-// Time-mode divided attention forward + backward (bf16 in/out, f32 arithmetic), gfx950.
+// Time-mode divided attention forward + backward (bf16 or float32 in/out -- template E -- f32 arithmetic), gfx950.
 //
 // Per (sample b, location n, head h): F queries x (1 cls + F) keys, head dim 64 (timesformer.py:121-131
 // with the '(b n) f d' grouping :302-303). 2.5 flop/B at F=4: purely HBM-bound, nothing for the matrix
@@ -19,8 +19,23 @@ namespace {
 constexpr int CLS_REC = 66;
 constexpr float kLog2e = 1.4426950408889634f;
 
-template <int DPL> struct Vec;
-template <> struct Vec<8> {
+// E = element type in HBM: uint16_t (bf16 bits, the benched path) or float (the parity configuration: the same kernels,
+// rows kept unpacked in registers)
+template <typename E, int DPL> struct Vec;
+template <int DPL> struct Vec<float, DPL> {
+  struct alignas(DPL * 4 > 16 ? 16 : DPL * 4) type { float v[DPL]; };
+  static __device__ __forceinline__ void unpack(const type& a, float (&v)[DPL]) {
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) v[i] = a.v[i];
+  }
+  static __device__ __forceinline__ type pack(const float (&v)[DPL]) {
+    type t;
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) t.v[i] = v[i];
+    return t;
+  }
+};
+template <> struct Vec<uint16_t, 8> {
   using type = uint4;
   static __device__ __forceinline__ void unpack(const uint4& a, float (&v)[8]) {
     v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xffff0000u);
@@ -33,7 +48,7 @@ template <> struct Vec<8> {
                       f32x2_to_bf16x2(v[6], v[7]));
   }
 };
-template <> struct Vec<4> {
+template <> struct Vec<uint16_t, 4> {
   using type = uint2;
   static __device__ __forceinline__ void unpack(const uint2& a, float (&v)[4]) {
     v[0] = __uint_as_float(a.x << 16); v[1] = __uint_as_float(a.x & 0xffff0000u);
@@ -44,7 +59,7 @@ template <> struct Vec<4> {
   }
 };
 
-template <> struct Vec<2> {
+template <> struct Vec<uint16_t, 2> {
   using type = uint32_t;
   static __device__ __forceinline__ void unpack(const uint32_t& a, float (&v)[2]) {
     v[0] = __uint_as_float(a << 16); v[1] = __uint_as_float(a & 0xffff0000u);
@@ -52,10 +67,10 @@ template <> struct Vec<2> {
   static __device__ __forceinline__ uint32_t pack(const float (&v)[2]) { return f32x2_to_bf16x2(v[0], v[1]); }
 };
 
-template <int DPL>
-__device__ __forceinline__ float dotp(const float (&a)[DPL], const typename Vec<DPL>::type& b) {
+template <typename E, int DPL>
+__device__ __forceinline__ float dotp(const float (&a)[DPL], const typename Vec<E, DPL>::type& b) {
   float v[DPL];
-  Vec<DPL>::unpack(b, v);
+  Vec<E, DPL>::unpack(b, v);
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < DPL; ++i) s = fmaf(a[i], v[i], s);
@@ -76,11 +91,11 @@ __device__ __forceinline__ float group_sum(float v) {
 }
 
 // block = (64/DPL) * H * NPB threads; thread group = fixed head h, location slot n_sub
-template <int F, int DPL>
-__global__ __launch_bounds__((DPL == 2 ? 512 : 256), (DPL == 2 ? 1 : (F <= 4 ? 4 : 2))) void time_fwd_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out,
+template <typename E, int F, int DPL>
+__global__ __launch_bounds__((DPL == 2 ? 512 : 256), (DPL == 2 || sizeof(E) == 4 ? 1 : (F <= 4 ? 4 : 2))) void time_fwd_kernel(const E* __restrict__ qkv, E* __restrict__ out,
                                                        float* __restrict__ lse, float* __restrict__ cls_ws, int N,
                                                        int H, int NPB, int NCH, int NC) {
-  using V = Vec<DPL>;
+  using V = Vec<E, DPL>;
   using vec_t = typename V::type;
   constexpr int LPP = 64 / DPL;
   extern __shared__ __attribute__((aligned(16))) float smem[];      // [NPB][H][LPP][2 + DPL]
@@ -89,8 +104,8 @@ __global__ __launch_bounds__((DPL == 2 ? 512 : 256), (DPL == 2 ? 1 : (F <= 4 ? 4
   const int chunk = blockIdx.x % NC, b = blockIdx.x / NC;
   const int D = H * 64, T = 1 + F * N;
   const size_t ts = (size_t)3 * D;
-  const uint16_t* base = qkv + (size_t)b * T * ts + h * 64 + dl * DPL;
-  uint16_t* obase = out + (size_t)b * T * D + h * 64 + dl * DPL;
+  const E* base = qkv + (size_t)b * T * ts + h * 64 + dl * DPL;
+  E* obase = out + (size_t)b * T * D + h * 64 + dl * DPL;
   float* lrow = lse + ((size_t)b * H + h) * T;
 
   const vec_t kc = *reinterpret_cast<const vec_t*>(base + D);           // cls key / value / query of this head
@@ -104,7 +119,7 @@ __global__ __launch_bounds__((DPL == 2 ? 512 : 256), (DPL == 2 ? 1 : (F <= 4 ? 4
 #pragma unroll
   for (int i = 0; i < DPL; ++i) ca[i] = 0.f;
   if (chunk == 0 && n_sub == 0) {           // the cls key itself enters the CLS row exactly once per (b,h)
-    cm = group_sum<DPL>(dotp<DPL>(qc, kc));
+    cm = group_sum<DPL>(dotp<E, DPL>(qc, kc));
     cl = 1.f;
     V::unpack(vc, ca);
   }
@@ -115,7 +130,7 @@ __global__ __launch_bounds__((DPL == 2 ? 512 : 256), (DPL == 2 ? 1 : (F <= 4 ? 4
     vec_t kk[F], vv[F];
 #pragma unroll
     for (int f = 0; f < F; ++f) {
-      const uint16_t* p = base + (size_t)(1 + f * N + n) * ts;
+      const E* p = base + (size_t)(1 + f * N + n) * ts;
       kk[f] = *reinterpret_cast<const vec_t*>(p + D);
       vv[f] = *reinterpret_cast<const vec_t*>(p + 2 * D);
     }
@@ -123,7 +138,7 @@ __global__ __launch_bounds__((DPL == 2 ? 512 : 256), (DPL == 2 ? 1 : (F <= 4 ? 4
     {
       float s[F], mx = cm;
 #pragma unroll
-      for (int f = 0; f < F; ++f) { s[f] = group_sum<DPL>(dotp<DPL>(qc, kk[f])); mx = fmaxf(mx, s[f]); }
+      for (int f = 0; f < F; ++f) { s[f] = group_sum<DPL>(dotp<E, DPL>(qc, kk[f])); mx = fmaxf(mx, s[f]); }
       const float al = __builtin_amdgcn_exp2f(cm - mx);
       cl *= al;
 #pragma unroll
@@ -147,10 +162,10 @@ __global__ __launch_bounds__((DPL == 2 ? 512 : 256), (DPL == 2 ? 1 : (F <= 4 ? 4
 #pragma unroll
       for (int i = 0; i < DPL; ++i) q[i] *= 0.125f * kLog2e;
       float s[F + 1];
-      s[0] = group_sum<DPL>(dotp<DPL>(q, kc));
+      s[0] = group_sum<DPL>(dotp<E, DPL>(q, kc));
       float mx = s[0];
 #pragma unroll
-      for (int f = 0; f < F; ++f) { s[f + 1] = group_sum<DPL>(dotp<DPL>(q, kk[f])); mx = fmaxf(mx, s[f + 1]); }
+      for (int f = 0; f < F; ++f) { s[f + 1] = group_sum<DPL>(dotp<E, DPL>(q, kk[f])); mx = fmaxf(mx, s[f + 1]); }
       float o[DPL], v[DPL];
       float p = __builtin_amdgcn_exp2f(s[0] - mx), l = p;
       V::unpack(vc, v);
@@ -204,12 +219,12 @@ __global__ __launch_bounds__((DPL == 2 ? 512 : 256), (DPL == 2 ? 1 : (F <= 4 ? 4
 // Everything of a (b, n, h) problem is thread-group local: the softmax is recomputed from the F+1 keys in
 // registers (no saved statistics needed, and delta = sum_j P dP needs no O rows: `out` is only read for the cls
 // row), dq/dk/dv rows of the patch tokens are written exactly once. HBM: 5 row reads + 3 row writes per token.
-template <int F, int DPL>
-__global__ __launch_bounds__((DPL == 2 ? 512 : 256), (DPL == 2 ? 1 : (F <= 2 ? 4 : (F <= 4 ? 3 : 2)))) void time_bwd_kernel(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out,
-                                                       const uint16_t* __restrict__ dout, const float* __restrict__ lse,
-                                                       uint16_t* __restrict__ dqkv, float* __restrict__ atom_ws, int N,
+template <typename E, int F, int DPL>
+__global__ __launch_bounds__((DPL == 2 ? 512 : 256), (DPL == 2 || sizeof(E) == 4 ? 1 : (F <= 2 ? 4 : (F <= 4 ? 3 : 2)))) void time_bwd_kernel(const E* __restrict__ qkv, const E* __restrict__ out,
+                                                       const E* __restrict__ dout, const float* __restrict__ lse,
+                                                       E* __restrict__ dqkv, float* __restrict__ atom_ws, int N,
                                                        int H, int NPB, int NCH, int NC) {
-  using V = Vec<DPL>;
+  using V = Vec<E, DPL>;
   using vec_t = typename V::type;
   constexpr int LPP = 64 / DPL;
   extern __shared__ __attribute__((aligned(16))) float smem[];      // [NPB][H][LPP][3 * DPL]
@@ -218,10 +233,10 @@ __global__ __launch_bounds__((DPL == 2 ? 512 : 256), (DPL == 2 ? 1 : (F <= 2 ? 4
   const int chunk = blockIdx.x % NC, b = blockIdx.x / NC;
   const int D = H * 64, T = 1 + F * N;
   const size_t ts = (size_t)3 * D;
-  const uint16_t* base = qkv + (size_t)b * T * ts + h * 64 + dl * DPL;
-  uint16_t* gbase = dqkv + (size_t)b * T * ts + h * 64 + dl * DPL;
-  const uint16_t* obase = out + (size_t)b * T * D + h * 64 + dl * DPL;
-  const uint16_t* dobase = dout + (size_t)b * T * D + h * 64 + dl * DPL;
+  const E* base = qkv + (size_t)b * T * ts + h * 64 + dl * DPL;
+  E* gbase = dqkv + (size_t)b * T * ts + h * 64 + dl * DPL;
+  const E* obase = out + (size_t)b * T * D + h * 64 + dl * DPL;
+  const E* dobase = dout + (size_t)b * T * D + h * 64 + dl * DPL;
 
   float qc[DPL], doc[DPL], kc[DPL], vc[DPL];
   V::unpack(*reinterpret_cast<const vec_t*>(base), qc);              // raw cls query
@@ -260,7 +275,7 @@ __global__ __launch_bounds__((DPL == 2 ? 512 : 256), (DPL == 2 ? 1 : (F <= 2 ? 4
 #pragma unroll
     for (int f = 0; f < F; ++f) {
       const int tok = 1 + f * N + n;
-      const uint16_t* p = base + (size_t)tok * ts;
+      const E* p = base + (size_t)tok * ts;
       qq[f] = *reinterpret_cast<const vec_t*>(p);
       kk[f] = *reinterpret_cast<const vec_t*>(p + D);
       vv[f] = *reinterpret_cast<const vec_t*>(p + 2 * D);
@@ -304,8 +319,8 @@ __global__ __launch_bounds__((DPL == 2 ? 512 : 256), (DPL == 2 ? 1 : (F <= 2 ? 4
       float mx = s[0];
 #pragma unroll
       for (int f = 0; f < F; ++f) {
-        s[f + 1] = group_sum<DPL>(dotp<DPL>(q, kk[f])) * (0.125f * kLog2e);
-        dp[f + 1] = group_sum<DPL>(dotp<DPL>(go, vv[f]));
+        s[f + 1] = group_sum<DPL>(dotp<E, DPL>(q, kk[f])) * (0.125f * kLog2e);
+        dp[f + 1] = group_sum<DPL>(dotp<E, DPL>(go, vv[f]));
         mx = fmaxf(mx, s[f + 1]);
       }
       float l = 0.f;
@@ -343,7 +358,7 @@ __global__ __launch_bounds__((DPL == 2 ? 512 : 256), (DPL == 2 ? 1 : (F <= 2 ? 4
     }
 #pragma unroll
     for (int f = 0; f < F; ++f) {
-      uint16_t* p = gbase + (size_t)(1 + f * N + n) * ts;
+      E* p = gbase + (size_t)(1 + f * N + n) * ts;
       *reinterpret_cast<vec_t*>(p + D) = V::pack(dk[f]);
       *reinterpret_cast<vec_t*>(p + 2 * D) = V::pack(dv[f]);
     }
@@ -397,23 +412,31 @@ TimeGeom time_geometry(int N, int H, int dpl) {
 
 }  // namespace
 
-void lvl_launch_cls_combine(const float* ws, void* out, float* lse, int B, int H, int nparts, int T, hipStream_t st);
-void lvl_launch_cls_grad_finalize(const float* atom_ws, void* dqkv, int B, int T, int H, hipStream_t st);
+void lvl_launch_cls_combine(const float* ws, void* out, float* lse, int B, int H, int nparts, int T, int dtype,
+                            hipStream_t st);
+void lvl_launch_cls_grad_finalize(const float* atom_ws, void* dqkv, int B, int T, int H, int dtype, hipStream_t st);
 
 bool lvl_time_fast_supported(int F, int N, int H) {
   if (!(F == 1 || F == 2 || F == 3 || F == 4 || F == 8 || F == 16)) return false;
   return time_geometry(N, H, time_dpl(F)).ok;
 }
 
-int lvl_time_fast_fwd(const void* qkv, void* out, float* lse, float* ws, int B, int F, int N, int H, hipStream_t st) {
+int lvl_time_fast_fwd(const void* qkv, void* out, float* lse, float* ws, int B, int F, int N, int H, int dtype,
+                      hipStream_t st) {
   const int dpl = time_dpl(F);
   const TimeGeom g = time_geometry(N, H, dpl);
   if (!g.ok) return lvl_fail(LVL_ENOSYS, "time_fast_fwd: unsupported head count %d", H);
   const size_t shmem = (size_t)g.NPB * H * (64 / dpl) * (2 + dpl) * sizeof(float);
   const dim3 grid((unsigned)(B * g.NC)), block(g.block);
-#define TIME_FWD(FF, DD)                                                                                        \
-  hipLaunchKernelGGL((time_fwd_kernel<FF, DD>), grid, block, shmem, st, (const uint16_t*)qkv, (uint16_t*)out, lse, \
-                     ws, N, H, g.NPB, g.NCH, g.NC)
+#define TIME_FWD(FF, DD)                                                                                          \
+  do {                                                                                                            \
+    if (dtype == LVL_F32)                                                                                         \
+      hipLaunchKernelGGL((time_fwd_kernel<float, FF, DD>), grid, block, shmem, st, (const float*)qkv, (float*)out, \
+                         lse, ws, N, H, g.NPB, g.NCH, g.NC);                                                      \
+    else                                                                                                          \
+      hipLaunchKernelGGL((time_fwd_kernel<uint16_t, FF, DD>), grid, block, shmem, st, (const uint16_t*)qkv,        \
+                         (uint16_t*)out, lse, ws, N, H, g.NPB, g.NCH, g.NC);                                      \
+  } while (0)
   switch (F) {
     case 1: TIME_FWD(1, 4); break;
     case 2: TIME_FWD(2, 4); break;
@@ -425,7 +448,7 @@ int lvl_time_fast_fwd(const void* qkv, void* out, float* lse, float* ws, int B, 
   }
 #undef TIME_FWD
   LVL_CHECK_LAUNCH("time_fwd");
-  lvl_launch_cls_combine(ws, out, lse, B, H, g.NC, 1 + F * N, st);
+  lvl_launch_cls_combine(ws, out, lse, B, H, g.NC, 1 + F * N, dtype, st);
   LVL_CHECK_LAUNCH("cls_combine");
   return LVL_OK;
 }
@@ -437,7 +460,7 @@ bool lvl_time_fast_bwd_supported(int F, int N, int H) {
 
 // ws layout: delta [B*H*T] f32 (unused here), then atomics [B*H*192] f32
 int lvl_time_fast_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* ws,
-                      int B, int F, int N, int H, hipStream_t st) {
+                      int B, int F, int N, int H, int dtype, hipStream_t st) {
   const int dpl = time_dpl(F);
   const TimeGeom g = time_geometry(N, H, dpl);
   if (!g.ok) return lvl_fail(LVL_ENOSYS, "time_fast_bwd: unsupported head count %d", H);
@@ -447,9 +470,16 @@ int lvl_time_fast_bwd(const void* qkv, const void* out, const void* dout, const 
   if (e != hipSuccess) return lvl_fail(LVL_EHIP, "time_bwd memset: %s", hipGetErrorString(e));
   const size_t shmem = (size_t)g.NPB * H * (64 / dpl) * 3 * dpl * sizeof(float);
   const dim3 grid((unsigned)(B * g.NC)), block(g.block);
-#define TIME_BWD(FF, DD)                                                                                          \
-  hipLaunchKernelGGL((time_bwd_kernel<FF, DD>), grid, block, shmem, st, (const uint16_t*)qkv, (const uint16_t*)out, \
-                     (const uint16_t*)dout, lse, (uint16_t*)dqkv, atom_ws, N, H, g.NPB, g.NCH, g.NC)
+#define TIME_BWD(FF, DD)                                                                                            \
+  do {                                                                                                              \
+    if (dtype == LVL_F32)                                                                                           \
+      hipLaunchKernelGGL((time_bwd_kernel<float, FF, DD>), grid, block, shmem, st, (const float*)qkv,                \
+                         (const float*)out, (const float*)dout, lse, (float*)dqkv, atom_ws, N, H, g.NPB, g.NCH, g.NC); \
+    else                                                                                                            \
+      hipLaunchKernelGGL((time_bwd_kernel<uint16_t, FF, DD>), grid, block, shmem, st, (const uint16_t*)qkv,          \
+                         (const uint16_t*)out, (const uint16_t*)dout, lse, (uint16_t*)dqkv, atom_ws, N, H, g.NPB,    \
+                         g.NCH, g.NC);                                                                              \
+  } while (0)
   switch (F) {
     case 1: TIME_BWD(1, 4); break;
     case 2: TIME_BWD(2, 4); break;
@@ -461,7 +491,7 @@ int lvl_time_fast_bwd(const void* qkv, const void* out, const void* dout, const 
   }
 #undef TIME_BWD
   LVL_CHECK_LAUNCH("time_bwd");
-  lvl_launch_cls_grad_finalize(atom_ws, dqkv, B, T, H, st);
+  lvl_launch_cls_grad_finalize(atom_ws, dqkv, B, T, H, dtype, st);
   LVL_CHECK_LAUNCH("cls_grad_finalize");
   return LVL_OK;
 }

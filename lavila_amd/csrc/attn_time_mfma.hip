@@ -187,7 +187,7 @@ __global__ __launch_bounds__(NWV * 64) void time_mfma_fwd_kernel(const uint16_t*
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) o[dt][r] *= linv;
     }
-    store_tile_rows(ot, o, 1.0f, lane,
+    store_tile_rows<PrecBf16>(ot, o, 1.0f, lane,
                     [&](int row) { return out + ((size_t)b * T + 1 + (size_t)row * N + n) * D + h * 64; },
                     [&](int row) { return row < F; });
     if (g == 0 && live) lse[((size_t)b * H + h) * T + 1 + c * N + n] = m * 0.125f + __logf(l);
@@ -387,9 +387,9 @@ __global__ __launch_bounds__(NWV * 64) void time_mfma_bwd_kernel(const uint16_t*
       av[dt] = mfma(pa_cv, gt, av[dt]);
     }
     auto row_ptr = [&](int row, int third) { return gbase + (size_t)(1 + (size_t)row * N + n) * ts + third * D; };
-    store_tile_rows(ot, odq, 0.125f, lane, [&](int row) { return row_ptr(row, 0); }, [&](int row) { return row < F; });
-    store_tile_rows(ot, odk, 0.125f, lane, [&](int row) { return row_ptr(row, 1); }, [&](int row) { return row < F; });
-    store_tile_rows(ot, odv, 1.0f, lane, [&](int row) { return row_ptr(row, 2); }, [&](int row) { return row < F; });
+    store_tile_rows<PrecBf16>(ot, odq, 0.125f, lane, [&](int row) { return row_ptr(row, 0); }, [&](int row) { return row < F; });
+    store_tile_rows<PrecBf16>(ot, odk, 0.125f, lane, [&](int row) { return row_ptr(row, 1); }, [&](int row) { return row < F; });
+    store_tile_rows<PrecBf16>(ot, odv, 1.0f, lane, [&](int row) { return row_ptr(row, 2); }, [&](int row) { return row < F; });
   }
   // the cls token's gradients: row 0 of the accumulated tiles (lanes g == 0), one atomic per channel and wave
   if (g == 0) {
@@ -412,8 +412,9 @@ inline Geo geometry(int N) {
 
 }  // namespace
 
-void lvl_launch_cls_combine(const float* ws, void* out, float* lse, int B, int H, int nparts, int T, hipStream_t st);
-void lvl_launch_cls_grad_finalize(const float* atom_ws, void* dqkv, int B, int T, int H, hipStream_t st);
+void lvl_launch_cls_combine(const float* ws, void* out, float* lse, int B, int H, int nparts, int T, int dtype,
+                            hipStream_t st);
+void lvl_launch_cls_grad_finalize(const float* atom_ws, void* dqkv, int B, int T, int H, int dtype, hipStream_t st);
 
 bool lvl_time_mfma_supported(int F, int N, int H) { return F >= 5 && F <= 16 && N >= 1 && H % NWV == 0; }
 
@@ -422,7 +423,7 @@ int lvl_time_mfma_fwd(const void* qkv, void* out, float* lse, float* ws, int B, 
   hipLaunchKernelGGL(time_mfma_fwd_kernel, dim3((unsigned)(B * g.NC * (H / NWV))), dim3(NWV * 64), 0, st,
                      (const uint16_t*)qkv, (uint16_t*)out, lse, ws, F, N, H, g.NCH, g.NC);
   LVL_CHECK_LAUNCH("time_mfma_fwd");
-  lvl_launch_cls_combine(ws, out, lse, B, H, g.NC, 1 + F * N, st);
+  lvl_launch_cls_combine(ws, out, lse, B, H, g.NC, 1 + F * N, LVL_BF16, st);
   LVL_CHECK_LAUNCH("cls_combine");
   return LVL_OK;
 }
@@ -441,7 +442,7 @@ int lvl_time_mfma_bwd(const void* qkv, const void* out, const void* dout, const 
                      (const uint16_t*)qkv, (const uint16_t*)out, (const uint16_t*)dout, lse, (uint16_t*)dqkv, atom_ws, F,
                      N, H, g.NCH, g.NC);
   LVL_CHECK_LAUNCH("time_mfma_bwd");
-  lvl_launch_cls_grad_finalize(atom_ws, dqkv, B, T, H, st);
+  lvl_launch_cls_grad_finalize(atom_ws, dqkv, B, T, H, LVL_BF16, st);
   LVL_CHECK_LAUNCH("cls_grad_finalize");
   return LVL_OK;
 }

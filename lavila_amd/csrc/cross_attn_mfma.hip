@@ -29,7 +29,7 @@ __global__ __launch_bounds__(64 * XW) void cross_attn_mfma_kernel(const uint16_t
   const int h = blockIdx.x % H, ctx = blockIdx.x / H;
   const int D = H * 64;
   const uint16_t* kb = kv + (size_t)ctx * Tk * 2 * D + h * 64;
-  stage_rows2<64 * XW, NKT / 2>(Ks, kb, (size_t)2 * D, nullptr, Vs, kb + D, (size_t)2 * D, nullptr, NKT * 16, Tk, tid);
+  stage_rows2<PrecBf16, 64 * XW, NKT / 2>(Ks, kb, (size_t)2 * D, nullptr, Vs, kb + D, (size_t)2 * D, nullptr, NKT * 16, Tk, tid, 0);
   __syncthreads();
   constexpr float kScale = 0.125f, kExp2 = 0.125f * 1.4426950408889634f;
   const FragOff fo = frag_offsets(lane);

@@ -142,7 +142,16 @@ class VideoPatchEmbed(nn.Module):
             raise NotImplementedError('non-square patches')
         w = self.proj.weight
         patches = ops.patchify(video, self.patch_size[0], _compute_dtype(w), frame_major=frame_major)
-        return ops.linear(patches, w.reshape(w.shape[0], -1), self.proj.bias)
+        w2 = w.reshape(w.shape[0], -1)
+        k = w2.shape[1]
+        if k % 64 and patches.is_cuda and w2.shape[0] % 256 == 0:
+            # 14 x 14 patches: 3*14*14 = 588 contraction elements. The MFMA GEMMs walk K in blocks of 64: zero columns up
+            # to 640 on both operands (exact) keep the patch embedding of the TSF-L/14 towers on lvl_linear_tn /
+            # lvl_linear_wgrad; the weight gradient comes back through the pad's slice
+            pad = 64 - k % 64
+            patches = F.pad(patches, (0, pad))
+            w2 = F.pad(w2, (0, pad))
+        return ops.linear(patches, w2, self.proj.bias)
 
     def forward(self, x):
         """Reference signature: x [B,F,C,H,W] -> [B*F, D, H/P, W/P] (timesformer.py:79-84)."""

@@ -170,12 +170,15 @@ def test_linear_and_mlp_autograd_float32_no_library_gemm():
         assert rel < 3e-5, (name, rel)
 
 
-@pytest.mark.parametrize('name', ['config1_tsfb_112'])
-def test_config1_runs_on_own_gemms_within_1e3(name):
-    """BASELINE configs[0] (CLIP_OPENAI_TIMESFORMER_BASE shape, 2 x 112^2, batch 4) against the reference's committed
-    outputs at north_star's 1e-3 -- forward, loss, backward of all 375 parameter tensors -- with every library GEMM
+@pytest.mark.parametrize('name', ['config1_tsfb_112', 'config2_tsfb_224_b8', 'tsfl14_224_b2', 'tsfl14_336_b2'])
+def test_full_size_models_run_on_own_kernels_within_1e3(name):
+    """The reference's committed outputs at north_star's 1e-3 -- forward, loss, backward of every parameter tensor -- for
+    BASELINE configs[0] (CLIP_OPENAI_TIMESFORMER_BASE shape, 2 x 112^2, batch 4), configs[1]'s clip shape (TSF-B/16,
+    4 x 224^2, batch 8: the shapes the bench runs, through the kernels the bench runs), and the
+    CLIP_OPENAI_TIMESFORMER_LARGE / _LARGE_336PX shapes (forward AND backward) -- with every library GEMM
     entry point of torch forbidden: the Linear layers, the patch-embedding contraction and the two projections run on
-    lvl_linear_tn / lvl_linear_wgrad in f32-class mode."""
+    lvl_linear_tn / lvl_linear_wgrad in f32-class mode, and no attention call may land on the shape-generic kernels:
+    space / causal attention run on the split-operand MFMA kernels, time attention on the float32 register-tiled ones."""
     from lavila.models.loss import CLIPLoss
     from lavila_amd import ops
     assert ops.F32_MFMA
@@ -187,11 +190,19 @@ def test_config1_runs_on_own_gemms_within_1e3(name):
     video, tokens = synthetic_inputs(c, seed=fx['input_seed'])
     video, tokens = video.to(DEV), tokens.to(DEV)
     crit = CLIPLoss(use_vissl=False, cache_labels=True, rank=0, world_size=1)
+    _generic_calls()
     with forbid_library_gemm():
         out = model(video, tokens, norm_embed=True)
         ld = crit(out)
         ld['loss'].backward()
         dbg = crit.debug_slabs(out)
+    torch.cuda.synchronize()
+    n_generic = _generic_calls()
+    if c['img'] // c['patch'] <= 16:       # up to 257 keys per space group: everything on the fast kernels
+        assert n_generic == 0, 'an attention call of the parity configuration fell to the shape-generic kernels'
+    else:                                  # TSF-L/14 at 336: 577-key space groups exceed the four-image LDS budget
+        # space fwd + bwd per block (the last block only needs its cls query: lvl_cls_attn); time / text stay fast
+        assert n_generic in (2 * c['depth'], 2 * (c['depth'] - 1)), n_generic
     tol = dict(atol=1e-3, rtol=1e-3)
     torch.testing.assert_close(out['image_embed'].cpu(), fx['image_embed'], **tol)
     torch.testing.assert_close(out['text_embed'].cpu(), fx['text_embed'], **tol)
@@ -207,6 +218,126 @@ def test_config1_runs_on_own_gemms_within_1e3(name):
     # how far inside the bar: report the measured distances (shown with -s / in the failure message)
     d_logit = (dbg['logits'][0].cpu() - fx['logits_per_image']).abs().max().item()
     d_embed = (out['image_embed'].cpu() - fx['image_embed']).abs().max().item()
-    print(f'[f32-class config1] max |d logit| = {d_logit:.2e}, max |d image_embed| = {d_embed:.2e}, '
+    print(f'[f32-class {name}] max |d logit| = {d_logit:.2e}, max |d image_embed| = {d_embed:.2e}, '
           f'|d loss| = {abs(ld["loss"].item() - fx["loss"].item()):.2e}')
     assert d_logit < 1e-3
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# attention: float32 tensors run on the f32-class instantiations of the benched kernels (split-operand MFMA for the
+# space groups and the causal text tower, float32 rows for the register-tiled time kernels), not on the generic ones
+# ----------------------------------------------------------------------------------------------------------------
+def _generic_calls(reset=True):
+    from lavila_amd import _cabi as C
+    return C.lib().lvl_debug_generic_attention_calls(int(reset))
+
+
+@contextlib.contextmanager
+def _f32_generic(on):
+    from lavila_amd import _cabi as C
+    C.lib().lvl_debug_f32_generic(int(on))
+    try:
+        yield
+    finally:
+        C.lib().lvl_debug_f32_generic(0)
+
+
+def _rel(a, b):
+    return ((a.double().cpu() - b.double()).norm() / b.double().norm()).item()
+
+
+@pytest.mark.parametrize('mode', ['space', 'time'])
+@pytest.mark.parametrize('B,Fr,N,H', [(4, 2, 49, 12),      # BASELINE config 1
+                                      (2, 4, 196, 12),     # config 2's clip shape (the benched kernels' instantiation)
+                                      (1, 4, 256, 16),     # TSF-L/14 at 224
+                                      (2, 3, 5, 2), (1, 1, 271, 1), (2, 2, 32, 1), (1, 2, 287, 2), (1, 8, 33, 3),
+                                      (1, 16, 10, 4)])
+def test_divided_attention_float32_on_fast_kernels_vs_float64(mode, B, Fr, N, H):
+    from lavila_amd import _cabi as C
+    from lavila_amd import ops
+    m = {'space': C.ATTN_SPACE, 'time': C.ATTN_TIME}[mode]
+    fast = bool(C.lib().lvl_attention_fast_path_f32(m, Fr, N, H))
+    if mode == 'space':
+        assert fast == (N + 1 <= 272)                  # forward: four LDS images up to 272 keys
+    else:
+        assert fast
+    g = torch.Generator().manual_seed(100 + Fr + N)
+    T, D = 1 + Fr * N, 64 * H
+    qkv = torch.randn(B, T, 3 * D, generator=g) * 1.5
+    dout = torch.randn(B, T, D, generator=g)
+    qo = qkv.double().requires_grad_(True)
+    oo = O.divided_attention_core(qo, H, Fr, N, mode)
+    oo.backward(dout.double())
+    res = {}
+    for generic in (False, True):
+        with _f32_generic(generic):
+            _generic_calls()
+            qg = qkv.to(DEV).requires_grad_(True)
+            o = ops.divided_attention(qg, Fr, N, H, mode)
+            o.backward(dout.to(DEV))
+            torch.cuda.synchronize()
+            n = _generic_calls()
+            assert n == (2 if (generic or not fast) else 0), (generic, n)
+            res[generic] = (o.detach(), qg.grad)
+    for generic, (o, dq) in res.items():
+        ro, rg = _rel(o, oo.detach()), _rel(dq, qo.grad)
+        assert ro < 2e-5 and rg < 4e-5, (mode, generic, ro, rg)
+        assert (o.double().cpu() - oo.detach()).abs().max() < 1e-4
+        assert (dq.double().cpu() - qo.grad).abs().max() < 1e-4 * max(1.0, qo.grad.abs().max().item())
+
+
+@pytest.mark.parametrize('B,L,H', [(4, 77, 8), (4, 32, 8), (2, 5, 1), (2, 130, 2), (1, 256, 1), (3, 19, 12)])
+def test_causal_attention_float32_on_fast_kernels_vs_float64(B, L, H):
+    from lavila_amd import _cabi as C
+    from lavila_amd import ops
+    assert C.lib().lvl_attention_fast_path_f32(2, 1, L, H) == 1
+    g = torch.Generator().manual_seed(L * 3 + H)
+    qkv = torch.randn(B, L, 3 * 64 * H, generator=g) * 1.5
+    dout = torch.randn(B, L, 64 * H, generator=g)
+    qo = qkv.double().requires_grad_(True)
+    oo = O.causal_attention_core(qo, H)
+    oo.backward(dout.double())
+    _generic_calls()
+    qg = qkv.to(DEV).requires_grad_(True)
+    o = ops.causal_attention(qg, H)
+    o.backward(dout.to(DEV))
+    torch.cuda.synchronize()
+    assert _generic_calls() == 0
+    assert _rel(o.detach(), oo.detach()) < 2e-5 and _rel(qg.grad, qo.grad) < 4e-5
+    assert (o.detach().double().cpu() - oo.detach()).abs().max() < 1e-4
+    assert (qg.grad.double().cpu() - qo.grad).abs().max() < 1e-4 * max(1.0, qo.grad.abs().max().item())
+
+
+@pytest.mark.parametrize('mode,B,Fr,N,H', [('space', 2, 4, 196, 12), ('time', 2, 4, 196, 12), ('space', 4, 2, 49, 12),
+                                           ('time', 4, 2, 49, 12), ('space', 1, 1, 256, 16), ('time', 1, 16, 9, 4),
+                                           ('space', 1, 2, 271, 1), ('causal', 3, 1, 77, 8), ('causal', 2, 1, 130, 12)])
+def test_attention_float32_one_hot_exact(mode, B, Fr, N, H):
+    """The exact structural test of tests/test_gpu_parity_bf16.py on the float32 instantiations: every query puts its whole
+    softmax mass on ONE key of its group, values are integers up to +-388 (NOT representable in bf16: the lo images
+    carry data), so out = v[target] and dv = scatter-add(dout) must hold bit for bit and dq / dk must be exactly 0 -- a
+    dropped key tile, lo image or cls partial cannot hide under a tolerance."""
+    from lavila_amd import ops
+    from test_gpu_parity_bf16 import _check_exact, _one_hot_problem
+    T = N if mode == 'causal' else 1 + Fr * N
+
+    def allowed(t):
+        if mode == 'causal':
+            return list(range(t + 1))
+        if t == 0:
+            return list(range(T))
+        f, n = divmod(t - 1, N)
+        if mode == 'space':
+            return [0] + [1 + f * N + m for m in range(N)]
+        return [0] + [1 + ff * N + n for ff in range(Fr)]
+    qkv, dout, out_want, dv_want, _ = _one_hot_problem(B, H, T, allowed, seed=23)
+    qkv, dout = qkv.float(), dout.float()
+    D = 64 * H
+    qkv[..., 2 * D:] *= 97.0                                    # |v| up to 388: h = bf16(v) != v
+    assert (qkv[..., 2 * D:].bfloat16().float() != qkv[..., 2 * D:]).any()
+    _generic_calls()
+    if mode == 'causal':
+        _check_exact(qkv, dout, out_want * 97.0, dv_want, lambda x: ops.causal_attention(x, H))
+    else:
+        _check_exact(qkv, dout, out_want * 97.0, dv_want, lambda x: ops.divided_attention(x, Fr, N, H, mode))
+    torch.cuda.synchronize()
+    assert _generic_calls() == 0

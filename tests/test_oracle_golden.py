@@ -7,7 +7,13 @@ from oracle import oracle as O
 from oracle.gen_golden import synthetic_inputs
 from conftest import load_golden
 
-MODELS = ['tiny_p16', 'tiny_p14_gated', 'tiny_f16', 'config1_tsfb_112']
+import os
+
+MODELS = ['tiny_p16', 'tiny_p14_gated', 'tiny_f16', 'config1_tsfb_112', 'config2_tsfb_224_b8']
+# the TSF-L/14 fixtures (24 blocks of width 1024) take a few minutes of CPU each: checked on request
+# (LAVILA_SLOW_ORACLE=1; done once when the fixtures were generated)
+if os.environ.get('LAVILA_SLOW_ORACLE') == '1':
+    MODELS += ['tsfl14_224_b2', 'tsfl14_336_b2']
 
 
 @pytest.mark.parametrize('case', range(4))
