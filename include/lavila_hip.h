@@ -136,6 +136,13 @@ int lvl_attention_fast_path(int mode, int F, int N, int H);
  * generic kernels: the A/B switch of the parity tests. */
 int lvl_attention_fast_path_f32(int mode, int F, int N, int H);
 int lvl_debug_f32_generic(int on);
+/* Space groups of more than 288 keys (TSF-L/14 at 336: 577 per frame; float32: more than 272) run on KEY-TILED STREAMING
+ * kernels (csrc/attn_space_stream.hip: a workgroup owns 128 queries -- or keys, in the dK/dV kernel -- and streams the
+ * other side through double-buffered 64-row LDS images; online softmax forward, lse-recomputed P backward) instead of
+ * keeping the whole group LDS-resident with one workgroup per compute unit. Test / measurement hook: mode 1 = streaming
+ * kernels for EVERY space group, -1 = never (the LDS-resident kernels up to 592 keys, as in round 3), 0 = the shipped
+ * choice. Results agree to rounding (bf16) / f32 summation order. */
+int lvl_debug_space_stream(int mode);
 /* Test hook: how many lvl_divided_attn_* / lvl_causal_attn_* calls of this process were served by the shape-generic
  * kernels so far (reset != 0: read and clear). */
 int lvl_debug_generic_attention_calls(int reset);

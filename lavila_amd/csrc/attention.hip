@@ -17,6 +17,12 @@ int lvl_generic_causal_bwd(const void* qkv, const void* out, const void* dout, c
 bool lvl_space_mfma_supported(int F, int N, int dtype);
 int lvl_space_mfma_fwd(const void* qkv, void* out, float* lse, float* ws, int B, int F, int N, int H, int dtype,
                        hipStream_t st);
+// key-tiled streaming kernels for large space groups (attn_space_stream.hip)
+bool lvl_space_stream_wanted(int F, int N, int dtype);
+int lvl_space_stream_fwd(const void* qkv, void* out, float* lse, float* ws, int B, int F, int N, int H, int dtype,
+                         hipStream_t st);
+int lvl_space_stream_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* ws,
+                         int B, int F, int N, int H, int dtype, hipStream_t st);
 bool lvl_time_fast_supported(int F, int N, int H);
 bool lvl_time_mfma_supported(int F, int N, int H);
 int lvl_time_mfma_fwd(const void* qkv, void* out, float* lse, float* ws, int B, int F, int N, int H, hipStream_t st);
@@ -79,6 +85,8 @@ extern "C" int lvl_divided_attn_fwd(const void* qkv, void* out, float* lse, floa
   if (int rc = check_divided("divided_attn_fwd", qkv, out, B, F, N, H, mode, dtype)) return rc;
   LVL_REQUIRE(lse && ws, "divided_attn_fwd: null lse / workspace");
   if (B == 0) return LVL_OK;
+  if (fast_dtype(dtype) && mode == LVL_ATTN_SPACE && F <= 64 && lvl_space_stream_wanted(F, N, dtype))
+    return lvl_space_stream_fwd(qkv, out, lse, ws, B, F, N, H, dtype, (hipStream_t)stream);
   if (fast_dtype(dtype) && mode == LVL_ATTN_SPACE && lvl_space_mfma_supported(F, N, dtype))
     return lvl_space_mfma_fwd(qkv, out, lse, ws, B, F, N, H, dtype, (hipStream_t)stream);
   if (dtype == LVL_BF16 && mode == LVL_ATTN_TIME && time_use_mfma(F, N, H))
@@ -95,6 +103,8 @@ extern "C" int lvl_divided_attn_bwd(const void* qkv, const void* out, const void
   LVL_REQUIRE(dout && lse && dqkv && ws, "divided_attn_bwd: null pointer");
   LVL_REQUIRE(lvl_aligned16(dout) && lvl_aligned16(dqkv), "divided_attn_bwd: pointers must be 16-byte aligned");
   if (B == 0) return LVL_OK;
+  if (fast_dtype(dtype) && mode == LVL_ATTN_SPACE && F <= 64 && lvl_space_stream_wanted(F, N, dtype))
+    return lvl_space_stream_bwd(qkv, out, dout, lse, dqkv, ws, B, F, N, H, dtype, (hipStream_t)stream);
   if (fast_dtype(dtype) && mode == LVL_ATTN_SPACE && lvl_space_mfma_bwd_supported(F, N, dtype))
     return lvl_space_mfma_bwd(qkv, out, dout, lse, dqkv, ws, B, F, N, H, dtype, (hipStream_t)stream);
   if (dtype == LVL_BF16 && mode == LVL_ATTN_TIME && time_use_mfma(F, N, H))
@@ -134,7 +144,8 @@ extern "C" int lvl_causal_attn_bwd(const void* qkv, const void* out, const void*
 // the shape-generic kernels of attn_generic.hip (correct, latency-bound). Host-side query, no device work.
 extern "C" int lvl_attention_fast_path(int mode, int F, int N, int H) {
   if (mode == LVL_ATTN_SPACE)
-    return lvl_space_mfma_supported(F, N, LVL_BF16) && lvl_space_mfma_bwd_supported(F, N, LVL_BF16);
+    return F <= 64 && (lvl_space_stream_wanted(F, N, LVL_BF16) ||
+                       (lvl_space_mfma_supported(F, N, LVL_BF16) && lvl_space_mfma_bwd_supported(F, N, LVL_BF16)));
   if (mode == LVL_ATTN_TIME)
     return lvl_time_mfma_supported(F, N, H) || (lvl_time_fast_supported(F, N, H) && lvl_time_fast_bwd_supported(F, N, H));
   if (mode == LVL_ATTN_CAUSAL) return lvl_text_mfma_supported(N) && lvl_text_mfma_bwd_supported(N, LVL_BF16);
@@ -146,7 +157,8 @@ extern "C" int lvl_attention_fast_path(int mode, int F, int N, int H) {
 extern "C" int lvl_attention_fast_path_f32(int mode, int F, int N, int H) {
   if (!f32_fast()) return 0;
   if (mode == LVL_ATTN_SPACE)
-    return lvl_space_mfma_supported(F, N, LVL_F32) && lvl_space_mfma_bwd_supported(F, N, LVL_F32);
+    return F <= 64 && (lvl_space_stream_wanted(F, N, LVL_F32) ||
+                       (lvl_space_mfma_supported(F, N, LVL_F32) && lvl_space_mfma_bwd_supported(F, N, LVL_F32)));
   if (mode == LVL_ATTN_TIME) return lvl_time_fast_supported(F, N, H) && lvl_time_fast_bwd_supported(F, N, H);
   if (mode == LVL_ATTN_CAUSAL) return lvl_text_mfma_supported(N) && lvl_text_mfma_bwd_supported(N, LVL_F32);
   return 0;

@@ -1,0 +1,696 @@
+// Space-mode divided attention for LARGE groups (TSF-L/14 at 336: 576 patches + cls = 577 keys per frame), forward and
+// backward, as KEY-TILED STREAMING kernels on the matrix cores, gfx950.
+//
+// The resident kernels (attn_space_mfma.hip / attn_space_bwd.hip) keep every key of a (sample, frame, head) group in
+// LDS; at 577 keys the two images fill 148 KiB, so one 4-wave workgroup owns a compute unit and the kernels run at 0.12
+// of HBM / 0.11 of the MFMA peak -- latency bound (profiles/r03_fp8_qk_and_config4_attention.txt). Here the group is cut
+// along the rows a wave OWNS (queries in the forward and dQ kernels, keys in the dK/dV kernel): a workgroup of 4 waves
+// owns 128 of them (two 16-row MFMA tiles per wave, fragments straight from HBM, each LDS fragment read feeds two MFMAs)
+// and STREAMS the other side through a double-buffered pair of 64-row LDS images (32 KiB): the next chunk's global loads
+// are in flight while the current chunk is multiplied, one barrier per chunk, 3-4 workgroups (12-16 waves) per compute
+// unit. The other side is re-read once per 128 own rows -- 5 times per group at 577 keys -- but from the L2 (148 KB per
+// group), not from HBM.
+//   forward  online softmax (running max / sum, rescale per chunk), O^T accumulated transposed (channels x queries) so
+//            that the rescale factor and the final 1/l are lane-local and a lane stores 4 consecutive channels directly;
+//            the cls query rides as one more query tile and leaves the usual per-frame partial (cls_combine_kernel).
+//   dq       P recomputed from the saved lse; dS^T packed straight into the B operand of dQ^T += K^T dS^T; delta = dO.O
+//            per query written for the dK/dV kernel; the cls query's partial dQ goes to the f32 atomic slab.
+//   dkv      waves own 32 keys, Q / dO (+ lse, delta) stream; the cls query is query row N of the group; the cls key's
+//            dK / dV go to the atomic slab (it collects gradient from every frame).
+// Same precision policies as the resident kernels (attn_mfma_common.h): PrecBf16, and PrecSplit for float32 tensors
+// (f32-class: hi/lo images, 3 MFMAs per product), which also takes the 577-key float32 groups off the generic kernels.
+#include "attn_mfma_common.h"
+
+namespace {
+
+using namespace attn_mfma;
+constexpr float kLog2e = 1.4426950408889634f;
+constexpr float kExp2 = 0.125f * kLog2e;          // exp(s * scale) = exp2(s * kExp2)
+constexpr int CLS_REC = 66;                       // cls partial record: m, l, acc[64]
+constexpr int KC = 64;                            // streamed rows per chunk (4 MFMA tiles)
+
+template <int IMAGES> struct StreamLds {
+  static constexpr int img_elems = KC * RS;                      // one 64-row image
+  static constexpr int buf_elems = 2 * img_elems;                // a buffer = image A | image B
+  static constexpr int lo_off = 2 * buf_elems;                   // ELEMENTS from a hi image to its lo image (PrecSplit)
+  static constexpr int img_bytes = IMAGES * 2 * buf_elems * 2;   // two buffers, hi (+ lo)
+  static constexpr int vec_off = img_bytes;                      // dkv kernel: lse | delta of the two buffers' rows
+  static constexpr int total_fwd = img_bytes;
+  static constexpr int total_dkv = img_bytes + 2 * 2 * KC * 4;
+};
+
+// One thread's share of a 64-row chunk: rows r_in and r_in + 32 of both images, 8 channels at c8.
+template <typename P>
+struct ChunkRegs { typename P::Raw a[2], b[2]; };
+
+// ------------------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------------------
+template <typename P>
+__global__ __launch_bounds__(256, (P::kSplit ? 1 : 3)) void space_stream_fwd_kernel(
+    const typename P::io_t* __restrict__ qkv, typename P::io_t* __restrict__ out, float* __restrict__ lse,
+    float* __restrict__ cls_ws, int F, int N, int H, int NB) {
+  using io_t = typename P::io_t;
+  using Op = typename P::Op;
+  using Tr = typename P::Tr;
+  using L = StreamLds<P::kImages>;
+  constexpr int LO = L::lo_off;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint16_t* img = reinterpret_cast<uint16_t*>(smem);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int blk = blockIdx.x % NB, grp = blockIdx.x / NB;
+  const int h = grp % H, f = (grp / H) % F, b = grp / (H * F);
+  const int D = H * 64, T = 1 + F * N, nkeys = N + 1, tok0 = 1 + f * N;
+  const size_t ts = (size_t)3 * D;
+  const io_t* base = qkv + (size_t)b * T * ts + h * 64;
+  const int c = lane & 15, g = lane >> 4;
+  const int nqt = (N + 15) / 16, ntiles = nqt + 1;          // patch query tiles + the cls query tile
+  const FragOff fo = frag_offsets(lane);
+
+  // this wave's two query tiles; a tile beyond the group aliases tile 0 (computed, never stored)
+  int qt[2];
+  bool live[2], cls_t[2];
+  Op qf[2][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    qt[t] = blk * 8 + wave * 2 + t;
+    live[t] = qt[t] < ntiles;
+    if (!live[t]) qt[t] = 0;
+    cls_t[t] = qt[t] == nqt;
+    const int qr = qt[t] * 16 + c;
+    const int tok = cls_t[t] ? 0 : tok0 + (qr < N ? qr : N - 1);
+    const io_t* qp = base + (size_t)tok * ts + g * 8;
+    qf[t][0] = P::load_op(qp);
+    qf[t][1] = P::load_op(qp + 32);
+  }
+
+  // chunk staging: key row kidx = chunk * KC + r is the cls token (kidx = 0) or token tok0 + kidx - 1
+  const int c8 = tid & 7, r_in = tid >> 3;
+  ChunkRegs<P> cr;
+  auto load_chunk = [&](int ch) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int kidx = ch * KC + p * 32 + r_in;
+      cr.a[p] = P::zero_raw();
+      cr.b[p] = P::zero_raw();
+      if (kidx < nkeys) {
+        const io_t* kp = base + (size_t)(kidx == 0 ? 0 : tok0 + kidx - 1) * ts + D + c8 * 8;
+        cr.a[p] = P::load_raw(kp);
+        cr.b[p] = P::load_raw(kp + D);
+      }
+    }
+  };
+  auto store_chunk = [&](int buf) {
+    uint16_t* ka = img + buf * L::buf_elems;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      P::stage(ka, LO, img_off(p * 32 + r_in, c8), cr.a[p]);
+      P::stage(ka + L::img_elems, LO, img_off(p * 32 + r_in, c8), cr.b[p]);
+    }
+  };
+
+  float m[2] = {-INFINITY, -INFINITY}, l[2] = {0.f, 0.f};
+  f32x4 o[2][4];                                  // O^T: [channel dt*16 + g*4 + r][query c]
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nchunks = (nkeys + KC - 1) / KC;
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+#pragma unroll 1
+  for (int ch = 0; ch < nchunks; ++ch) {
+    if (ch + 1 < nchunks) load_chunk(ch + 1);
+    const uint16_t* Ks = img + (ch & 1) * L::buf_elems;
+    const uint16_t* Vs = Ks + L::img_elems;
+    const int k0 = ch * KC;
+    const int nt = (nkeys - k0 + 15) / 16 < 4 ? (nkeys - k0 + 15) / 16 : 4;      // key tiles of this chunk (uniform)
+    f32x4 s[2][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (k < nt) {
+        const Op ka0 = P::tile_op(Ks, LO, k, fo.a[0]), ka1 = P::tile_op(Ks, LO, k, fo.a[1]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          s[t][k] = mfma(ka0, qf[t][0], f32x4{0.f, 0.f, 0.f, 0.f});
+          s[t][k] = mfma(ka1, qf[t][1], s[t][k]);
+        }
+      } else {
+        s[0][k] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        s[1][k] = s[0][k];
+      }
+    }
+    // s[t][k][r] = raw S[query c of tile t][key k0 + k*16 + g*4 + r]
+    Op pa[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      if (k0 + nt * 16 > nkeys) {                 // the chunk holds padded keys (zero rows): mask them
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            s[t][k][r] = (k0 + k * 16 + g * 4 + r < nkeys) ? s[t][k][r] : -INFINITY;
+      }
+      // the cls query sees the cls key (key 0) only in frame 0, so that the F partials count it once
+      if (ch == 0 && cls_t[t] && f != 0 && g == 0) s[t][0][0] = -INFINITY;
+      float mg = -INFINITY;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) mg = fmaxf(mg, fmaxf(fmaxf(s[t][k][0], s[t][k][1]), fmaxf(s[t][k][2], s[t][k][3])));
+      mg = fmaxf(mg, __shfl_xor(mg, 16, 64));
+      mg = fmaxf(mg, __shfl_xor(mg, 32, 64));
+      const float mn = fmaxf(m[t], mg);
+      const float al = (m[t] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((m[t] - mn) * kExp2);
+      const float mk = (mn == -INFINITY) ? 0.f : mn * kExp2;
+      m[t] = mn;
+      float ls = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = __builtin_amdgcn_exp2f(fmaf(s[t][k][r], kExp2, -mk));
+          s[t][k][r] = p;
+          ls += p;
+        }
+      l[t] = l[t] * al + ls;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[t][dt][r] *= al;           // transposed accumulator: the factor is lane-local
+      pa[t][0] = P::pack(s[t][0], s[t][1]);
+      pa[t][1] = P::pack(s[t][2], s[t][3]);
+    }
+    // O^T += V^T P^T over the chunk's two 32-key halves: every transpose read of V feeds both query tiles
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (2 * j < nt) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const Tr lo = P::tile_tr(Vs, LO, 2 * j, fo.tr[dt]);
+          const Tr hi = P::tile_tr(Vs, LO, 2 * j + 1, fo.tr[dt]);
+          const Op vb = P::join(lo, hi);
+          o[0][dt] = mfma(vb, pa[0][j], o[0][dt]);
+          o[1][dt] = mfma(vb, pa[1][j], o[1][dt]);
+        }
+      }
+    }
+    if (ch + 1 < nchunks) store_chunk((ch + 1) & 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    float lt = l[t];
+    lt += __shfl_xor(lt, 16, 64);
+    lt += __shfl_xor(lt, 32, 64);
+    if (!live[t]) continue;
+    if (cls_t[t]) {
+      // record of the cls query over this frame's keys: (max, sum, un-normalised acc[64]) = query column 0
+      float* rec = cls_ws + (((size_t)b * H + h) * F + f) * CLS_REC;
+      if (c == 0) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) rec[2 + dt * 16 + g * 4 + r] = o[t][dt][r];
+        if (g == 0) { rec[0] = m[t] * 0.125f; rec[1] = lt; }
+      }
+      continue;
+    }
+    const int qrow = qt[t] * 16 + c;
+    if (qrow < N) {
+      const float linv = P::kSplit ? 1.0f / lt : __builtin_amdgcn_rcpf(lt);
+      io_t* orow = out + ((size_t)b * T + tok0 + qrow) * D + h * 64;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        P::store4(orow + dt * 16 + g * 4, o[t][dt][0] * linv, o[t][dt][1] * linv, o[t][dt][2] * linv,
+                  o[t][dt][3] * linv);
+      if (g == 0) lse[((size_t)b * H + h) * T + tok0 + qrow] = m[t] * 0.125f + __logf(lt);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// dQ (and delta)
+// ------------------------------------------------------------------------------------------------------------
+template <typename P>
+__global__ __launch_bounds__(256, (P::kSplit ? 1 : 3)) void space_stream_dq_kernel(
+    const typename P::io_t* __restrict__ qkv, const typename P::io_t* __restrict__ out,
+    const typename P::io_t* __restrict__ dout, const float* __restrict__ lse, typename P::io_t* __restrict__ dqkv,
+    float* __restrict__ delta, float* __restrict__ atom_ws, int F, int N, int H, int NB) {
+  using io_t = typename P::io_t;
+  using Op = typename P::Op;
+  using Tr = typename P::Tr;
+  using L = StreamLds<P::kImages>;
+  constexpr int LO = L::lo_off;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint16_t* img = reinterpret_cast<uint16_t*>(smem);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int blk = blockIdx.x % NB, grp = blockIdx.x / NB;
+  const int h = grp % H, f = (grp / H) % F, b = grp / (H * F);
+  const int D = H * 64, T = 1 + F * N, nkeys = N + 1, tok0 = 1 + f * N;
+  const size_t ts = (size_t)3 * D;
+  const io_t* base = qkv + (size_t)b * T * ts + h * 64;
+  const io_t* obase = out + (size_t)b * T * D + h * 64;
+  const io_t* dobase = dout + (size_t)b * T * D + h * 64;
+  const float* lrow = lse + ((size_t)b * H + h) * T;
+  float* drow = delta + ((size_t)b * H + h) * T;
+  float* cls_slab = atom_ws + ((size_t)b * H + h) * 192;        // d cls q | d cls k | d cls v
+  const int c = lane & 15, g = lane >> 4;
+  const int nqt = (N + 15) / 16, ntiles = nqt + 1;
+  const FragOff fo = frag_offsets(lane);
+
+  int qt[2];
+  bool live[2], cls_t[2];
+  Op qf[2][2], gf[2][2];
+  float Lk[2], dl[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    qt[t] = blk * 8 + wave * 2 + t;
+    live[t] = qt[t] < ntiles;
+    if (!live[t]) qt[t] = 0;
+    cls_t[t] = qt[t] == nqt;
+    const int qr = qt[t] * 16 + c;
+    const int tok = cls_t[t] ? 0 : tok0 + (qr < N ? qr : N - 1);
+    const io_t* qp = base + (size_t)tok * ts + g * 8;
+    qf[t][0] = P::load_op(qp);
+    qf[t][1] = P::load_op(qp + 32);
+    gf[t][0] = P::load_op(dobase + (size_t)tok * D + g * 8);
+    gf[t][1] = P::load_op(dobase + (size_t)tok * D + g * 8 + 32);
+    const Op y0 = P::load_op(obase + (size_t)tok * D + g * 8), y1 = P::load_op(obase + (size_t)tok * D + g * 8 + 32);
+    float a[8], bb[8], acc = 0.f;
+    P::to_f32(gf[t][0], a);
+    P::to_f32(y0, bb);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc = fmaf(a[i], bb[i], acc);
+    P::to_f32(gf[t][1], a);
+    P::to_f32(y1, bb);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc = fmaf(a[i], bb[i], acc);
+    acc += __shfl_xor(acc, 16, 64);
+    acc += __shfl_xor(acc, 32, 64);
+    dl[t] = acc;
+    Lk[t] = lrow[tok] * kLog2e;
+    // delta of the patch queries and -- once per group: it is the same in every frame -- of the cls query (token 0)
+    if (live[t] && g == 0 && ((!cls_t[t] && qr < N) || (cls_t[t] && c == 0))) drow[tok] = acc;
+  }
+
+  const int c8 = tid & 7, r_in = tid >> 3;
+  ChunkRegs<P> cr;
+  auto load_chunk = [&](int ch) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int kidx = ch * KC + p * 32 + r_in;
+      cr.a[p] = P::zero_raw();
+      cr.b[p] = P::zero_raw();
+      if (kidx < nkeys) {
+        const io_t* kp = base + (size_t)(kidx == 0 ? 0 : tok0 + kidx - 1) * ts + D + c8 * 8;
+        cr.a[p] = P::load_raw(kp);
+        cr.b[p] = P::load_raw(kp + D);
+      }
+    }
+  };
+  auto store_chunk = [&](int buf) {
+    uint16_t* ka = img + buf * L::buf_elems;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      P::stage(ka, LO, img_off(p * 32 + r_in, c8), cr.a[p]);
+      P::stage(ka + L::img_elems, LO, img_off(p * 32 + r_in, c8), cr.b[p]);
+    }
+  };
+
+  f32x4 o[2][4];                                  // dQ^T: [channel dt*16 + g*4 + r][query c]
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nchunks = (nkeys + KC - 1) / KC;
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+#pragma unroll 1
+  for (int ch = 0; ch < nchunks; ++ch) {
+    if (ch + 1 < nchunks) load_chunk(ch + 1);
+    const uint16_t* Ks = img + (ch & 1) * L::buf_elems;
+    const uint16_t* Vs = Ks + L::img_elems;
+    const int k0 = ch * KC;
+    const int nt = (nkeys - k0 + 15) / 16 < 4 ? (nkeys - k0 + 15) / 16 : 4;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {                 // the chunk's two 32-key halves
+      if (2 * j >= nt) continue;
+      Op kf[2][2], vf[2][2];
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          kf[kt][hh] = P::tile_op(Ks, LO, 2 * j + kt, fo.a[hh]);
+          vf[kt][hh] = P::tile_op(Vs, LO, 2 * j + kt, fo.a[hh]);
+        }
+      Op pa[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+        f32x4 p0 = {-dl[t], -dl[t], -dl[t], -dl[t]}, p1 = p0;     // dP - delta: delta rides in the accumulator
+        s0 = mfma(kf[0][0], qf[t][0], s0);
+        p0 = mfma(vf[0][0], gf[t][0], p0);
+        s1 = mfma(kf[1][0], qf[t][0], s1);
+        p1 = mfma(vf[1][0], gf[t][0], p1);
+        s0 = mfma(kf[0][1], qf[t][1], s0);
+        p0 = mfma(vf[0][1], gf[t][1], p0);
+        s1 = mfma(kf[1][1], qf[t][1], s1);
+        p1 = mfma(vf[1][1], gf[t][1], p1);
+        float d0[4], d1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float e0 = __builtin_amdgcn_exp2f(fmaf(s0[r], kExp2, -Lk[t]));
+          float e1 = __builtin_amdgcn_exp2f(fmaf(s1[r], kExp2, -Lk[t]));
+          const int key0 = k0 + (2 * j) * 16 + g * 4 + r, key1 = key0 + 16;
+          e0 = key0 < nkeys ? e0 : 0.f;           // padded key rows are zero, but exp2(-lse) may overflow: mask
+          e1 = key1 < nkeys ? e1 : 0.f;
+          if (cls_t[t] && f != 0 && key0 == 0) e0 = 0.f;        // (cls query, cls key) outside frame 0
+          d0[r] = e0 * p0[r];
+          d1[r] = e1 * p1[r];
+        }
+        pa[t] = P::pack(d0, d1);
+      }
+      // dQ^T += K^T . dS^T for these 32 keys: A fragments are transpose reads of the K image
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const Tr lo = P::tile_tr(Ks, LO, 2 * j, fo.tr[dt]);
+        const Tr hi = P::tile_tr(Ks, LO, 2 * j + 1, fo.tr[dt]);
+        const Op kb = P::join(lo, hi);
+        o[0][dt] = mfma(kb, pa[0], o[0][dt]);
+        o[1][dt] = mfma(kb, pa[1], o[1][dt]);
+      }
+    }
+    if (ch + 1 < nchunks) store_chunk((ch + 1) & 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    if (!live[t]) continue;
+    const int qrow = qt[t] * 16 + c;
+    if (cls_t[t]) {
+      if (c == 0) {                               // this frame's share of d(cls q)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) atomicAdd(cls_slab + dt * 16 + g * 4 + r, o[t][dt][r] * 0.125f);
+      }
+    } else if (qrow < N) {
+      io_t* row = dqkv + (size_t)b * T * ts + (size_t)(tok0 + qrow) * ts + h * 64;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        P::store4(row + dt * 16 + g * 4, o[t][dt][0] * 0.125f, o[t][dt][1] * 0.125f, o[t][dt][2] * 0.125f,
+                  o[t][dt][3] * 0.125f);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// dK / dV
+// ------------------------------------------------------------------------------------------------------------
+template <typename P>
+__global__ __launch_bounds__(256, (P::kSplit ? 1 : 2)) void space_stream_dkv_kernel(
+    const typename P::io_t* __restrict__ qkv, const typename P::io_t* __restrict__ dout,
+    const float* __restrict__ lse, const float* __restrict__ delta, typename P::io_t* __restrict__ dqkv,
+    float* __restrict__ atom_ws, int F, int N, int H, int NB) {
+  using io_t = typename P::io_t;
+  using Op = typename P::Op;
+  using Tr = typename P::Tr;
+  using L = StreamLds<P::kImages>;
+  constexpr int LO = L::lo_off;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint16_t* img = reinterpret_cast<uint16_t*>(smem);
+  float* vec = reinterpret_cast<float*>(smem + L::vec_off);      // [2 buffers][lse(64) | delta(64)]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int blk = blockIdx.x % NB, grp = blockIdx.x / NB;
+  const int h = grp % H, f = (grp / H) % F, b = grp / (H * F);
+  const int D = H * 64, T = 1 + F * N, nkeys = N + 1, tok0 = 1 + f * N;
+  const int nq = N + 1;                             // queries of the group: N patch rows, then the cls query (row N)
+  const size_t ts = (size_t)3 * D;
+  const io_t* base = qkv + (size_t)b * T * ts + h * 64;
+  const io_t* dobase = dout + (size_t)b * T * D + h * 64;
+  const float* lrow = lse + ((size_t)b * H + h) * T;
+  const float* drow = delta + ((size_t)b * H + h) * T;
+  float* cls_slab = atom_ws + ((size_t)b * H + h) * 192;
+  const int c = lane & 15, g = lane >> 4;
+  const int nkt = (nkeys + 15) / 16;
+  const FragOff fo = frag_offsets(lane);
+
+  // this wave's two key tiles (32 keys): fragments straight from HBM
+  int kt[2];
+  bool live[2];
+  Op kk[2][2], vv[2][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    kt[t] = blk * 8 + wave * 2 + t;
+    live[t] = kt[t] < nkt;
+    const int krow = kt[t] * 16 + c;
+    kk[t][0] = P::zero_op(); kk[t][1] = kk[t][0]; vv[t][0] = kk[t][0]; vv[t][1] = kk[t][0];
+    if (live[t] && krow < nkeys) {
+      const io_t* kptr = base + (size_t)(krow == 0 ? 0 : tok0 + krow - 1) * ts + D + g * 8;
+      kk[t][0] = P::load_op(kptr);
+      kk[t][1] = P::load_op(kptr + 32);
+      vv[t][0] = P::load_op(kptr + D);
+      vv[t][1] = P::load_op(kptr + D + 32);
+    }
+  }
+
+  // chunk staging: query row qidx = chunk * KC + r is patch token tok0 + qidx (qidx < N) or the cls token (qidx = N)
+  const int c8 = tid & 7, r_in = tid >> 3;
+  ChunkRegs<P> cr;
+  float lse_r = INFINITY, del_r = 0.f;              // threads 0..63: lse (log2 units) / delta of row tid of the chunk
+  auto load_chunk = [&](int ch) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int qidx = ch * KC + p * 32 + r_in;
+      cr.a[p] = P::zero_raw();
+      cr.b[p] = P::zero_raw();
+      if (qidx < nq) {
+        const int tk = qidx < N ? tok0 + qidx : 0;
+        cr.a[p] = P::load_raw(base + (size_t)tk * ts + c8 * 8);
+        cr.b[p] = P::load_raw(dobase + (size_t)tk * D + c8 * 8);
+      }
+    }
+    if (tid < KC) {
+      const int qidx = ch * KC + tid;
+      lse_r = INFINITY;                             // padded queries: exp2(-inf) = 0
+      del_r = 0.f;
+      if (qidx < nq) {
+        const int tk = qidx < N ? tok0 + qidx : 0;
+        lse_r = lrow[tk] * kLog2e;
+        del_r = drow[tk];
+      }
+    }
+  };
+  auto store_chunk = [&](int buf) {
+    uint16_t* qa = img + buf * L::buf_elems;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      P::stage(qa, LO, img_off(p * 32 + r_in, c8), cr.a[p]);
+      P::stage(qa + L::img_elems, LO, img_off(p * 32 + r_in, c8), cr.b[p]);
+    }
+    if (tid < KC) {
+      vec[buf * 2 * KC + tid] = lse_r;
+      vec[buf * 2 * KC + KC + tid] = del_r;
+    }
+  };
+
+  f32x4 adk[2][4], adv[2][4];                       // dK^T, dV^T: [channel dt*16 + g*4 + r][key c]
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { adk[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; adv[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+  const int nchunks = (nq + KC - 1) / KC;
+  const int cls_chunk = N / KC, cls_half = (N % KC) >> 5, cls_sub = N & 31;     // where the cls query sits
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+#pragma unroll 1
+  for (int ch = 0; ch < nchunks; ++ch) {
+    if (ch + 1 < nchunks) load_chunk(ch + 1);
+    const uint16_t* Qs = img + (ch & 1) * L::buf_elems;
+    const uint16_t* Gs = Qs + L::img_elems;
+    const float* lse_s = vec + (ch & 1) * 2 * KC;
+    const float* del_s = lse_s + KC;
+    const int q0 = ch * KC;
+    const int nqt_c = (nq - q0 + 15) / 16 < 4 ? (nq - q0 + 15) / 16 : 4;       // query tiles of this chunk (uniform)
+#pragma unroll
+    for (int qh = 0; qh < 2; ++qh) {               // the chunk's two 32-query halves
+      if (2 * qh >= nqt_c) continue;
+      const uint16_t* Qp = Qs + qh * 32 * RS;
+      const uint16_t* Gp = Gs + qh * 32 * RS;
+      Op qa[2][2], ga[2][2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          qa[q][hh] = P::tile_op(Qp, LO, q, fo.a[hh]);
+          ga[q][hh] = P::tile_op(Gp, LO, q, fo.a[hh]);
+        }
+      const float4 ls0 = *reinterpret_cast<const float4*>(lse_s + qh * 32 + g * 4);
+      const float4 ls1 = *reinterpret_cast<const float4*>(lse_s + qh * 32 + 16 + g * 4);
+      const float4 de0 = *reinterpret_cast<const float4*>(del_s + qh * 32 + g * 4);
+      const float4 de1 = *reinterpret_cast<const float4*>(del_s + qh * 32 + 16 + g * 4);
+      const float lsa[8] = {ls0.x, ls0.y, ls0.z, ls0.w, ls1.x, ls1.y, ls1.z, ls1.w};
+      const float dea[8] = {de0.x, de0.y, de0.z, de0.w, de1.x, de1.y, de1.z, de1.w};
+      // (cls query, cls key) outside frame 0 is not attended: one element of the group's first key tile
+      const bool kill_here = f != 0 && ch == cls_chunk && qh == cls_half;
+      Op pa[2], da[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+        f32x4 p0 = {-dea[0], -dea[1], -dea[2], -dea[3]}, p1 = {-dea[4], -dea[5], -dea[6], -dea[7]};    // dP - delta
+        s0 = mfma(qa[0][0], kk[t][0], s0);
+        s1 = mfma(qa[1][0], kk[t][0], s1);
+        p0 = mfma(ga[0][0], vv[t][0], p0);
+        p1 = mfma(ga[1][0], vv[t][0], p1);
+        s0 = mfma(qa[0][1], kk[t][1], s0);
+        s1 = mfma(qa[1][1], kk[t][1], s1);
+        p0 = mfma(ga[0][1], vv[t][1], p0);
+        p1 = mfma(ga[1][1], vv[t][1], p1);
+        // s0[r] = S[query q0 + qh*32 + g*4 + r][key kt[t]*16 + c], s1: queries + 16
+        const bool kill_pair = kill_here && kt[t] == 0 && c == 0;
+        float e0[4], e1[4], d0[4], d1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          e0[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], kExp2, -lsa[r]));
+          e1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], kExp2, -lsa[4 + r]));
+          e0[r] = (kill_pair && g * 4 + r == cls_sub) ? 0.f : e0[r];
+          e1[r] = (kill_pair && 16 + g * 4 + r == cls_sub) ? 0.f : e1[r];
+          d0[r] = e0[r] * p0[r];
+          d1[r] = e1[r] * p1[r];
+        }
+        pa[t] = P::pack(e0, e1);
+        da[t] = P::pack(d0, d1);
+      }
+      // dV^T += dO^T P, dK^T += Q^T dS: every transpose read feeds both key tiles
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const Tr g_lo = P::tile_tr(Gp, LO, 0, fo.tr[dt]), g_hi = P::tile_tr(Gp, LO, 1, fo.tr[dt]);
+        const Tr q_lo = P::tile_tr(Qp, LO, 0, fo.tr[dt]), q_hi = P::tile_tr(Qp, LO, 1, fo.tr[dt]);
+        const Op gb = P::join(g_lo, g_hi), qb = P::join(q_lo, q_hi);
+        adv[0][dt] = mfma(gb, pa[0], adv[0][dt]);
+        adk[0][dt] = mfma(qb, da[0], adk[0][dt]);
+        adv[1][dt] = mfma(gb, pa[1], adv[1][dt]);
+        adk[1][dt] = mfma(qb, da[1], adk[1][dt]);
+      }
+    }
+    if (ch + 1 < nchunks) store_chunk((ch + 1) & 1);
+    __syncthreads();
+  }
+
+  io_t* dkb = dqkv + (size_t)b * T * ts + D + h * 64;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    if (!live[t]) continue;
+    const int krow = kt[t] * 16 + c;
+    if (krow >= 1 && krow < nkeys) {
+      io_t* row = dkb + (size_t)(tok0 + krow - 1) * ts;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        P::store4(row + dt * 16 + g * 4, adk[t][dt][0] * 0.125f, adk[t][dt][1] * 0.125f, adk[t][dt][2] * 0.125f,
+                  adk[t][dt][3] * 0.125f);
+        P::store4(row + D + dt * 16 + g * 4, adv[t][dt][0], adv[t][dt][1], adv[t][dt][2], adv[t][dt][3]);
+      }
+    } else if (krow == 0) {          // the cls KEY collects gradient from every frame: f32 atomics
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          atomicAdd(cls_slab + 64 + dt * 16 + g * 4 + r, adk[t][dt][r] * 0.125f);
+          atomicAdd(cls_slab + 128 + dt * 16 + g * 4 + r, adv[t][dt][r]);
+        }
+    }
+  }
+}
+
+std::atomic<int> g_stream_mode{0};      // 0 auto (groups the resident kernels do not take two-per-CU), 1 always, -1 never
+
+template <typename P>
+int launch_stream_fwd(const void* qkv, void* out, float* lse, float* ws, int B, int F, int N, int H, hipStream_t st) {
+  using io_t = typename P::io_t;
+  using L = StreamLds<P::kImages>;
+  const int NB = ((N + 15) / 16 + 1 + 7) / 8;
+  if (L::total_fwd > 64 * 1024)
+    if (int rc = lvl_allow_lds<space_stream_fwd_kernel<P>>()) return rc;
+  hipLaunchKernelGGL((space_stream_fwd_kernel<P>), dim3((unsigned)(B * F * H * NB)), dim3(256), L::total_fwd, st,
+                     (const io_t*)qkv, (io_t*)out, lse, ws, F, N, H, NB);
+  LVL_CHECK_LAUNCH("space_stream_fwd");
+  return LVL_OK;
+}
+
+template <typename P>
+int launch_stream_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* delta,
+                      float* atom_ws, int B, int F, int N, int H, hipStream_t st) {
+  using io_t = typename P::io_t;
+  using L = StreamLds<P::kImages>;
+  const int NBq = ((N + 15) / 16 + 1 + 7) / 8, NBk = ((N + 1 + 15) / 16 + 7) / 8;
+  if (L::total_dkv > 64 * 1024) {
+    if (int rc = lvl_allow_lds<space_stream_dq_kernel<P>>()) return rc;
+    if (int rc = lvl_allow_lds<space_stream_dkv_kernel<P>>()) return rc;
+  }
+  hipLaunchKernelGGL((space_stream_dq_kernel<P>), dim3((unsigned)(B * F * H * NBq)), dim3(256), L::total_fwd, st,
+                     (const io_t*)qkv, (const io_t*)out, (const io_t*)dout, lse, (io_t*)dqkv, delta, atom_ws, F, N, H,
+                     NBq);
+  LVL_CHECK_LAUNCH("space_stream_dq");
+  hipLaunchKernelGGL((space_stream_dkv_kernel<P>), dim3((unsigned)(B * F * H * NBk)), dim3(256), L::total_dkv, st,
+                     (const io_t*)qkv, (const io_t*)dout, lse, delta, (io_t*)dqkv, atom_ws, F, N, H, NBk);
+  LVL_CHECK_LAUNCH("space_stream_dkv");
+  return LVL_OK;
+}
+
+}  // namespace
+
+void lvl_launch_cls_combine(const float* ws, void* out, float* lse, int B, int H, int nparts, int T, int dtype,
+                            hipStream_t st);
+void lvl_launch_cls_grad_finalize(const float* atom_ws, void* dqkv, int B, int T, int H, int dtype, hipStream_t st);
+
+// Test / measurement hook: 1 = the streaming kernels for EVERY space group (parity tests at small shapes, A/B against the
+// resident kernels), -1 = never, 0 = the shipped choice (lvl_space_stream_wanted).
+extern "C" int lvl_debug_space_stream(int mode) {
+  g_stream_mode.store(mode < 0 ? -1 : (mode > 0 ? 1 : 0));
+  return LVL_OK;
+}
+
+// the shipped choice: groups of more than 288 keys (bf16: the resident kernels would run one 4-wave workgroup per CU;
+// float32: their four images do not fit the LDS at all)
+bool lvl_space_stream_wanted(int F, int N, int dtype) {
+  const int mode = g_stream_mode.load();
+  if (mode != 0) return mode > 0;
+  return N + 1 > 288 || (dtype == LVL_F32 && N + 1 > 272);
+}
+
+int lvl_space_stream_fwd(const void* qkv, void* out, float* lse, float* ws, int B, int F, int N, int H, int dtype,
+                         hipStream_t st) {
+  const int rc = dtype == LVL_F32 ? launch_stream_fwd<PrecSplit>(qkv, out, lse, ws, B, F, N, H, st)
+                                  : launch_stream_fwd<PrecBf16>(qkv, out, lse, ws, B, F, N, H, st);
+  if (rc != LVL_OK) return rc;
+  lvl_launch_cls_combine(ws, out, lse, B, H, F, 1 + F * N, dtype, st);
+  LVL_CHECK_LAUNCH("cls_combine");
+  return LVL_OK;
+}
+
+// ws layout: delta [B*H*T] f32, then atomics [B*H*192] f32 (d cls q | d cls k | d cls v)
+int lvl_space_stream_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* ws,
+                         int B, int F, int N, int H, int dtype, hipStream_t st) {
+  const int T = 1 + F * N;
+  float* delta = ws;
+  float* atom_ws = ws + (size_t)B * H * T;
+  hipError_t e = hipMemsetAsync(atom_ws, 0, (size_t)B * H * 192 * sizeof(float), st);
+  if (e != hipSuccess) return lvl_fail(LVL_EHIP, "space_stream_bwd memset: %s", hipGetErrorString(e));
+  const int rc = dtype == LVL_F32
+                     ? launch_stream_bwd<PrecSplit>(qkv, out, dout, lse, dqkv, delta, atom_ws, B, F, N, H, st)
+                     : launch_stream_bwd<PrecBf16>(qkv, out, dout, lse, dqkv, delta, atom_ws, B, F, N, H, st);
+  if (rc != LVL_OK) return rc;
+  lvl_launch_cls_grad_finalize(atom_ws, dqkv, B, T, H, dtype, st);
+  LVL_CHECK_LAUNCH("cls_grad_finalize");
+  return LVL_OK;
+}

@@ -1,0 +1,116 @@
+"""GPU (-m gpu): the key-tiled STREAMING space-attention kernels (csrc/attn_space_stream.hip; BASELINE configs[3]:
+TSF-L/14 at 336 has 577 keys per space group). Forced on for every shape (lvl_debug_space_stream(1)) they must agree
+with the oracle like the LDS-resident kernels do -- chunk boundaries (64 keys), partially filled last chunks, fewer
+query tiles than a workgroup owns, the cls query tile and the cls key's atomics -- in bf16 and in float32 (split-operand
+f32 class), and exactly on the one-hot problems; by default they take the groups of more than 288 keys."""
+import contextlib
+
+import pytest
+import torch
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+@contextlib.contextmanager
+def stream_mode(mode):
+    from lavila_amd import _cabi as C
+    C.lib().lvl_debug_space_stream(mode)
+    try:
+        yield
+    finally:
+        C.lib().lvl_debug_space_stream(0)
+
+
+def _generic_calls():
+    from lavila_amd import _cabi as C
+    return C.lib().lvl_debug_generic_attention_calls(1)
+
+
+SHAPES = [(2, 3, 5, 2), (2, 2, 1, 2), (1, 3, 31, 2), (2, 2, 32, 1), (1, 2, 63, 2), (1, 1, 64, 3), (1, 2, 127, 1),
+          (1, 4, 196, 12), (1, 1, 256, 16), (1, 2, 287, 1), (1, 1, 288, 1), (1, 2, 576, 2), (1, 1, 591, 1),
+          (1, 1, 640, 1)]
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('B,Fr,N,H', SHAPES)
+def test_streaming_space_attention_vs_oracle(dt, B, Fr, N, H):
+    from lavila_amd import ops
+    g = torch.Generator().manual_seed(7 + Fr + N)
+    T, D = 1 + Fr * N, 64 * H
+    qkv = (torch.randn(B, T, 3 * D, generator=g) * 1.5).to(dt).float()
+    dout = torch.randn(B, T, D, generator=g).to(dt).float()
+    qo = qkv.double().requires_grad_(True)
+    oo = O.divided_attention_core(qo, H, Fr, N, 'space')
+    oo.backward(dout.double())
+    with stream_mode(1):
+        _generic_calls()
+        qg = qkv.to(DEV, dt).requires_grad_(True)
+        bias = torch.zeros(3 * D, device=DEV, requires_grad=True)
+        o = ops.divided_attention(qg, Fr, N, H, 'space', bias=bias)
+        o.backward(dout.to(DEV, dt))
+        torch.cuda.synchronize()
+        assert _generic_calls() == 0
+    if dt == torch.float32:
+        assert (o.detach().double().cpu() - oo.detach()).abs().max() < 1e-4
+        assert (qg.grad.double().cpu() - qo.grad).abs().max() < 1e-4 * max(1.0, qo.grad.abs().max().item())
+        rel = ((qg.grad.double().cpu() - qo.grad).norm() / qo.grad.norm()).item()
+        assert rel < 4e-5, rel
+    else:
+        torch.testing.assert_close(o.detach().float().cpu(), oo.detach().float(), atol=6e-2, rtol=3e-2)
+        torch.testing.assert_close(qg.grad.float().cpu(), qo.grad.float(), atol=0.18, rtol=3e-2)
+        rel = ((qg.grad.double().cpu() - qo.grad).norm() / qo.grad.norm()).item()
+        assert rel < 2e-2, rel
+    # the qkv bias gradient identities (ops._qkv_bias_grad) hold for these kernels' dqkv as well
+    want = qo.grad.sum((0, 1))
+    tol = (3e-2 if dt == torch.bfloat16 else 5e-5) * (want.abs().max().item() + 1e-6)
+    assert (bias.grad.double().cpu() - want).abs().max().item() < tol
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('B,Fr,N,H', [(2, 4, 196, 12), (1, 2, 49, 3), (1, 2, 576, 2), (1, 3, 591, 1), (1, 1, 65, 2)])
+def test_streaming_space_attention_one_hot_exact(dt, B, Fr, N, H):
+    """tests/test_gpu_parity_bf16.py's exact problem through the streaming kernels: out = v[target], dv = scatter-add of
+    dout, dq = dk = 0, bit for bit (float32: values that need the lo images)."""
+    from lavila_amd import ops
+    from test_gpu_parity_bf16 import _check_exact, _one_hot_problem
+    T = 1 + Fr * N
+
+    def allowed(t):
+        if t == 0:
+            return list(range(T))
+        f, n = divmod(t - 1, N)
+        return [0] + [1 + f * N + m for m in range(N)]
+    qkv, dout, out_want, dv_want, _ = _one_hot_problem(B, H, T, allowed, seed=31)
+    if dt == torch.float32:
+        qkv, dout = qkv.float(), dout.float()
+        qkv[..., 2 * 64 * H:] *= 97.0
+        out_want = out_want * 97.0
+    with stream_mode(1):
+        _check_exact(qkv, dout, out_want, dv_want, lambda x: ops.divided_attention(x, Fr, N, H, 'space'))
+
+
+def test_large_groups_take_the_streaming_kernels_and_agree_with_the_resident_ones():
+    """Default dispatch at 577 keys (TSF-L/14 at 336) = the streaming kernels; the round-3 LDS-resident kernels
+    (lvl_debug_space_stream(-1)) give the same result up to bf16 rounding of different summation orders."""
+    from lavila_amd import _cabi as C
+    from lavila_amd import ops
+    assert C.lib().lvl_attention_fast_path(C.ATTN_SPACE, 2, 576, 16) == 1
+    assert C.lib().lvl_attention_fast_path_f32(C.ATTN_SPACE, 2, 576, 16) == 1
+    B, Fr, N, H = 2, 2, 576, 16
+    g = torch.Generator().manual_seed(1)
+    T, D = 1 + Fr * N, 64 * H
+    qkv = torch.randn(B, T, 3 * D, generator=g).to(DEV).bfloat16()
+    dout = torch.randn(B, T, D, generator=g).to(DEV).bfloat16()
+    res = []
+    for mode in (0, -1):
+        with stream_mode(mode):
+            x = qkv.clone().requires_grad_(True)
+            o = ops.divided_attention(x, Fr, N, H, 'space')
+            o.backward(dout)
+            res.append((o.detach().float(), x.grad.float()))
+    torch.testing.assert_close(res[0][0], res[1][0], atol=2e-2, rtol=2e-2)
+    torch.testing.assert_close(res[0][1], res[1][1], atol=6e-2, rtol=3e-2)
+    assert ((res[0][1] - res[1][1]).norm() / res[1][1].norm()).item() < 1e-2

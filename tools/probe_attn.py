@@ -16,6 +16,9 @@ B = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 20
 F, N, H = int(os.environ.get('PROBE_F', '4')), int(os.environ.get('PROBE_N', '196')), int(os.environ.get('PROBE_H', '12'))
 T, D = 1 + F * N, 64 * H
+if 'PROBE_STREAM' in os.environ:      # 1: streaming space kernels for every shape, -1: never (round-3 resident kernels)
+    from lavila_amd import _cabi as C
+    C.lib().lvl_debug_space_stream(int(os.environ['PROBE_STREAM']))
 g = torch.Generator(device='cuda').manual_seed(0)
 qkv = (torch.randn(B, T, 3 * D, device='cuda', generator=g) * 1.0).bfloat16().requires_grad_(True)
 dout = torch.randn(B, T, D, device='cuda', generator=g).bfloat16()
