@@ -49,7 +49,7 @@ struct ChunkRegs { typename P::Raw a[2], b[2]; };
 template <typename P>
 __global__ __launch_bounds__(256, (P::kSplit ? 1 : 3)) void space_stream_fwd_kernel(
     const typename P::io_t* __restrict__ qkv, typename P::io_t* __restrict__ out, float* __restrict__ lse,
-    float* __restrict__ cls_ws, int F, int N, int H, int NB) {
+    float* __restrict__ cls_ws, int F, int N, int H, int NB, int NG) {
   using io_t = typename P::io_t;
   using Op = typename P::Op;
   using Tr = typename P::Tr;
@@ -59,7 +59,12 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : 3)) void space_stream_fwd_ker
   uint16_t* img = reinterpret_cast<uint16_t*>(smem);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int blk = blockIdx.x % NB, grp = blockIdx.x / NB;
+  // XCD-aware decode: workgroup i runs on XCD i % 8 (observed, for speed only); the NB workgroups of a group take the
+  // same XCD so that the rows they all stream are fetched into ONE L2 instead of up to NB of them (measured at 577
+  // keys with group-major block order: the streamed side crossed the fabric ~5x)
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int blk = slot % NB, grp = (slot / NB) * 8 + xcd;
+  if (grp >= NG) return;
   const int h = grp % H, f = (grp / H) % F, b = grp / (H * F);
   const int D = H * 64, T = 1 + F * N, nkeys = N + 1, tok0 = 1 + f * N;
   const size_t ts = (size_t)3 * D;
@@ -238,7 +243,7 @@ template <typename P>
 __global__ __launch_bounds__(256, (P::kSplit ? 1 : 3)) void space_stream_dq_kernel(
     const typename P::io_t* __restrict__ qkv, const typename P::io_t* __restrict__ out,
     const typename P::io_t* __restrict__ dout, const float* __restrict__ lse, typename P::io_t* __restrict__ dqkv,
-    float* __restrict__ delta, float* __restrict__ atom_ws, int F, int N, int H, int NB) {
+    float* __restrict__ delta, float* __restrict__ atom_ws, int F, int N, int H, int NB, int NG) {
   using io_t = typename P::io_t;
   using Op = typename P::Op;
   using Tr = typename P::Tr;
@@ -248,7 +253,12 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : 3)) void space_stream_dq_kern
   uint16_t* img = reinterpret_cast<uint16_t*>(smem);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int blk = blockIdx.x % NB, grp = blockIdx.x / NB;
+  // XCD-aware decode: workgroup i runs on XCD i % 8 (observed, for speed only); the NB workgroups of a group take the
+  // same XCD so that the rows they all stream are fetched into ONE L2 instead of up to NB of them (measured at 577
+  // keys with group-major block order: the streamed side crossed the fabric ~5x)
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int blk = slot % NB, grp = (slot / NB) * 8 + xcd;
+  if (grp >= NG) return;
   const int h = grp % H, f = (grp / H) % F, b = grp / (H * F);
   const int D = H * 64, T = 1 + F * N, nkeys = N + 1, tok0 = 1 + f * N;
   const size_t ts = (size_t)3 * D;
@@ -418,7 +428,7 @@ template <typename P>
 __global__ __launch_bounds__(256, (P::kSplit ? 1 : 2)) void space_stream_dkv_kernel(
     const typename P::io_t* __restrict__ qkv, const typename P::io_t* __restrict__ dout,
     const float* __restrict__ lse, const float* __restrict__ delta, typename P::io_t* __restrict__ dqkv,
-    float* __restrict__ atom_ws, int F, int N, int H, int NB) {
+    float* __restrict__ atom_ws, int F, int N, int H, int NB, int NG) {
   using io_t = typename P::io_t;
   using Op = typename P::Op;
   using Tr = typename P::Tr;
@@ -429,7 +439,12 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : 2)) void space_stream_dkv_ker
   float* vec = reinterpret_cast<float*>(smem + L::vec_off);      // [2 buffers][lse(64) | delta(64)]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int blk = blockIdx.x % NB, grp = blockIdx.x / NB;
+  // XCD-aware decode: workgroup i runs on XCD i % 8 (observed, for speed only); the NB workgroups of a group take the
+  // same XCD so that the rows they all stream are fetched into ONE L2 instead of up to NB of them (measured at 577
+  // keys with group-major block order: the streamed side crossed the fabric ~5x)
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int blk = slot % NB, grp = (slot / NB) * 8 + xcd;
+  if (grp >= NG) return;
   const int h = grp % H, f = (grp / H) % F, b = grp / (H * F);
   const int D = H * 64, T = 1 + F * N, nkeys = N + 1, tok0 = 1 + f * N;
   const int nq = N + 1;                             // queries of the group: N patch rows, then the cls query (row N)
@@ -621,8 +636,9 @@ int launch_stream_fwd(const void* qkv, void* out, float* lse, float* ws, int B, 
   const int NB = ((N + 15) / 16 + 1 + 7) / 8;
   if (L::total_fwd > 64 * 1024)
     if (int rc = lvl_allow_lds<space_stream_fwd_kernel<P>>()) return rc;
-  hipLaunchKernelGGL((space_stream_fwd_kernel<P>), dim3((unsigned)(B * F * H * NB)), dim3(256), L::total_fwd, st,
-                     (const io_t*)qkv, (io_t*)out, lse, ws, F, N, H, NB);
+  const int NG = B * F * H;                       // groups; the grid is padded to whole rounds of 8 XCDs
+  hipLaunchKernelGGL((space_stream_fwd_kernel<P>), dim3((unsigned)((NG + 7) / 8 * 8 * NB)), dim3(256), L::total_fwd, st,
+                     (const io_t*)qkv, (io_t*)out, lse, ws, F, N, H, NB, NG);
   LVL_CHECK_LAUNCH("space_stream_fwd");
   return LVL_OK;
 }
@@ -637,12 +653,13 @@ int launch_stream_bwd(const void* qkv, const void* out, const void* dout, const 
     if (int rc = lvl_allow_lds<space_stream_dq_kernel<P>>()) return rc;
     if (int rc = lvl_allow_lds<space_stream_dkv_kernel<P>>()) return rc;
   }
-  hipLaunchKernelGGL((space_stream_dq_kernel<P>), dim3((unsigned)(B * F * H * NBq)), dim3(256), L::total_fwd, st,
+  const int NG = B * F * H;
+  hipLaunchKernelGGL((space_stream_dq_kernel<P>), dim3((unsigned)((NG + 7) / 8 * 8 * NBq)), dim3(256), L::total_fwd, st,
                      (const io_t*)qkv, (const io_t*)out, (const io_t*)dout, lse, (io_t*)dqkv, delta, atom_ws, F, N, H,
-                     NBq);
+                     NBq, NG);
   LVL_CHECK_LAUNCH("space_stream_dq");
-  hipLaunchKernelGGL((space_stream_dkv_kernel<P>), dim3((unsigned)(B * F * H * NBk)), dim3(256), L::total_dkv, st,
-                     (const io_t*)qkv, (const io_t*)dout, lse, delta, (io_t*)dqkv, atom_ws, F, N, H, NBk);
+  hipLaunchKernelGGL((space_stream_dkv_kernel<P>), dim3((unsigned)((NG + 7) / 8 * 8 * NBk)), dim3(256), L::total_dkv, st,
+                     (const io_t*)qkv, (const io_t*)dout, lse, delta, (io_t*)dqkv, atom_ws, F, N, H, NBk, NG);
   LVL_CHECK_LAUNCH("space_stream_dkv");
   return LVL_OK;
 }

@@ -27,9 +27,12 @@
 // the boundary -- and when its unit is exhausted it takes unclaimed chunks of the other splits of the SAME tile into its own accumulators
 // (its partial slab then simply holds more rows; the slab sum is unchanged). A workgroup whose CU is held by another
 // kernel (an RCCL channel) therefore delays the launch by its tile-mates' share of its rows, not by a second round of
-// the whole kernel; when it finally starts it finds its chunks gone and writes a zero slab. With every CU available
-// nobody steals: each slab holds exactly the rows of the static plan, in the same order -- results are bit-identical
-// to the static schedule and run-to-run deterministic.
+// the whole kernel; when it finally starts it finds its chunks gone and writes a zero slab. When nobody steals, each
+// slab holds exactly the rows of the static plan, in the same order, and the result is bit-identical to the static
+// schedule. That is the common case with every CU available, NOT a guarantee: a workgroup that finishes its unit takes
+// chunks from a tile-mate that is merely slower by more than one chunk (XCD / HBM jitter), the slabs then hold other
+// row sets and the f32 summation order of dW depends on timing (exact on integer operands, last-bit differences
+// otherwise). Bit-reproducible runs: LAVILA_DYNAMIC_TILES=0 (static plan; the default on a single GPU).
 #include "common.h"
 
 int lvl_debug_late_mod();

@@ -500,7 +500,19 @@ class GPT2LMHeadModel(nn.Module):
         return self.lm_head
 
     def _param_key(self):
-        return (ops._generation,) + tuple((p._version, p.data_ptr()) for p in self.parameters())
+        """What the packed inference image was built from: the decoder's OWN parameters (version counter + storage) and a
+        decoder-local generation. (Round 3 keyed on the process-wide weight-copy generation of ops.py, which every
+        optimizer step and every grad-enabled model forward anywhere in the process bumps: a 1.5-B-parameter repack and a
+        hipGraph recapture per batch for nothing -- ADVICE r3.) Writes that bypass the version counter (`param.data`
+        edits, a fused optimizer stepping the decoder) need `invalidate_packed_weights()`."""
+        return (getattr(self, '_pack_gen', 0),) + tuple((p._version, p.data_ptr()) for p in self.parameters())
+
+    def invalidate_packed_weights(self):
+        """Forget the packed bf16 image and the decode sessions built on it (they are rebuilt on the next call)."""
+        self._pack_gen = getattr(self, '_pack_gen', 0) + 1
+        self._packs, self._sessions = {}, {}
+
+    clear_sessions = invalidate_packed_weights
 
     def _compute_dtype(self):
         lp = ops.autocast_dtype()
@@ -545,7 +557,8 @@ class GPT2LMHeadModel(nn.Module):
             raise ValueError(f'sequence of {L} tokens exceeds the decoder\'s {pack.positions} positions')
         ids = input_ids.reshape(-1, L)
         B = ids.shape[0]
-        lo, hi = int(ids.min()), int(ids.max())          # nn.Embedding would fail on these; the gather kernel clamps
+        lo, hi = (int(v) for v in torch.stack(torch.aminmax(ids)).tolist())      # ONE read-back; nn.Embedding would
+        # fail on out-of-range ids, the gather kernel clamps
         if lo < 0 or hi >= pack.vocab:
             raise IndexError(f'input_ids out of range [0, {pack.vocab}): min {lo}, max {hi}')
         with torch.no_grad(), torch.autocast('cuda', enabled=False):
@@ -579,7 +592,8 @@ class GPT2LMHeadModel(nn.Module):
             sess = self._sessions.get(key)
             if sess is not None and sess.pack is pack:
                 return sess.rebind(enc)
+            # keep two: drop the older ones BEFORE the new session's buffers are allocated
+            self._sessions = {k: v for k, v in list(self._sessions.items())[-1:] if v.pack is pack}
             sess = DecodeSession(self, pack, enc, max_length, seqs_per_context, graph)
-            self._sessions = {k: v for k, v in list(self._sessions.items())[-1:] if v.pack is pack}   # keep two
             self._sessions[key] = sess
             return sess

@@ -361,6 +361,42 @@ def load_pretrained_gpt2(name):
     return torch.load(path, map_location='cpu', weights_only=True)
 
 
+_XATTN_TAGS = ('crossattention', 'ln_cross_attn', 'alpha_cattn', 'alpha_dense')
+
+
+def load_gpt2_weights(text_decoder, gpt2_sd):
+    """models.py:919-923: EVERY parameter of the plain GPT-2 is written into the gated decoder (`rsetattr(text_decoder,
+    n + '.data', p.data)` raises on a name it cannot resolve). Accepted key spellings: the LM-head model's
+    (`transformer.h.0...`, what `GPT2LMHeadModel.state_dict()` holds) and the bare `GPT2Model`'s of the hub's raw gpt2
+    checkpoints (`h.0...`, `wte.weight`). Fails loudly if a parameter of the plain GPT-2 part of the decoder -- everything
+    except the cross-attention additions -- is missing from the checkpoint, has another shape, or if the checkpoint holds
+    a parameter the decoder does not know."""
+    own = dict(text_decoder.named_parameters())
+    plain = {n for n in own if not any(t in n for t in _XATTN_TAGS)}
+    loaded = set()
+    with torch.no_grad():
+        for n, v in gpt2_sd.items():
+            if n.endswith(('.attn.bias', '.attn.masked_bias')):          # causal-mask buffers of the HF modules
+                continue
+            key = n if n in own else 'transformer.' + n
+            if n == 'lm_head.weight':                                     # tied to transformer.wte.weight
+                if tuple(v.shape) != tuple(own['transformer.wte.weight'].shape):
+                    raise RuntimeError(f'GPT-2 checkpoint: lm_head.weight {tuple(v.shape)} does not fit the decoder')
+                continue
+            if key not in own:
+                raise RuntimeError(f'GPT-2 checkpoint: parameter {n!r} has no counterpart in the gated decoder')
+            if tuple(own[key].shape) != tuple(v.shape):
+                raise RuntimeError(f'GPT-2 checkpoint: {n!r} is {tuple(v.shape)}, the decoder expects '
+                                   f'{tuple(own[key].shape)}')
+            own[key].copy_(v)
+            loaded.add(key)
+    missing = sorted(plain - loaded)
+    if missing:
+        raise RuntimeError(f'GPT-2 checkpoint: {len(missing)} parameters of the plain GPT-2 were not found '
+                           f'(first: {missing[:3]}); the decoder would keep random weights there')
+    return loaded
+
+
 def _vclm_openai_timesformer(clip_name, vision_kwargs, vision_width, vision_layers, gpt2_name, cross_attn_freq, text_width,
                              heads, gated_xattn, random_init_gpt2, freeze_lm_vclm, freeze_visual_vclm,
                              freeze_visual_vclm_temporal, num_frames, timesformer_gated_xattn, kwargs):
@@ -382,11 +418,7 @@ def _vclm_openai_timesformer(clip_name, vision_kwargs, vision_width, vision_laye
         gpt2_sd = load_pretrained_gpt2(gpt2_name)
         if gpt2_sd is not None:
             print('Loading LM from pretrained weights..')
-            own = dict(text_decoder.named_parameters())
-            with torch.no_grad():
-                for n, v in gpt2_sd.items():
-                    if n in own:                          # models.py:921-923: every parameter of the plain GPT-2
-                        own[n].copy_(v)
+            load_gpt2_weights(text_decoder, gpt2_sd)
     if freeze_lm_vclm:
         print('Freeze the LM part of TextDecoder of VCLM')
         text_decoder.freeze_lm_weights()

@@ -124,6 +124,8 @@ def sample_next_token(logits, top_k, top_p, temperature, target=None, pad_id=-10
     k = 0 if not top_k else min(int(top_k), vocab)
     p = 1.0 if top_p is None else float(top_p)
     t = 1.0 if temperature is None else float(temperature)
+    if not (0.0 < p <= 1.0) or not (t > 0.0) or k < 0:
+        return None          # outside the kernel's domain (the reference's warpers decide what happens): framework ops
     C.check(C.lib().lvl_sample_next_token(C.ptr(logits), stride, rows, vocab, t, k, p, C.ptr(uniform), C.ptr(tgt),
                                           int(pad_id) if pad_id is not None else -100, C.ptr(nxt), C.ptr(nll), C.ptr(cnt),
                                           C.ptr(dbg), C.stream_ptr()), 'lvl_sample_next_token')

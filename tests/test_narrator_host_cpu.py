@@ -230,3 +230,34 @@ def test_narrator_modules_resolve_under_the_reference_import_paths():
     assert n.VCLM_HF is lavila_amd.narrator.VCLM_HF
     assert g.GPT2LMHeadModel is lavila_amd.gpt2_gated.GPT2LMHeadModel and callable(g.augment_gpt2_config)
     assert coca.CrossAttention is lavila_amd.narrator.CrossAttention and coca.LayerNorm is lavila_amd.narrator.LayerNorm
+
+
+def test_pretrained_gpt2_loader_covers_every_plain_parameter_or_raises():
+    """models.py:919-923 writes every parameter of the plain GPT-2 into the gated decoder and fails on a name it cannot
+    resolve. Both checkpoint spellings load (LM-head keys `transformer.h...` and the hub's raw `h...`); a missing, an
+    unknown or a mis-shaped parameter raises instead of leaving random weights behind."""
+    import pytest
+    from lavila_amd.gpt2_gated import GPT2LMHeadModel, augment_gpt2_config, gpt2_config
+    from lavila_amd.models import load_gpt2_weights
+    cfg = augment_gpt2_config(gpt2_config('gpt2'), cross_attn_freq=1, gated_xattn=True)
+    cfg.n_layer, cfg.n_embd, cfg.n_head, cfg.vocab_size, cfg.n_positions = 2, 64, 1, 97, 16
+    dec = GPT2LMHeadModel(cfg)
+    tags = ('crossattention', 'ln_cross_attn', 'alpha_cattn', 'alpha_dense')
+    g = torch.Generator().manual_seed(0)
+    plain = {n: torch.randn(p.shape, generator=g) for n, p in dec.named_parameters() if not any(t in n for t in tags)}
+    plain['transformer.h.0.attn.bias'] = torch.ones(1, 1, 16, 16)          # HF buffers ride along in a state_dict
+    plain['lm_head.weight'] = plain['transformer.wte.weight']
+    for strip in (False, True):
+        sd = {(k[len('transformer.'):] if strip and k.startswith('transformer.') else k): v for k, v in plain.items()}
+        dec2 = GPT2LMHeadModel(cfg)
+        loaded = load_gpt2_weights(dec2, sd)
+        own = dict(dec2.named_parameters())
+        assert all(torch.equal(own[k], plain[k]) for k in loaded) and len(loaded) == len(plain) - 2
+    broken = dict(plain)
+    del broken['transformer.h.1.mlp.c_fc.bias']
+    with pytest.raises(RuntimeError, match='were not found'):
+        load_gpt2_weights(GPT2LMHeadModel(cfg), broken)
+    with pytest.raises(RuntimeError, match='no counterpart'):
+        load_gpt2_weights(GPT2LMHeadModel(cfg), dict(plain, **{'transformer.h.7.ln_1.weight': torch.zeros(64)}))
+    with pytest.raises(RuntimeError, match='expects'):
+        load_gpt2_weights(GPT2LMHeadModel(cfg), dict(plain, **{'transformer.ln_f.weight': torch.zeros(65)}))
