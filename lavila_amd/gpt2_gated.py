@@ -444,6 +444,16 @@ class DecodeSession:
         self.reset()
         return self
 
+    def reorder(self, index):
+        """Beam search: row r continues the caption that row index[r] held (narrator.py:223,337: `input_ids[beam_idx]`;
+        the reference re-runs the prefixes, here the cached keys / values move with their captions). Only the filled
+        positions are gathered; rows of one clip stay inside that clip, so the image keys / values are untouched."""
+        n = self.steps
+        if n == 0:
+            return
+        for c in self.cache:
+            c[:, :n] = c[:, :n].index_select(0, index)
+
     def step(self, ids):
         if self.steps >= self.capacity:
             raise RuntimeError(f'DecodeSession: cache of {self.capacity} positions is full')

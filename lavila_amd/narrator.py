@@ -135,7 +135,7 @@ def sample_next_token(logits, top_k, top_p, temperature, target=None, pad_id=-10
 
 class VCLM_HF(nn.Module):
     """narrator.py:31-147: same constructor; encode_image, forward and generate run on the HIP path (`text_decoder`:
-    a lavila_amd.gpt2_gated.GPT2LMHeadModel); the beam-search variants are not built."""
+    a lavila_amd.gpt2_gated.GPT2LMHeadModel), and so do beam_sample / group_beam_search (round 4)."""
 
     def __init__(self, vision_width: int, vision_model: nn.Module, text_width: int, text_decoder: nn.Module,
                  num_img_queries=256, dim_head=64, heads=8, **kwargs):
@@ -261,9 +261,122 @@ class VCLM_HF(nn.Module):
                 generated = torch.cat((generated, next_token), dim=1)
         return generated, torch.exp(nlls / num_tokens)
 
-    def beam_sample(self, *args, **kwargs):
-        raise NotImplementedError('VCLM_HF.beam_sample (narrator.py:149-241, transformers BeamSearchScorer) is not built; '
-                                  'use generate() -- the reference drivers\' default caption_sample=multinomial_sample')
+    # ---- beam search (narrator.py:149-366) ---------------------------------------------------------------------
+    def _beam_logits(self, kv_cache, image_tokens, rows_per_clip, max_text_length, graph):
+        """-> (step(input_ids) -> next-token logits [rows, vocab] float32, reorder(rows index)). kv_cache: one new row per
+        beam against cached keys / values (the cache rows are re-gathered with the beams after every step); otherwise the
+        reference's schedule: the whole prefix through the decoder every step (narrator.py:180-185,282-286)."""
+        if kv_cache:
+            session = self.text_decoder.decode_session(image_tokens, max_text_length, seqs_per_context=rows_per_clip,
+                                                       graph=graph)
+            return (lambda ids: session.step(ids[:, -1]).float()), session.reorder
+        repeated = image_tokens.repeat_interleave(rows_per_clip, dim=0)
+        return (lambda ids: self.text_decoder(ids.contiguous(), encoder_hidden_states=repeated).logits[:, -1, :].float(),
+                lambda index: None)
 
-    def group_beam_search(self, *args, **kwargs):
-        raise NotImplementedError('VCLM_HF.group_beam_search (narrator.py:243-366) is not built; use generate()')
+    @staticmethod
+    def _warp_beams(scores, top_k, top_p, temperature):
+        """narrator.py:368-389 with num_beams > 1: the same warpers as _warp, each keeping at least TWO tokens per row."""
+        if temperature is not None and temperature != 1.0:
+            scores = scores / temperature
+        if top_k is not None and top_k != 0:
+            k = min(max(int(top_k), 2), scores.shape[-1])
+            kth = torch.topk(scores, k)[0][..., -1, None]
+            scores = scores.masked_fill(scores < kth, float('-inf'))
+        if top_p is not None and top_p < 1.0:
+            sorted_scores, sorted_idx = torch.sort(scores, descending=False)
+            remove = sorted_scores.softmax(dim=-1).cumsum(dim=-1) <= (1 - top_p)
+            remove[..., -2:] = False
+            scores = scores.masked_fill(remove.scatter(1, sorted_idx, remove), float('-inf'))
+        return scores
+
+    def beam_sample(self, image_tokens, tokenizer, target=None, max_text_length=77, top_k=None, top_p=None,
+                    temperature=1.0, length_penalty=1., num_beams=3, num_return_sequences=1, teacher_forcing=False,
+                    early_stopping=False, kv_cache=True, graph=True):
+        """narrator.py:149-241, same arguments and return value (sequences [B * num_return_sequences, <= max_text_length],
+        sequence_scores): every clip runs num_return_sequences independent beam searches of num_beams beams; per step the
+        2 * num_beams candidates of a search are DRAWN (multinomial without replacement over its beams' warped
+        log-probabilities + beam scores, narrator.py:196-208), sorted and handed to the beam bookkeeping
+        (lavila_amd.beam_search.BeamScorer = transformers' BeamSearchScorer). `target`, `teacher_forcing` and
+        `early_stopping` are accepted and unused, as in the reference."""
+        from .beam_search import BeamScorer
+        if self.text_decoder is None:
+            raise NotImplementedError('beam search needs a text decoder (lavila_amd.gpt2_gated.GPT2LMHeadModel)')
+        batch = image_tokens.shape[0]
+        device = image_tokens.device
+        bos, eos, pad = tokenizer.bos_token_id, tokenizer.eos_token_id, tokenizer.pad_token_id
+        per_clip = num_beams * num_return_sequences
+        scorer = BeamScorer(batch * num_return_sequences, num_beams, device, length_penalty=length_penalty)
+        entries = scorer.entries
+        input_ids = torch.full((batch * per_clip, 1), bos, dtype=torch.long, device=device)
+        beam_scores = torch.zeros(entries * num_beams, device=device)
+        reached = torch.zeros(entries * num_beams, dtype=torch.bool, device=device)
+        with torch.no_grad():
+            step, reorder = self._beam_logits(kv_cache, image_tokens, per_clip, max_text_length, graph)
+            for _ in range(max_text_length - 1):
+                scores = F.log_softmax(step(input_ids), dim=-1) + beam_scores[:, None]
+                scores = self._warp_beams(scores, top_k, top_p, temperature)
+                vocab = scores.shape[-1]
+                scores = scores.view(entries, num_beams * vocab)
+                cand = torch.multinomial(F.softmax(scores, dim=-1), num_samples=2 * num_beams)
+                cand_scores, order = torch.sort(torch.gather(scores, -1, cand), descending=True, dim=1)
+                cand = torch.gather(cand, -1, order)
+                beam_scores, new_tokens, rows = scorer.process(input_ids, cand_scores, cand % vocab,
+                                                               torch.div(cand, vocab, rounding_mode='floor'), pad, eos)
+                input_ids = torch.cat([input_ids[rows, :], new_tokens.unsqueeze(-1)], dim=-1)
+                reorder(rows)
+                reached = reached | (input_ids[:, -1] == eos)
+                if scorer.is_done or bool(torch.all(reached)):
+                    break
+            return scorer.finalize(input_ids, beam_scores, max_text_length, pad, eos)
+
+    def group_beam_search(self, image_tokens, tokenizer, target=None, max_text_length=77, top_k=None, top_p=None,
+                          temperature=1.0, length_penalty=1., num_beams=6, num_beam_groups=3, num_return_sequences=1,
+                          teacher_forcing=False, early_stopping=False, kv_cache=True, graph=True):
+        """narrator.py:243-366, same arguments and return value: every clip runs num_beams beams in num_beam_groups groups;
+        the groups take the top 2 * group_size candidates of their own beams in turn (no diversity penalty: the reference
+        skips the logits processors, narrator.py:303-305) and the num_return_sequences best closed hypotheses of a clip
+        are returned."""
+        from .beam_search import BeamScorer
+        if self.text_decoder is None:
+            raise NotImplementedError('beam search needs a text decoder (lavila_amd.gpt2_gated.GPT2LMHeadModel)')
+        batch = image_tokens.shape[0]
+        device = image_tokens.device
+        bos, eos, pad = tokenizer.bos_token_id, tokenizer.eos_token_id, tokenizer.pad_token_id
+        scorer = BeamScorer(batch, num_beams, device, length_penalty=length_penalty, keep=num_return_sequences,
+                            num_beam_groups=num_beam_groups)
+        sub = num_beams // num_beam_groups
+        input_ids = torch.full((batch * num_beams, 1), bos, dtype=torch.long, device=device)
+        beam_scores = torch.full((batch, num_beams), -1e9, dtype=torch.float, device=device)
+        beam_scores[:, ::sub] = 0
+        beam_scores = beam_scores.view(batch * num_beams)
+        reached = torch.zeros(batch * num_beams, dtype=torch.bool, device=device)
+        base = torch.arange(batch, device=device)[:, None] * num_beams
+        with torch.no_grad():
+            step, reorder = self._beam_logits(kv_cache, image_tokens, num_beams, max_text_length, graph)
+            current = torch.zeros(batch * num_beams, dtype=torch.long, device=device)
+            gather_rows = torch.zeros(batch * num_beams, dtype=torch.long, device=device)
+            for _ in range(max_text_length - 1):
+                logits = step(input_ids)                                   # every beam of every group, once per step
+                for gi in range(num_beam_groups):
+                    lo = gi * sub
+                    rows_g = (base + torch.arange(lo, lo + sub, device=device)[None, :]).reshape(-1)     # this group's rows
+                    group_ids = input_ids[rows_g]
+                    scores = F.log_softmax(logits[rows_g], dim=-1) + beam_scores[rows_g].unsqueeze(-1)
+                    scores = self._warp_beams(scores, top_k, top_p, temperature)
+                    vocab = scores.shape[-1]
+                    cand_scores, cand = torch.topk(scores.view(batch, sub * vocab), 2 * sub, dim=1, largest=True,
+                                                   sorted=True)
+                    new_scores, new_tokens, picked = scorer.process(group_ids, cand_scores, cand % vocab,
+                                                                    torch.div(cand, vocab, rounding_mode='floor'), pad, eos)
+                    beam_scores[rows_g] = new_scores
+                    input_ids[rows_g] = group_ids[picked]
+                    current[rows_g] = new_tokens
+                    # `picked` indexes the group's rows (entry * sub + beam): as rows of the whole batch
+                    gather_rows[rows_g] = num_beams * torch.div(picked, sub, rounding_mode='floor') + lo + picked % sub
+                input_ids = torch.cat([input_ids, current.unsqueeze(-1)], dim=-1)
+                reorder(gather_rows)
+                reached = reached | (input_ids[:, -1] == eos)
+                if scorer.is_done or bool(torch.all(reached)):
+                    break
+            return scorer.finalize(input_ids, beam_scores, max_text_length, pad, eos)

@@ -460,6 +460,68 @@ def run_narrator_decoder_golden():
     torch.save(out, os.path.join(GOLDEN, 'narrator_decoder.pt'))
 
 
+def run_narrator_beam_golden():
+    """`VCLM_HF.beam_sample` and `VCLM_HF.group_beam_search` of the unmodified narrator.py (narrator.py:149-366) on the
+    narrator_decoder.pt models (same procedural weights, same image tokens), with the transformers-4.27 BeamSearchScorer
+    restated in oracle/beam_scorer.py (the installed transformers has none). beam_sample draws 2 * num_beams candidates
+    with torch.multinomial: with top_k = 2 (min_tokens_to_keep = 2 for beams, narrator.py:380-383) every beam keeps exactly
+    two tokens, the draw without replacement returns ALL 2 * num_beams candidates and the following sort makes the
+    outcome independent of the random stream -- the deterministic setting the goldens use."""
+    from transformers import GPT2Config
+    from oracle.ref_import import load_reference_narrator
+    ref = load_reference_narrator()
+    c, d = NARRATOR, DECODER
+    out = {'variants': {}}
+    for vi, (name, var) in enumerate(d['variants'].items()):
+        torch.manual_seed(0)
+        vis = ref.timesformer.SpaceTimeTransformer(
+            img_size=c['img'], patch_size=c['patch'], embed_dim=c['dim'], depth=c['depth'], num_heads=c['heads'],
+            num_frames=c['frames'], time_init='zeros', attention_style='frozen-in-time', ln_pre=True,
+            act_layer=ref.openai_model.QuickGELU, is_tanh_gating=False)
+        vis.head = nn.Identity()
+        vis.pre_logits = nn.Identity()
+        vis.fc = nn.Identity()
+        base = GPT2Config(vocab_size=d['vocab'], n_positions=d['positions'], n_embd=c['text_width'], n_layer=d['layers'],
+                          n_head=c['pool_heads'], use_cache=False, bos_token_id=d['vocab'] - 1, eos_token_id=d['vocab'] - 1)
+        dec = ref.gpt2_gated.GPT2LMHeadModel(ref.gpt2_gated.augment_gpt2_config(base, **var))
+        model = ref.narrator.VCLM_HF(vision_width=c['dim'], vision_model=vis, text_width=c['text_width'],
+                                     text_decoder=dec, num_img_queries=c['queries'], dim_head=64, heads=c['pool_heads'])
+        shapes, keep, weights = decoder_weights(model, seed=29 + vi)
+        model.load_state_dict(weights, strict=True)
+        dec.lm_head.weight = dec.transformer.wte.weight
+        model.eval()
+        video, _ = O.synthetic_batch(c['batch'], c['frames'], c['img'], seed=78)
+        bos = d['vocab'] - 1
+        runs = {}
+        with torch.no_grad():
+            image_tokens = model.encode_image(video)
+            tok = types.SimpleNamespace(bos_token_id=bos, eos_token_id=-1, pad_token_id=0)
+            L = 12
+            ids0, _ = model.group_beam_search(image_tokens, tok, max_text_length=L, num_beams=4, num_beam_groups=2)
+            # eos ids that the searches really emit, so that hypotheses close and entries finish at different steps
+            eos_a, eos_b = int(ids0[0, 3]), int(ids0[1, 5])
+            cases = {
+                'gbs_free': ('group_beam_search', dict(num_beams=6, num_beam_groups=3, num_return_sequences=2), -1),
+                'gbs_eos': ('group_beam_search', dict(num_beams=4, num_beam_groups=2, num_return_sequences=1), eos_a),
+                'gbs_eos_lp': ('group_beam_search', dict(num_beams=6, num_beam_groups=2, num_return_sequences=3,
+                                                         length_penalty=0.6, top_k=5, temperature=0.8), eos_b),
+                'gbs_one_group': ('group_beam_search', dict(num_beams=3, num_beam_groups=1, num_return_sequences=2,
+                                                            length_penalty=1.5), eos_a),
+                'bs_free': ('beam_sample', dict(num_beams=3, top_k=2), -1),
+                'bs_eos': ('beam_sample', dict(num_beams=3, top_k=2, temperature=0.7, length_penalty=0.8), eos_b),
+                'bs_rep': ('beam_sample', dict(num_beams=2, top_k=2, num_return_sequences=2), eos_a),
+            }
+            for cname, (fn, kw, eos) in cases.items():
+                tok = types.SimpleNamespace(bos_token_id=bos, eos_token_id=eos, pad_token_id=0)
+                torch.manual_seed(5)
+                seq, score = getattr(model, fn)(image_tokens, tok, max_text_length=L, **kw)
+                runs[cname] = {'fn': fn, 'kwargs': kw, 'eos': eos, 'max_text_length': L, 'sequences': seq,
+                               'sequence_scores': score}
+                print('narrator_beam', name, cname, tuple(seq.shape), seq[0].tolist(), [round(x, 4) for x in score.tolist()])
+        out['variants'][name] = {'bos': bos, 'pad': 0, 'runs': runs}
+    torch.save(out, os.path.join(GOLDEN, 'narrator_beam.pt'))
+
+
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     torch.set_num_threads(8)
@@ -480,6 +542,8 @@ def main():
         run_narrator_pool_golden(ref)
     if not only or 'decoder' in only:
         run_narrator_decoder_golden()
+    if not only or 'beam' in only:
+        run_narrator_beam_golden()
 
 
 if __name__ == '__main__':

@@ -84,7 +84,8 @@ def _install_stubs():
 
 def _install_transformers_4_27_names():
     """lavila/models/gpt2_gated.py:36-48 and narrator.py:16 import names of transformers 4.27 that 5.x dropped
-    (SequenceSummary, head pruning helpers, model_parallel_utils, the docstring decorators, BeamSearchScorer). None of
+    (SequenceSummary, head pruning helpers, model_parallel_utils, the docstring decorators, BeamSearchScorer). Except for
+    BeamSearchScorer (restated in oracle/beam_scorer.py for the beam-search goldens) none of
     them is on the path the goldens exercise (GPT2LMHeadModel.forward, VCLM_HF.forward / generate), so inert stand-ins
     are installed under the old names before the unmodified reference source is imported. `get_head_mask` /
     `invert_attention_mask` (PreTrainedModel methods the forward calls, gpt2_gated.py:884,889) are restated from their
@@ -126,9 +127,9 @@ def _install_transformers_4_27_names():
             sys.modules["transformers.utils.model_parallel_utils"] = m
             tu.model_parallel_utils = m
     if not hasattr(transformers, "BeamSearchScorer"):
-        class BeamSearchScorer:                       # beam_sample / group_beam_search only
-            def __init__(self, *a, **k):
-                _unused()
+        # beam_sample / group_beam_search (narrator.py:149-366): the 4.27 class is restated in oracle/beam_scorer.py
+        # (parity unpinned against the absent dependency; the reference's own loops around it run unmodified)
+        from oracle.beam_scorer import BeamSearchScorer
         transformers.BeamSearchScorer = BeamSearchScorer
 
     base = mu.PreTrainedModel

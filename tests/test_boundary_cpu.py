@@ -375,7 +375,7 @@ def test_gemm_tile_counter_reply_register_is_untouched_in_isa(tmp_path):
 def test_narrator_seam_state_dict_matches_reference_names():
     """lavila_amd.narrator.VCLM_HF owns `visual.*`, `img_queries`, `img_attn_pool.*`, `img_attn_pool_norm.*` under the
     reference's names (narrator.py:44-49, coca.py:27-31,76-82), beta buffers included, so those entries of a VCLM_*
-    checkpoint load unchanged; without a decoder module forward says so, and the beam-search variants are not built."""
+    checkpoint load unchanged; without a decoder module forward and the beam searches say so."""
     import contextlib
     import io
     from lavila.models.openai_model import QuickGELU

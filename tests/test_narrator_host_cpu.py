@@ -261,3 +261,75 @@ def test_pretrained_gpt2_loader_covers_every_plain_parameter_or_raises():
         load_gpt2_weights(GPT2LMHeadModel(cfg), dict(plain, **{'transformer.h.7.ln_1.weight': torch.zeros(64)}))
     with pytest.raises(RuntimeError, match='expects'):
         load_gpt2_weights(GPT2LMHeadModel(cfg), dict(plain, **{'transformer.ln_f.weight': torch.zeros(65)}))
+
+
+@pytest.mark.parametrize('variant', ['freq1_gated', 'freq2_plain'])
+def test_beam_search_bookkeeping_matches_reference(variant, monkeypatch):
+    """VCLM_HF.beam_sample / group_beam_search (narrator.py:149-366) against the reference's own runs
+    (tests/golden/narrator_beam.pt: unmodified narrator.py + the transformers-4.27 BeamSearchScorer restated in
+    oracle/beam_scorer.py): sequences equal, scores to rounding -- on the key/value cache (rows re-gathered with the beams)
+    and on the reference's recompute schedule. The beam_sample cases use top_k = 2, where the draw of 2 * num_beams
+    candidates returns all of them and the outcome does not depend on the random stream."""
+    _emulate_device_primitives(monkeypatch)
+    m, c, d, v = _model(variant)
+    bx = load_golden('narrator_beam.pt')['variants'][variant]
+    img = v['image_tokens']
+    with torch.no_grad():
+        for name, run in bx['runs'].items():
+            tok = types.SimpleNamespace(bos_token_id=bx['bos'], eos_token_id=run['eos'], pad_token_id=bx['pad'])
+            for cache in (True, False):
+                for seed in (0, 123):
+                    torch.manual_seed(seed)
+                    seq, score = getattr(m, run['fn'])(img, tok, max_text_length=run['max_text_length'], kv_cache=cache,
+                                                       graph=False, **run['kwargs'])
+                    assert seq.shape == run['sequences'].shape and torch.equal(seq, run['sequences']), (name, cache, seed)
+                    torch.testing.assert_close(score, run['sequence_scores'], atol=1e-4, rtol=1e-4)
+
+
+def test_beam_scorer_equals_the_restated_transformers_class_on_random_candidates():
+    """lavila_amd.beam_search.BeamScorer against oracle.beam_scorer.BeamSearchScorer (the 4.27 class restated) on random
+    candidate streams with frequent eos: same beams after every process() call, same finalize()."""
+    from lavila_amd.beam_search import BeamScorer
+    from oracle.beam_scorer import BeamSearchScorer
+    g = torch.Generator().manual_seed(3)
+    for trial in range(30):
+        entries, groups = int(torch.randint(1, 4, (1,), generator=g)), int(torch.randint(1, 3, (1,), generator=g))
+        sub = int(torch.randint(1, 4, (1,), generator=g))
+        beams = groups * sub
+        if beams < 2:
+            continue
+        lp = [1.0, 0.5, 2.0][trial % 3]
+        keep = int(torch.randint(1, beams + 1, (1,), generator=g))
+        a = BeamSearchScorer(entries, beams, 'cpu', length_penalty=lp, num_beam_hyps_to_keep=keep, num_beam_groups=groups)
+        b = BeamScorer(entries, beams, 'cpu', length_penalty=lp, keep=keep, num_beam_groups=groups)
+        ids = torch.randint(5, 50, (entries * beams, 1), generator=g)
+        scores = torch.zeros(entries * beams)
+        eos, pad = 1, 0
+        for step in range(6):
+            cur = torch.zeros(entries * beams, dtype=torch.long)
+            for gi in range(groups):
+                rows = (torch.arange(entries)[:, None] * beams + torch.arange(gi * sub, gi * sub + sub)[None]).reshape(-1)
+                gids = ids[rows]
+                cs = -torch.rand(entries, 2 * sub, generator=g).cumsum(1) - step          # descending
+                ct = torch.randint(1, 4, (entries, 2 * sub), generator=g)                # eos = 1 shows up often
+                # never more than `sub` eos among the candidates (the scorer's own precondition)
+                for e in range(entries):
+                    seen = 0
+                    for j in range(2 * sub):
+                        if ct[e, j] == eos:
+                            seen += 1
+                            if seen > sub:
+                                ct[e, j] = 2
+                ci = torch.randint(0, sub, (entries, 2 * sub), generator=g)
+                ra = a.process(gids, cs, ct, ci, pad_token_id=pad, eos_token_id=eos)
+                rb = b.process(gids, cs, ct, ci, pad, eos)
+                assert torch.equal(ra['next_beam_scores'], rb[0]) and torch.equal(ra['next_beam_tokens'], rb[1])
+                assert torch.equal(ra['next_beam_indices'], rb[2])
+                scores[rows] = rb[0]
+                ids[rows] = gids[rb[2]]
+                cur[rows] = rb[1]
+            ids = torch.cat([ids, cur[:, None]], 1)
+            assert bool(a.is_done) == b.is_done
+        fa = a.finalize(ids, scores, None, None, max_length=7, pad_token_id=pad, eos_token_id=eos)
+        fb = b.finalize(ids, scores, 7, pad, eos)
+        assert torch.equal(fa['sequences'], fb[0]) and torch.equal(fa['sequence_scores'], fb[1])
