@@ -26,6 +26,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: exactly the entry points declared here are exported. */
+#pragma GCC visibility push(default)
 
 enum { LVL_F32 = 0, LVL_BF16 = 1 };
 enum { LVL_OK = 0, LVL_EINVAL = -22, LVL_ENOSYS = -38, LVL_EHIP = -5 };
@@ -143,6 +145,8 @@ int lvl_debug_f32_generic(int on);
  * kernels for EVERY space group, -1 = never (the LDS-resident kernels up to 592 keys, as in round 3), 0 = the shipped
  * choice. Results agree to rounding (bf16) / f32 summation order. */
 int lvl_debug_space_stream(int mode);
+/* Measurement hook: register budget of the streaming forward kernel (0 = 3 workgroups per compute unit, 1 = 4). */
+int lvl_debug_stream_variant(int v);
 /* Test hook: how many lvl_divided_attn_* / lvl_causal_attn_* calls of this process were served by the shape-generic
  * kernels so far (reset != 0: read and clear). */
 int lvl_debug_generic_attention_calls(int reset);
@@ -362,6 +366,7 @@ int lvl_cast_transpose(const float* src, void* dst, void* dst_t, int N, int K, v
 int lvl_split_bf16x3(const float* src, void* dst, int64_t rows, int cols, int64_t src_row_stride,
                      int64_t dst_row_stride, int64_t dst_term_stride, int role, void* stream);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

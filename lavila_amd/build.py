@@ -48,8 +48,8 @@ def build(force=False, verbose=True):
     procs = []
     for src in sources():
         obj = os.path.join(LIBDIR, os.path.basename(src)[:-4] + '.o')
-        cmd = [hipcc, f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-Wall',
-               '-Wno-unused-function', '-c', src, '-o', obj]
+        cmd = [hipcc, f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-fvisibility=hidden',
+               '-Wall', '-Wno-unused-function', '-c', src, '-o', obj]
         if verbose:
             print('[lavila_amd.build]', ' '.join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -27,6 +27,22 @@ __device__ __forceinline__ f32x4 mfma(uint4 a, uint4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(a), as_bf16x8(b), c, 0, 0, 0);
 }
 
+// Reductions over the four 16-lane rows of a wave (the C layout of a 16x16 MFMA tile spreads one query / key column over
+// lanes c, c+16, c+32, c+48): two gfx950 row swaps (v_permlane16_swap, v_permlane32_swap: plain VALU, no LDS crossbar
+// round trip like the ds_bpermute a __shfl_xor compiles to) and every lane holds the result.
+__device__ __forceinline__ float rows4_max(float x) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float rows4_sum(float x) {
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 // element offset of 16-byte slot `slot` (8 channels) of row `row`
 __device__ __forceinline__ int img_off(int row, int slot) { return row * RS + ((slot ^ (row & 7)) << 3); }
 

@@ -115,8 +115,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 1 : ((NKT <= 13 && !P::kSplit) 
       P::to_f32(ny1, bb);
 #pragma unroll
       for (int i = 0; i < 8; ++i) dl = fmaf(a[i], bb[i], dl);
-      dl += __shfl_xor(dl, 16, 64);
-      dl += __shfl_xor(dl, 32, 64);
+      dl = rows4_sum(dl);
     }
     if ((qt + NW) * 16 < N) load_frags(qt + NW);
     const size_t srow = ((size_t)b * H + h) * T + tok;
@@ -352,8 +351,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 1 : (P::kSplit ? 2 : 4))) void 
         dpc = fmaf(doc[hh * 32 + g * 8 + i], vf[i], dpc);
       }
     }
-    sc += __shfl_xor(sc, 16, 64); sc += __shfl_xor(sc, 32, 64);
-    dpc += __shfl_xor(dpc, 16, 64); dpc += __shfl_xor(dpc, 32, 64);
+    sc = rows4_sum(sc);
+    dpc = rows4_sum(dpc);
     const bool cls_sees = krow < nkeys && (krow > 0 || f == 0);
     const float pc = cls_sees ? __builtin_amdgcn_exp2f(fmaf(sc, kExp2, -Lc)) : 0.f;
     const float dsc = pc * (dpc - dlc);
@@ -513,8 +512,7 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : 2)) void space_bwd_fused_kern
       P::to_f32(yf[t][1], bb);
 #pragma unroll
       for (int i = 0; i < 8; ++i) acc = fmaf(a[i], bb[i], acc);
-      acc += __shfl_xor(acc, 16, 64);
-      acc += __shfl_xor(acc, 32, 64);
+      acc = rows4_sum(acc);
       dl[t] = acc;
       const int qrow = (2 * qp + t) * 16 + c;
       Lk[t] = lraw[t] * kLog2e;

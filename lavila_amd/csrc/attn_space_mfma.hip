@@ -157,8 +157,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 1 : ((NKT <= 13 && !P::kSplit) 
           mg = fmaxf(mg, fmaxf(fmaxf(acc[k][0], acc[k][1]), fmaxf(acc[k][2], acc[k][3])));
         }
       }
-      mg = fmaxf(mg, __shfl_xor(mg, 16, 64));
-      mg = fmaxf(mg, __shfl_xor(mg, 32, 64));
+      mg = rows4_max(mg);
       if (NG > 1) {
         // rescale what the earlier groups accumulated; a group (or everything so far) may be fully masked: -inf
         const float mn = fmaxf(m, mg);
@@ -206,8 +205,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 1 : ((NKT <= 13 && !P::kSplit) 
         }
       }
     }
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    l = rows4_sum(l);
     // o[dt][r] = O[query g*4+r][d = dt*16 + c]
     if (cls_tile) {
       // record of the CLS query over this frame's keys: (max, sum, un-normalised acc[64]) = column/row 0

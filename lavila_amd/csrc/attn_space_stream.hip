@@ -46,8 +46,10 @@ struct ChunkRegs { typename P::Raw a[2], b[2]; };
 // ------------------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------------------
-template <typename P>
-__global__ __launch_bounds__(256, (P::kSplit ? 1 : 3)) void space_stream_fwd_kernel(
+// OCC = workgroups per compute unit the register budget is cut for (bf16: 3 -> <= 168 VGPRs, 4 -> <= 128 with a few
+// spilled dwords; which one runs is a measured choice, lvl_debug_stream_variant)
+template <typename P, int OCC>
+__global__ __launch_bounds__(256, (P::kSplit ? 1 : OCC)) void space_stream_fwd_kernel(
     const typename P::io_t* __restrict__ qkv, typename P::io_t* __restrict__ out, float* __restrict__ lse,
     float* __restrict__ cls_ws, int F, int N, int H, int NB, int NG) {
   using io_t = typename P::io_t;
@@ -164,8 +166,7 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : 3)) void space_stream_fwd_ker
       float mg = -INFINITY;
 #pragma unroll
       for (int k = 0; k < 4; ++k) mg = fmaxf(mg, fmaxf(fmaxf(s[t][k][0], s[t][k][1]), fmaxf(s[t][k][2], s[t][k][3])));
-      mg = fmaxf(mg, __shfl_xor(mg, 16, 64));
-      mg = fmaxf(mg, __shfl_xor(mg, 32, 64));
+      mg = rows4_max(mg);
       const float mn = fmaxf(m[t], mg);
       const float al = (m[t] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((m[t] - mn) * kExp2);
       const float mk = (mn == -INFINITY) ? 0.f : mn * kExp2;
@@ -207,9 +208,7 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : 3)) void space_stream_fwd_ker
 
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
-    float lt = l[t];
-    lt += __shfl_xor(lt, 16, 64);
-    lt += __shfl_xor(lt, 32, 64);
+    const float lt = rows4_sum(l[t]);
     if (!live[t]) continue;
     if (cls_t[t]) {
       // record of the cls query over this frame's keys: (max, sum, un-normalised acc[64]) = query column 0
@@ -299,8 +298,7 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : 3)) void space_stream_dq_kern
     P::to_f32(y1, bb);
 #pragma unroll
     for (int i = 0; i < 8; ++i) acc = fmaf(a[i], bb[i], acc);
-    acc += __shfl_xor(acc, 16, 64);
-    acc += __shfl_xor(acc, 32, 64);
+    acc = rows4_sum(acc);
     dl[t] = acc;
     Lk[t] = lrow[tok] * kLog2e;
     // delta of the patch queries and -- once per group: it is the same in every frame -- of the cls query (token 0)
@@ -628,6 +626,7 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : 2)) void space_stream_dkv_ker
 }
 
 std::atomic<int> g_stream_mode{0};      // 0 auto (groups the resident kernels do not take two-per-CU), 1 always, -1 never
+std::atomic<int> g_stream_variant{0};   // forward kernel: 0 = 3 workgroups per CU, 1 = 4
 
 template <typename P>
 int launch_stream_fwd(const void* qkv, void* out, float* lse, float* ws, int B, int F, int N, int H, hipStream_t st) {
@@ -635,10 +634,14 @@ int launch_stream_fwd(const void* qkv, void* out, float* lse, float* ws, int B, 
   using L = StreamLds<P::kImages>;
   const int NB = ((N + 15) / 16 + 1 + 7) / 8;
   if (L::total_fwd > 64 * 1024)
-    if (int rc = lvl_allow_lds<space_stream_fwd_kernel<P>>()) return rc;
+    if (int rc = lvl_allow_lds<space_stream_fwd_kernel<P, 3>>()) return rc;
   const int NG = B * F * H;                       // groups; the grid is padded to whole rounds of 8 XCDs
-  hipLaunchKernelGGL((space_stream_fwd_kernel<P>), dim3((unsigned)((NG + 7) / 8 * 8 * NB)), dim3(256), L::total_fwd, st,
-                     (const io_t*)qkv, (io_t*)out, lse, ws, F, N, H, NB, NG);
+  if (!P::kSplit && g_stream_variant.load() == 1)
+    hipLaunchKernelGGL((space_stream_fwd_kernel<P, 4>), dim3((unsigned)((NG + 7) / 8 * 8 * NB)), dim3(256),
+                       L::total_fwd, st, (const io_t*)qkv, (io_t*)out, lse, ws, F, N, H, NB, NG);
+  else
+    hipLaunchKernelGGL((space_stream_fwd_kernel<P, 3>), dim3((unsigned)((NG + 7) / 8 * 8 * NB)), dim3(256),
+                       L::total_fwd, st, (const io_t*)qkv, (io_t*)out, lse, ws, F, N, H, NB, NG);
   LVL_CHECK_LAUNCH("space_stream_fwd");
   return LVL_OK;
 }
@@ -674,6 +677,11 @@ void lvl_launch_cls_grad_finalize(const float* atom_ws, void* dqkv, int B, int T
 // resident kernels), -1 = never, 0 = the shipped choice (lvl_space_stream_wanted).
 extern "C" int lvl_debug_space_stream(int mode) {
   g_stream_mode.store(mode < 0 ? -1 : (mode > 0 ? 1 : 0));
+  return LVL_OK;
+}
+
+extern "C" int lvl_debug_stream_variant(int v) {
+  g_stream_variant.store(v);
   return LVL_OK;
 }
 

@@ -26,6 +26,17 @@ def test_cabi_exports_every_declared_symbol():
         assert hasattr(lib, name), name
     assert b'gfx950' in _cabi.lib().lvl_version()
     assert _cabi.lib().lvl_workspace_floats(b'layernorm_bwd', 10, 768) > 0
+    # ... and nothing else: the library is built with -fvisibility=hidden, its C++ internals (launch helpers, lvl_fail,
+    # kernel host stubs) stay inside (34 mangled symbols were exported)
+    import shutil
+    import subprocess
+    nm = shutil.which('nm') or '/opt/rocm/lib/llvm/bin/llvm-nm'
+    if os.path.exists(nm):
+        out = subprocess.run([nm, '-D', '--defined-only', _cabi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+        exported = {l.split()[-1] for l in out.splitlines() if len(l.split()) >= 3 and l.split()[-2] in 'TtDdBbRr'}
+        funcs = {l.split()[-1] for l in out.splitlines() if len(l.split()) >= 3 and l.split()[-2] == 'T'}
+        assert funcs == declared, funcs ^ declared
+        assert not [e for e in exported if e.startswith('_Z') and 'lvl' in e], 'mangled internals exported'
 
 
 def test_workspace_queries_are_host_only_and_shape_aware():

@@ -1,7 +1,7 @@
 #!/bin/bash
 # HBM traffic of the dominant kernels INSIDE the bench step: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; counters only,
 # no tracing) of `bench.py --steps 1 --warmup 1`, aggregated per kernel family into gpurun_out/traffic/*.json
-# (copy to profiles/r03_traffic_*.json). Units / gfx950 correction: MI355X_MICROARCH.md section HBM (FETCH_SIZE counts the
+# (copy to profiles/rNN_traffic_*.json). Units / gfx950 correction: MI355X_MICROARCH.md section HBM (FETCH_SIZE counts the
 # 128-byte requests of wide coalesced reads at 64 B: x2; both counters are in KiB).
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/traffic
@@ -41,8 +41,8 @@ def family(sub, min_bytes, tag, note):
                  'bytes = 2*1024*FETCH_SIZE + 1024*WRITE_SIZE (gfx950: wide reads are tallied at half), averaged over the launches'}
     json.dump(j, open(f'{out}/{tag}.json', 'w'), indent=1)
     print(tag, j['launches'], 'launches, avg', j['traffic_bytes_per_launch'] / 1e9, 'GB (min', j['min'] / 1e9, 'max', j['max'] / 1e9, ')')
-family('gemm_tn_kernel', 2e8, 'r03_traffic_gemm_tn', 'all video-tower lvl_linear_tn launches (forward + input gradient, shape mix of the step)')
-family('wgrad_kernel<4, 2, 6, 6', 2e8, 'r03_traffic_wgrad', 'all video-tower lvl_linear_wgrad launches (shape mix of the step)')
-family('space_fwd_kernel<13, false', 1e8, 'r03_traffic_space_fwd', 'space-mode lvl_divided_attn_fwd launches')
-family("space_bwd_fused_kernel", 1e8, "r03_traffic_space_bwd", "space-mode lvl_divided_attn_bwd launches (fused kernel)")
+family('gemm_tn_kernel', 2e8, 'r04_traffic_gemm_tn', 'all video-tower lvl_linear_tn launches (forward + input gradient, shape mix of the step)')
+family('wgrad_kernel<4, 2, 6, 6', 2e8, 'r04_traffic_wgrad', 'all video-tower lvl_linear_wgrad launches (shape mix of the step)')
+family('13, false, 8, false', 1e8, 'r04_traffic_space_fwd', 'space-mode lvl_divided_attn_fwd launches')
+family("space_bwd_fused_kernel", 1e8, "r04_traffic_space_bwd", "space-mode lvl_divided_attn_bwd launches (fused kernel)")
 PY

@@ -19,6 +19,9 @@ T, D = 1 + F * N, 64 * H
 if 'PROBE_STREAM' in os.environ:      # 1: streaming space kernels for every shape, -1: never (round-3 resident kernels)
     from lavila_amd import _cabi as C
     C.lib().lvl_debug_space_stream(int(os.environ['PROBE_STREAM']))
+if 'PROBE_STREAM_VARIANT' in os.environ:
+    from lavila_amd import _cabi as C
+    C.lib().lvl_debug_stream_variant(int(os.environ['PROBE_STREAM_VARIANT']))
 g = torch.Generator(device='cuda').manual_seed(0)
 qkv = (torch.randn(B, T, 3 * D, device='cuda', generator=g) * 1.0).bfloat16().requires_grad_(True)
 dout = torch.randn(B, T, D, device='cuda', generator=g).bfloat16()
