@@ -13,11 +13,16 @@ for w in fwd bwd; do (timeout 300 python tools/probe_attn.py space $w 256 20 2>&
 for v in 0 1; do for w in fwd bwd; do
   (PROBE_STREAM_VARIANT=$v PROBE_F=16 PROBE_N=576 PROBE_H=16 timeout 300 python tools/probe_attn.py space $w 8 20 2>&1 | tail -1) >> $O/probe_config4_variant$v.txt
 done; done
-cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof -o b -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-events > $GRAFT_REPO_ROOT/$O/prof.log 2>&1
-cd $GRAFT_REPO_ROOT
-python tools/kernel_stats.py "$O/prof/**/*kernel_trace.csv" 7 > $O/bench_kernel_stats.csv 2>$O/kernel_stats.err || python tools/kernel_stats.py "$O/prof/*kernel_trace.csv" 7 > $O/bench_kernel_stats.csv 2>>$O/kernel_stats.err
-find $O/prof -name "*kernel_stats.csv" -exec cp {} $O/rocprof_kernel_stats.csv \;
-rm -rf $O/prof/*/*kernel_trace.csv $O/prof/*kernel_trace.csv 2>/dev/null
+for mode in default serial; do
+  cd /tmp
+  if [ $mode = serial ]; then export LAVILA_TEXT_STREAM=0; else unset LAVILA_TEXT_STREAM; fi
+  timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/prof_$mode -o b -- python $GRAFT_REPO_ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-events > $GRAFT_REPO_ROOT/$O/prof_$mode.log 2>&1
+  cd $GRAFT_REPO_ROOT
+  DB=$(find $O/prof_$mode -name "*.db" | head -1)
+  [ -n "$DB" ] && python tools/kernel_stats.py $DB 7 > $O/bench_kernel_stats_$mode.csv 2>$O/kernel_stats_$mode.err
+  rm -rf $O/prof_$mode
+done
+unset LAVILA_TEXT_STREAM
 bash tools/pmc_bench_traffic.sh > $O/traffic.log 2>&1
 cp gpurun_out/traffic/*.json $O/ 2>/dev/null
 rm -rf gpurun_out/traffic/FETCH_SIZE gpurun_out/traffic/WRITE_SIZE
