@@ -220,3 +220,52 @@ def test_gather_features_matches_reference(with_grad):
         torch.testing.assert_close(torch.tensor(at), want['all_txt'][r])
         torch.testing.assert_close(torch.tensor(di), want['dimg'][r])
         torch.testing.assert_close(torch.tensor(dt), want['dtxt'][r])
+
+
+def _rs_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from lavila_amd import distributed_utils as DU
+    calls = []
+
+    def reduce_scatter_tensor(output, input, op=dist.ReduceOp.SUM, group=None, async_op=False):
+        # what RCCL's reduce_scatter_tensor does, on gloo: checks the contract the call site must honour
+        assert op == dist.ReduceOp.SUM and input.is_contiguous() and output.is_contiguous()
+        assert input.shape[0] == world * output.shape[0] and input.shape[1:] == output.shape[1:]
+        calls.append(tuple(input.shape))
+        buf = input.clone()
+        dist.all_reduce(buf)
+        output.copy_(buf[rank * output.shape[0]:(rank + 1) * output.shape[0]])
+
+    DU.dist.get_backend = lambda *a, **k: 'nccl'                   # take the RCCL branch of GatherLayer.backward
+    DU.dist.reduce_scatter_tensor = reduce_scatter_tensor
+    x = (torch.arange(6, dtype=torch.float32).reshape(3, 2) + 100 * rank).requires_grad_(True)
+    gx = DU.gather_from_all(x)
+    (gx * (rank + 1) * torch.arange(1, 1 + gx.numel(), dtype=torch.float32).reshape(gx.shape)).sum().backward()
+    q.put((rank, gx.tolist(), x.grad.tolist(), calls))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_layer_backward_reduce_scatter_branch():
+    """GatherLayer.backward on a non-gloo backend calls dist.reduce_scatter_tensor(own, grad, SUM) (one slice per rank
+    instead of the reference's all_reduce-then-slice, distributed_utils.py:64-67). No RCCL here: the branch runs on two
+    gloo ranks with the collective emulated (its argument contract asserted) -- the values must equal the reference's
+    all_reduce + slice: d x_r = sum over ranks of their upstream gradient on rank r's rows."""
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rs_worker, args=(r, world, 29791, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    coef = torch.arange(1, 13, dtype=torch.float32).reshape(6, 2)
+    for rank, gx, dx, calls in got:
+        assert calls == [(6, 2)]
+        assert gx == [[0.0, 1.0], [2.0, 3.0], [4.0, 5.0], [100.0, 101.0], [102.0, 103.0], [104.0, 105.0]]
+        want = sum((r + 1) * coef for r in range(world))[rank * 3:(rank + 1) * 3]
+        torch.testing.assert_close(torch.tensor(dx), want)
