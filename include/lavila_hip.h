@@ -145,8 +145,7 @@ int lvl_debug_f32_generic(int on);
  * kernels for EVERY space group, -1 = never (the LDS-resident kernels up to 592 keys, as in round 3), 0 = the shipped
  * choice. Results agree to rounding (bf16) / f32 summation order. */
 int lvl_debug_space_stream(int mode);
-/* Measurement hook: register budgets of the streaming kernels (bit 0: forward kernel cut for 4 workgroups per compute unit
- * instead of 3; bit 1: dQ kernel for 2 instead of 3). */
+/* Measurement hook: register budget of the streaming forward kernel (0 = 3 workgroups per compute unit, 1 = 4). */
 int lvl_debug_stream_variant(int v);
 /* Test hook: how many lvl_divided_attn_* / lvl_causal_attn_* calls of this process were served by the shape-generic
  * kernels so far (reset != 0: read and clear). */

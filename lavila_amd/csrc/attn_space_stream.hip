@@ -19,8 +19,6 @@
 //            dK / dV go to the atomic slab (it collects gradient from every frame).
 // Same precision policies as the resident kernels (attn_mfma_common.h): PrecBf16, and PrecSplit for float32 tensors
 // (f32-class: hi/lo images, 3 MFMAs per product), which also takes the 577-key float32 groups off the generic kernels.
-#include <type_traits>
-
 #include "attn_mfma_common.h"
 
 namespace {
@@ -136,16 +134,11 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : OCC)) void space_stream_fwd_k
     const uint16_t* Ks = img + (ch & 1) * L::buf_elems;
     const uint16_t* Vs = Ks + L::img_elems;
     const int k0 = ch * KC;
-    // FULL chunks (64 valid keys: all but the last one) run a branch-free body -- the uniform per-tile branches of the
-    // generic body cut the loop into basic blocks of 4 MFMAs behind their own LDS wait, which the scheduler cannot
-    // overlap; the last chunk takes the generic body (tile skipping + key masks)
-    auto chunk_body = [&](auto full_tag) {
-    constexpr bool FULL = decltype(full_tag)::value;
-    const int nt = FULL ? 4 : ((nkeys - k0 + 15) / 16 < 4 ? (nkeys - k0 + 15) / 16 : 4);      // key tiles of this chunk
+    const int nt = (nkeys - k0 + 15) / 16 < 4 ? (nkeys - k0 + 15) / 16 : 4;      // key tiles of this chunk (uniform)
     f32x4 s[2][4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      if (FULL || k < nt) {
+      if (k < nt) {
         const Op ka0 = P::tile_op(Ks, LO, k, fo.a[0]), ka1 = P::tile_op(Ks, LO, k, fo.a[1]);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -161,7 +154,7 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : OCC)) void space_stream_fwd_k
     Op pa[2][2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      if (!FULL && k0 + nt * 16 > nkeys) {        // the chunk holds padded keys (zero rows): mask them
+      if (k0 + nt * 16 > nkeys) {                 // the chunk holds padded keys (zero rows): mask them
 #pragma unroll
         for (int k = 0; k < 4; ++k)
 #pragma unroll
@@ -198,7 +191,7 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : OCC)) void space_stream_fwd_k
     // O^T += V^T P^T over the chunk's two 32-key halves: every transpose read of V feeds both query tiles
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      if (FULL || 2 * j < nt) {
+      if (2 * j < nt) {
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
           const Tr lo = P::tile_tr(Vs, LO, 2 * j, fo.tr[dt]);
@@ -209,11 +202,6 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : OCC)) void space_stream_fwd_k
         }
       }
     }
-    };
-    if (k0 + KC <= nkeys)
-      chunk_body(std::true_type{});
-    else
-      chunk_body(std::false_type{});
     if (ch + 1 < nchunks) store_chunk((ch + 1) & 1);
     __syncthreads();
   }
@@ -250,8 +238,8 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : OCC)) void space_stream_fwd_k
 // ------------------------------------------------------------------------------------------------------------
 // dQ (and delta)
 // ------------------------------------------------------------------------------------------------------------
-template <typename P, int OCC>
-__global__ __launch_bounds__(256, (P::kSplit ? 1 : OCC)) void space_stream_dq_kernel(
+template <typename P>
+__global__ __launch_bounds__(256, (P::kSplit ? 1 : 3)) void space_stream_dq_kernel(
     const typename P::io_t* __restrict__ qkv, const typename P::io_t* __restrict__ out,
     const typename P::io_t* __restrict__ dout, const float* __restrict__ lse, typename P::io_t* __restrict__ dqkv,
     float* __restrict__ delta, float* __restrict__ atom_ws, int F, int N, int H, int NB, int NG) {
@@ -357,13 +345,10 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : OCC)) void space_stream_dq_ke
     const uint16_t* Ks = img + (ch & 1) * L::buf_elems;
     const uint16_t* Vs = Ks + L::img_elems;
     const int k0 = ch * KC;
-    // full chunks: branch-free body (see the forward kernel); the last chunk: tile skipping + key masks
-    auto chunk_body = [&](auto full_tag) {
-    constexpr bool FULL = decltype(full_tag)::value;
-    const int nt = FULL ? 4 : ((nkeys - k0 + 15) / 16 < 4 ? (nkeys - k0 + 15) / 16 : 4);
+    const int nt = (nkeys - k0 + 15) / 16 < 4 ? (nkeys - k0 + 15) / 16 : 4;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {                 // the chunk's two 32-key halves
-      if (!FULL && 2 * j >= nt) continue;
+      if (2 * j >= nt) continue;
       Op kf[2][2], vf[2][2];
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
@@ -391,10 +376,8 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : OCC)) void space_stream_dq_ke
           float e0 = __builtin_amdgcn_exp2f(fmaf(s0[r], kExp2, -Lk[t]));
           float e1 = __builtin_amdgcn_exp2f(fmaf(s1[r], kExp2, -Lk[t]));
           const int key0 = k0 + (2 * j) * 16 + g * 4 + r, key1 = key0 + 16;
-          if (!FULL) {
-            e0 = key0 < nkeys ? e0 : 0.f;         // padded key rows are zero, but exp2(-lse) may overflow: mask
-            e1 = key1 < nkeys ? e1 : 0.f;
-          }
+          e0 = key0 < nkeys ? e0 : 0.f;           // padded key rows are zero, but exp2(-lse) may overflow: mask
+          e1 = key1 < nkeys ? e1 : 0.f;
           if (cls_t[t] && f != 0 && key0 == 0) e0 = 0.f;        // (cls query, cls key) outside frame 0
           d0[r] = e0 * p0[r];
           d1[r] = e1 * p1[r];
@@ -411,11 +394,6 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : OCC)) void space_stream_dq_ke
         o[1][dt] = mfma(kb, pa[1], o[1][dt]);
       }
     }
-    };
-    if (k0 + KC <= nkeys)
-      chunk_body(std::true_type{});
-    else
-      chunk_body(std::false_type{});
     if (ch + 1 < nchunks) store_chunk((ch + 1) & 1);
     __syncthreads();
   }
@@ -556,12 +534,10 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : 2)) void space_stream_dkv_ker
     const float* lse_s = vec + (ch & 1) * 2 * KC;
     const float* del_s = lse_s + KC;
     const int q0 = ch * KC;
-    auto chunk_body = [&](auto full_tag) {
-    constexpr bool FULL = decltype(full_tag)::value;      // 64 valid query rows: branch-free body
-    const int nqt_c = FULL ? 4 : ((nq - q0 + 15) / 16 < 4 ? (nq - q0 + 15) / 16 : 4);       // query tiles of this chunk
+    const int nqt_c = (nq - q0 + 15) / 16 < 4 ? (nq - q0 + 15) / 16 : 4;       // query tiles of this chunk (uniform)
 #pragma unroll
     for (int qh = 0; qh < 2; ++qh) {               // the chunk's two 32-query halves
-      if (!FULL && 2 * qh >= nqt_c) continue;
+      if (2 * qh >= nqt_c) continue;
       const uint16_t* Qp = Qs + qh * 32 * RS;
       const uint16_t* Gp = Gs + qh * 32 * RS;
       Op qa[2][2], ga[2][2];
@@ -620,11 +596,6 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : 2)) void space_stream_dkv_ker
         adk[1][dt] = mfma(qb, da[1], adk[1][dt]);
       }
     }
-    };
-    if (q0 + KC <= nq)
-      chunk_body(std::true_type{});
-    else
-      chunk_body(std::false_type{});
     if (ch + 1 < nchunks) store_chunk((ch + 1) & 1);
     __syncthreads();
   }
@@ -655,7 +626,7 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : 2)) void space_stream_dkv_ker
 }
 
 std::atomic<int> g_stream_mode{0};      // 0 auto (groups the resident kernels do not take two-per-CU), 1 always, -1 never
-std::atomic<int> g_stream_variant{0};   // bit 0: forward kernel cut for 4 workgroups per CU (default 3); bit 1: dQ kernel for 2 (default 3)
+std::atomic<int> g_stream_variant{0};   // forward kernel: 0 = 3 workgroups per CU, 1 = 4
 
 template <typename P>
 int launch_stream_fwd(const void* qkv, void* out, float* lse, float* ws, int B, int F, int N, int H, hipStream_t st) {
@@ -665,7 +636,7 @@ int launch_stream_fwd(const void* qkv, void* out, float* lse, float* ws, int B, 
   if (L::total_fwd > 64 * 1024)
     if (int rc = lvl_allow_lds<space_stream_fwd_kernel<P, 3>>()) return rc;
   const int NG = B * F * H;                       // groups; the grid is padded to whole rounds of 8 XCDs
-  if (!P::kSplit && (g_stream_variant.load() & 1))
+  if (!P::kSplit && g_stream_variant.load() == 1)
     hipLaunchKernelGGL((space_stream_fwd_kernel<P, 4>), dim3((unsigned)((NG + 7) / 8 * 8 * NB)), dim3(256),
                        L::total_fwd, st, (const io_t*)qkv, (io_t*)out, lse, ws, F, N, H, NB, NG);
   else
@@ -682,18 +653,13 @@ int launch_stream_bwd(const void* qkv, const void* out, const void* dout, const 
   using L = StreamLds<P::kImages>;
   const int NBq = ((N + 15) / 16 + 1 + 7) / 8, NBk = ((N + 1 + 15) / 16 + 7) / 8;
   if (L::total_dkv > 64 * 1024) {
-    if (int rc = lvl_allow_lds<space_stream_dq_kernel<P, 3>>()) return rc;
+    if (int rc = lvl_allow_lds<space_stream_dq_kernel<P>>()) return rc;
     if (int rc = lvl_allow_lds<space_stream_dkv_kernel<P>>()) return rc;
   }
   const int NG = B * F * H;
-  if (!P::kSplit && (g_stream_variant.load() & 2))
-    hipLaunchKernelGGL((space_stream_dq_kernel<P, 2>), dim3((unsigned)((NG + 7) / 8 * 8 * NBq)), dim3(256),
-                       L::total_fwd, st, (const io_t*)qkv, (const io_t*)out, (const io_t*)dout, lse, (io_t*)dqkv, delta,
-                       atom_ws, F, N, H, NBq, NG);
-  else
-    hipLaunchKernelGGL((space_stream_dq_kernel<P, 3>), dim3((unsigned)((NG + 7) / 8 * 8 * NBq)), dim3(256),
-                       L::total_fwd, st, (const io_t*)qkv, (const io_t*)out, (const io_t*)dout, lse, (io_t*)dqkv, delta,
-                       atom_ws, F, N, H, NBq, NG);
+  hipLaunchKernelGGL((space_stream_dq_kernel<P>), dim3((unsigned)((NG + 7) / 8 * 8 * NBq)), dim3(256), L::total_fwd, st,
+                     (const io_t*)qkv, (const io_t*)out, (const io_t*)dout, lse, (io_t*)dqkv, delta, atom_ws, F, N, H,
+                     NBq, NG);
   LVL_CHECK_LAUNCH("space_stream_dq");
   hipLaunchKernelGGL((space_stream_dkv_kernel<P>), dim3((unsigned)((NG + 7) / 8 * 8 * NBk)), dim3(256), L::total_dkv, st,
                      (const io_t*)qkv, (const io_t*)dout, lse, delta, (io_t*)dqkv, atom_ws, F, N, H, NBk, NG);
