@@ -340,6 +340,16 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device('cuda', dev_index)
     rehearsal = None
+    force_group = world == 1 and os.environ.get('LAVILA_BENCH_ONE_RANK_RCCL') == '1'
+    if force_group:
+        # A/B on a single GPU: the multi-GPU code path (RCCL process group, DistributedDataParallel with its bucket
+        # all-reduce, device tile counters) with ONE rank -- the collectives run on the real library, their data path is a
+        # device copy. Not the default and not a scaling measurement: config.note says so.
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('LAVILA_DYNAMIC_TILES', '1')
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=device)
+        rehearsal = 'ONE-RANK RCCL GROUP (LAVILA_BENCH_ONE_RANK_RCCL=1): DDP + RCCL call sites + tile counters on one GPU'
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         # 'nccl' = RCCL over xGMI (one rank per GPU). Fewer devices than ranks (a 1-GPU box rehearsing the N>1 path):
@@ -380,7 +390,7 @@ def main():
     ops.linear_wgrad_raw = wtimer.wrap(ops.linear_wgrad_raw, lambda dy, x, *a, **k: dy.shape[0] == video_rows,
                                        work=lambda dy, x, *a, **k: 2.0 * dy.shape[0] * dy.shape[1] * x.shape[1])
     net = model
-    if world > 1:
+    if world > 1 or force_group:
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev_index], bucket_cap_mb=200,
                                                         gradient_as_bucket_view=True)
     crit = CLIPLoss(use_vissl=True, cache_labels=True, rank=rank, world_size=world)
@@ -547,7 +557,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args, model, img)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or force_group:
         dist.barrier()
         dist.destroy_process_group()
 

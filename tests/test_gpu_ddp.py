@@ -217,3 +217,81 @@ def test_zero_step_then_forward_runs_on_the_updated_weights():
         assert abs(lz - lp) < 1e-5 and abs(lze - lpe) < 1e-5, (rank, lz, lp, lze, lpe)   # ZeRO == AdamW, next forward
         assert abs(lp - lb) > 1e-3, (lp, lb)              # ... and the step did move the loss (lr 1e-2): not vacuous
     assert got[0][1] == got[1][1]                         # both ranks: the same global loss
+
+
+def _rccl_worker(port, q):
+    """One rank, backend 'nccl' (= RCCL): every collective call site of the multi-GPU path executes on the real library
+    (a one-rank communicator: the data path is a device copy, the API / stream / DDP-hook plumbing is the real one)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    os.environ['LAVILA_DYNAMIC_TILES'] = '1'            # what a rank of a multi-GPU job runs
+    import torch.distributed as dist
+    from helpers import build_model
+    from lavila.models.loss import CLIPLoss
+    from lavila_amd import distributed_utils as DU
+    from oracle import oracle as O
+    try:
+        torch.cuda.set_device(0)
+        dev = torch.device('cuda', 0)
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)      # bench.py's call
+        res = {'backend': dist.get_backend()}
+        x = torch.arange(12, dtype=torch.float32, device=dev).reshape(6, 2).requires_grad_(True)
+        g = DU.all_gather_rows(x.detach())
+        res['all_gather'] = bool(torch.equal(g, x.detach()))
+        y = DU.GatherLayer.apply(x)                      # backward: reduce_scatter_tensor on RCCL
+        (y * 3).sum().backward()
+        res['reduce_scatter'] = bool(torch.equal(x.grad, torch.full_like(x, 3.0)))
+        # DistributedDataParallel (RCCL gradient all-reduce on bucket views) around the custom autograd Functions
+        model = build_model(CFG)
+        shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        w = O.procedural_weights(shapes, seed=3)
+        model.load_state_dict(w)
+        model.cuda().train()
+        ddp = torch.nn.parallel.DistributedDataParallel(model, device_ids=[0], bucket_cap_mb=200,
+                                                        gradient_as_bucket_view=True)
+        crit = CLIPLoss(use_vissl=True, cache_labels=True, rank=0, world_size=1)
+        video, tokens = _inputs(1)
+        for _ in range(2):
+            model.zero_grad(set_to_none=True)
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                out = ddp(video.cuda(), tokens.cuda(), norm_embed=True)
+                ld = crit(out)
+            ld['loss'].backward()
+        torch.cuda.synchronize()
+        wo = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in w.items()}
+        oo = O.clip_forward(video, tokens, wo, CFG['heads'], CFG['t_heads'], norm_embed=True)
+        lo = O.clip_loss(oo['image_embed'], oo['text_embed'], oo['logit_scale'])['loss']
+        res['loss'] = (ld['loss'].item(), lo.item())
+        res['grads_finite'] = all(bool(torch.isfinite(p.grad).all()) for p in model.parameters())
+        # the two gathers of the sharded loss's multi-rank branch (lavila_amd/loss.py:_ContrastiveFn), as it issues them:
+        # [B, 2E] bf16 embeddings and the [1, 2B+3] f32 row-LSE / partial-sum record
+        both = torch.randn(5, 128, device=dev).bfloat16()
+        rec = torch.randn(1, 13, device=dev)
+        res['loss_gathers'] = bool(torch.equal(DU.all_gather_rows(both), both) and torch.equal(DU.all_gather_rows(rec), rec))
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put(res)
+    except Exception as e:            # noqa: BLE001
+        import traceback
+        q.put({'error': repr(e), 'trace': traceback.format_exc()[-1500:]})
+
+
+def test_rccl_call_sites_execute_on_a_one_rank_group():
+    """No multi-GPU node is available to the build, so no RCCL call of the N > 1 path had ever executed.
+    A one-rank 'nccl' group on the one MI355X runs every call site on the real library: init_process_group(device_id=...),
+    all_gather_into_tensor, reduce_scatter_tensor (GatherLayer.backward's RCCL branch), DistributedDataParallel with
+    bucket views + the custom autograd Functions + the text side stream + the tile counters, and the sharded loss's
+    gathers."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(29611, q))
+    p.start()
+    res = q.get(timeout=600)
+    p.join(timeout=120)
+    assert 'error' not in res, res
+    assert res['backend'] == 'nccl' and res['all_gather'] and res['reduce_scatter'] and res['grads_finite']
+    assert abs(res['loss'][0] - res['loss'][1]) < 3e-2, res['loss']           # bf16 step vs the f32 oracle
+    assert res['loss_gathers']

@@ -159,8 +159,10 @@ def test_vclm_constructors_and_cpu_is_loud():
     assert m.img_queries.shape == (256, 768) and dec.lm_head.weight is dec.transformer.wte.weight
     with torch.no_grad(), pytest.raises(HipExtensionError):
         dec(torch.zeros(1, 3, dtype=torch.long))
-    with pytest.raises(NotImplementedError):
-        m.group_beam_search()
+    import types
+    tok = types.SimpleNamespace(bos_token_id=50256, eos_token_id=50256, pad_token_id=50256)
+    with torch.no_grad(), pytest.raises(HipExtensionError):          # beam search is built (round 4): on CPU it is as loud
+        m.group_beam_search(torch.zeros(1, 256, 768), tok, max_text_length=4, num_beams=2, num_beam_groups=1)
 
 
 @pytest.mark.parametrize('top_k,top_p,temperature', [(None, 0.95, 0.7), (50, None, 1.0), (40, 0.9, 0.8), (None, None, 1.3),
