@@ -418,8 +418,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    verbose = os.environ.get('LAVILA_BENCH_VERBOSE') == '1'      # per-step progress on stderr (diagnosing a slow rank)
+    for i in range(args.warmup):
+        h0 = time.perf_counter()
         step()
+        if verbose:
+            torch.cuda.synchronize()
+            print(f'[bench rank {rank}] warm-up step {i}: {1e3 * (time.perf_counter() - h0):.1f} ms', file=sys.stderr, flush=True)
     fence()
     timer.enabled = wtimer.enabled = gtimer.enabled = not args.no_events
     t0 = time.perf_counter()
@@ -430,6 +435,8 @@ def main():
         loss = step()
         host_steps.append(time.perf_counter() - h0)
         host_s += host_steps[-1]
+        if verbose:
+            print(f'[bench rank {rank}] step: host {1e3 * host_steps[-1]:.1f} ms', file=sys.stderr, flush=True)
     fence()
     elapsed = time.perf_counter() - t0
     timer.enabled = wtimer.enabled = gtimer.enabled = False

@@ -37,18 +37,58 @@ template <int IMAGES> struct StreamLds {
   static constexpr int vec_off = img_bytes;                      // dkv kernel: lse | delta of the two buffers' rows
   static constexpr int total_fwd = img_bytes;
   static constexpr int total_dkv = img_bytes + 2 * 2 * KC * 4;
+  static constexpr int total_dma = 3 * buf_elems * 2;            // LDS-DMA ring of three stages (bf16)
 };
 
 // One thread's share of a 64-row chunk: rows r_in and r_in + 32 of both images, 8 channels at c8.
 template <typename P>
 struct ChunkRegs { typename P::Raw a[2], b[2]; };
 
+// ---- LDS-DMA ring (bf16 instantiations) -------------------------------------------------------------------------
+// With register staging the next chunk's loads are issued when the current chunk starts and must have landed when it
+// ends: ONE chunk of run-ahead, and a chunk's arithmetic (<= 1 us) is shorter than a global-load round trip under load,
+// so every chunk waited for memory (measured: 3.1 us per chunk at 577 keys where the MFMA + VALU work is < 1 us). The
+// DMA form keeps a ring of NST = 3 stages filled by global_load_lds_dwordx4 (no VGPR round trip, no ds_write pass):
+// chunk c+2 is requested before chunk c is multiplied. A stage is 16 fills of 1 KiB (8 rows x 128 B; fills 0-7 image A,
+// 8-15 image B), four per wave; lane l of a fill lands at row 8*blk + (l >> 3), PHYSICAL slot l & 7, and therefore
+// fetches the logical slot (l & 7) ^ (row & 7) of its row (the images' XOR swizzle, applied on the source side).
+// Rows past the end of the group re-read the last valid row (never used unmasked). The fills go through inline asm:
+// hipcc would otherwise drain them (vmcnt(0)) at every barrier; the waits are counted by hand (4 fills per wave and
+// chunk, in-order completion).
+constexpr int NST = 3;
+
+#pragma clang diagnostic ignored "-Winline-asm"
+template <typename RowPtr>
+__device__ __forceinline__ void dma_issue_chunk(uint16_t* stage, int ch, int nrows, int wave_u, int lane, RowPtr row_ptr) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int f = wave_u * 4 + i;
+    const int image = f >> 3, blk = f & 7;
+    const int row = blk * 8 + (lane >> 3);
+    int idx = ch * KC + row;
+    idx = idx < nrows ? idx : nrows - 1;
+    const uint16_t* src = row_ptr(idx, image) + (((lane & 7) ^ (row & 7)) << 3);
+    const uint32_t m0v = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(stage + image * (KC * RS)) + (uint32_t)blk * 1024u);
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(src) : "memory", "m0");
+  }
+}
+// wait for this wave's fills of the chunk about to be multiplied (the next chunk's four may stay in flight), then meet
+// the other waves: everybody's fills of the chunk have landed and everybody is done with the previous chunk
+__device__ __forceinline__ void dma_wait_chunk(bool more_in_flight) {
+  if (more_in_flight)
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------------------
 // OCC = workgroups per compute unit the register budget is cut for (bf16: 3 -> <= 168 VGPRs, 4 -> <= 128 with a few
 // spilled dwords; which one runs is a measured choice, lvl_debug_stream_variant)
-template <typename P, int OCC>
+template <typename P, int OCC, bool DMA>
 __global__ __launch_bounds__(256, (P::kSplit ? 1 : OCC)) void space_stream_fwd_kernel(
     const typename P::io_t* __restrict__ qkv, typename P::io_t* __restrict__ out, float* __restrict__ lse,
     float* __restrict__ cls_ws, int F, int N, int H, int NB, int NG) {
@@ -125,13 +165,32 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : OCC)) void space_stream_fwd_k
     for (int dt = 0; dt < 4; ++dt) o[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nchunks = (nkeys + KC - 1) / KC;
-  load_chunk(0);
-  store_chunk(0);
-  __syncthreads();
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  auto key_row = [&](int kidx, int image) {          // K (image 0) / V (image 1) row of key kidx, as bf16 elements
+    return reinterpret_cast<const uint16_t*>(base) + (size_t)(kidx == 0 ? 0 : tok0 + kidx - 1) * ts + D * (1 + image);
+  };
+  int stage = 0;
+  if constexpr (DMA) {
+    dma_issue_chunk(img, 0, nkeys, wave_u, lane, key_row);
+    if (nchunks > 1) dma_issue_chunk(img + L::buf_elems, 1, nkeys, wave_u, lane, key_row);
+  } else {
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+  }
 #pragma unroll 1
   for (int ch = 0; ch < nchunks; ++ch) {
-    if (ch + 1 < nchunks) load_chunk(ch + 1);
-    const uint16_t* Ks = img + (ch & 1) * L::buf_elems;
+    if constexpr (DMA) {
+      dma_wait_chunk(ch + 1 < nchunks);
+      if (ch + 2 < nchunks) {          // into the stage chunk ch-1 used: every wave has passed the barrier behind it
+        const int s2 = stage == 0 ? 2 : stage - 1;
+        dma_issue_chunk(img + s2 * L::buf_elems, ch + 2, nkeys, wave_u, lane, key_row);
+      }
+    } else {
+      if (ch + 1 < nchunks) load_chunk(ch + 1);
+      stage = ch & 1;
+    }
+    const uint16_t* Ks = img + stage * L::buf_elems;
     const uint16_t* Vs = Ks + L::img_elems;
     const int k0 = ch * KC;
     const int nt = (nkeys - k0 + 15) / 16 < 4 ? (nkeys - k0 + 15) / 16 : 4;      // key tiles of this chunk (uniform)
@@ -202,8 +261,12 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : OCC)) void space_stream_fwd_k
         }
       }
     }
-    if (ch + 1 < nchunks) store_chunk((ch + 1) & 1);
-    __syncthreads();
+    if constexpr (DMA) {
+      stage = stage == NST - 1 ? 0 : stage + 1;
+    } else {
+      if (ch + 1 < nchunks) store_chunk((ch + 1) & 1);
+      __syncthreads();
+    }
   }
 
 #pragma unroll
@@ -626,7 +689,9 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : 2)) void space_stream_dkv_ker
 }
 
 std::atomic<int> g_stream_mode{0};      // 0 auto (groups the resident kernels do not take two-per-CU), 1 always, -1 never
-std::atomic<int> g_stream_variant{0};   // forward kernel: 0 = 3 workgroups per CU, 1 = 4
+// bit 0: register-staged forward kernel cut for 4 workgroups per CU (default 3); bit 2: register staging instead of the
+// LDS-DMA ring (bf16)
+std::atomic<int> g_stream_variant{0};
 
 template <typename P>
 int launch_stream_fwd(const void* qkv, void* out, float* lse, float* ws, int B, int F, int N, int H, hipStream_t st) {
@@ -634,14 +699,23 @@ int launch_stream_fwd(const void* qkv, void* out, float* lse, float* ws, int B, 
   using L = StreamLds<P::kImages>;
   const int NB = ((N + 15) / 16 + 1 + 7) / 8;
   if (L::total_fwd > 64 * 1024)
-    if (int rc = lvl_allow_lds<space_stream_fwd_kernel<P, 3>>()) return rc;
+    if (int rc = lvl_allow_lds<space_stream_fwd_kernel<P, 3, false>>()) return rc;
   const int NG = B * F * H;                       // groups; the grid is padded to whole rounds of 8 XCDs
-  if (!P::kSplit && g_stream_variant.load() == 1)
-    hipLaunchKernelGGL((space_stream_fwd_kernel<P, 4>), dim3((unsigned)((NG + 7) / 8 * 8 * NB)), dim3(256),
-                       L::total_fwd, st, (const io_t*)qkv, (io_t*)out, lse, ws, F, N, H, NB, NG);
+  const dim3 grid((unsigned)((NG + 7) / 8 * 8 * NB));
+  if constexpr (!P::kSplit) {
+    if (!(g_stream_variant.load() & 4)) {         // default: LDS-DMA ring (bit 2 of the variant: register staging)
+      hipLaunchKernelGGL((space_stream_fwd_kernel<P, 3, true>), grid, dim3(256), L::total_dma, st, (const io_t*)qkv,
+                         (io_t*)out, lse, ws, F, N, H, NB, NG);
+      LVL_CHECK_LAUNCH("space_stream_fwd");
+      return LVL_OK;
+    }
+  }
+  if (!P::kSplit && (g_stream_variant.load() & 1))
+    hipLaunchKernelGGL((space_stream_fwd_kernel<P, 4, false>), grid, dim3(256), L::total_fwd, st, (const io_t*)qkv,
+                       (io_t*)out, lse, ws, F, N, H, NB, NG);
   else
-    hipLaunchKernelGGL((space_stream_fwd_kernel<P, 3>), dim3((unsigned)((NG + 7) / 8 * 8 * NB)), dim3(256),
-                       L::total_fwd, st, (const io_t*)qkv, (io_t*)out, lse, ws, F, N, H, NB, NG);
+    hipLaunchKernelGGL((space_stream_fwd_kernel<P, 3, false>), grid, dim3(256), L::total_fwd, st, (const io_t*)qkv,
+                       (io_t*)out, lse, ws, F, N, H, NB, NG);
   LVL_CHECK_LAUNCH("space_stream_fwd");
   return LVL_OK;
 }
