@@ -38,6 +38,7 @@ template <int IMAGES> struct StreamLds {
   static constexpr int total_fwd = img_bytes;
   static constexpr int total_dkv = img_bytes + 2 * 2 * KC * 4;
   static constexpr int total_dma = 3 * buf_elems * 2;            // LDS-DMA ring of three stages (bf16)
+  static constexpr int total_dma_dkv = total_dma + 3 * 4 * KC * 4;   // + lse / delta rows of the three stages
 };
 
 // One thread's share of a 64-row chunk: rows r_in and r_in + 32 of both images, 8 channels at c8.
@@ -46,15 +47,16 @@ struct ChunkRegs { typename P::Raw a[2], b[2]; };
 
 // ---- LDS-DMA ring (bf16 instantiations) -------------------------------------------------------------------------
 // With register staging the next chunk's loads are issued when the current chunk starts and must have landed when it
-// ends: ONE chunk of run-ahead, and a chunk's arithmetic (<= 1 us) is shorter than a global-load round trip under load,
-// so every chunk waited for memory (measured: 3.1 us per chunk at 577 keys where the MFMA + VALU work is < 1 us). The
+// ends: ONE chunk of run-ahead, eight staging registers per thread and a ds_write pass per chunk. The
 // DMA form keeps a ring of NST = 3 stages filled by global_load_lds_dwordx4 (no VGPR round trip, no ds_write pass):
 // chunk c+2 is requested before chunk c is multiplied. A stage is 16 fills of 1 KiB (8 rows x 128 B; fills 0-7 image A,
 // 8-15 image B), four per wave; lane l of a fill lands at row 8*blk + (l >> 3), PHYSICAL slot l & 7, and therefore
 // fetches the logical slot (l & 7) ^ (row & 7) of its row (the images' XOR swizzle, applied on the source side).
 // Rows past the end of the group re-read the last valid row (never used unmasked). The fills go through inline asm:
 // hipcc would otherwise drain them (vmcnt(0)) at every barrier; the waits are counted by hand (4 fills per wave and
-// chunk, in-order completion).
+// chunk, in-order completion). Measured at 16 x 577 keys, batch 8 (profiles/r04_config4_attention_dma_ring.txt): forward
+// 0.417 -> 0.404 ms, forward + backward 1.355 -> 1.335 ms against register staging (variant bit 2) -- the chunks were NOT
+// waiting for memory (the hypothesis this was built on); what bounds them is the softmax's VALU work.
 constexpr int NST = 3;
 
 #pragma clang diagnostic ignored "-Winline-asm"
@@ -72,11 +74,20 @@ __device__ __forceinline__ void dma_issue_chunk(uint16_t* stage, int ch, int nro
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(src) : "memory", "m0");
   }
 }
+// forces the compiler to have the operand's registers loaded here (an empty asm that "modifies" them)
+__device__ __forceinline__ void pin_op(uint4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+__device__ __forceinline__ void pin_op(Op2& v) {
+  pin_op(v.h);
+  pin_op(v.l);
+}
+__device__ __forceinline__ void pin_f32(float& v) { asm volatile("" : "+v"(v)); }
+
 // wait for this wave's fills of the chunk about to be multiplied (the next chunk's four may stay in flight), then meet
 // the other waves: everybody's fills of the chunk have landed and everybody is done with the previous chunk
+template <int FILLS = 4>
 __device__ __forceinline__ void dma_wait_chunk(bool more_in_flight) {
   if (more_in_flight)
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(FILLS) : "memory");
   else
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -173,6 +184,12 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : OCC)) void space_stream_fwd_k
   if constexpr (DMA) {
     dma_issue_chunk(img, 0, nkeys, wave_u, lane, key_row);
     if (nchunks > 1) dma_issue_chunk(img + L::buf_elems, 1, nkeys, wave_u, lane, key_row);
+    // Pin the query fragments NOW. hipcc defers the wait for their loads to the first use INSIDE the loop, where its
+    // s_waitcnt vmcnt(0) (it does not count the asm fills) would drain the run-ahead fills in every iteration.
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) pin_op(qf[t][hh]);
   } else {
     load_chunk(0);
     store_chunk(0);
@@ -301,7 +318,7 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : OCC)) void space_stream_fwd_k
 // ------------------------------------------------------------------------------------------------------------
 // dQ (and delta)
 // ------------------------------------------------------------------------------------------------------------
-template <typename P>
+template <typename P, bool DMA>
 __global__ __launch_bounds__(256, (P::kSplit ? 1 : 3)) void space_stream_dq_kernel(
     const typename P::io_t* __restrict__ qkv, const typename P::io_t* __restrict__ out,
     const typename P::io_t* __restrict__ dout, const float* __restrict__ lse, typename P::io_t* __restrict__ dqkv,
@@ -399,13 +416,39 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : 3)) void space_stream_dq_kern
     for (int dt = 0; dt < 4; ++dt) o[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nchunks = (nkeys + KC - 1) / KC;
-  load_chunk(0);
-  store_chunk(0);
-  __syncthreads();
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  auto key_row = [&](int kidx, int image) {
+    return reinterpret_cast<const uint16_t*>(base) + (size_t)(kidx == 0 ? 0 : tok0 + kidx - 1) * ts + D * (1 + image);
+  };
+  int stage = 0;
+  if constexpr (DMA) {
+    dma_issue_chunk(img, 0, nkeys, wave_u, lane, key_row);
+    if (nchunks > 1) dma_issue_chunk(img + L::buf_elems, 1, nkeys, wave_u, lane, key_row);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {                  // see the forward kernel: no deferred compiler waits inside the loop
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) { pin_op(qf[t][hh]); pin_op(gf[t][hh]); }
+      pin_f32(Lk[t]);
+      pin_f32(dl[t]);
+    }
+  } else {
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+  }
 #pragma unroll 1
   for (int ch = 0; ch < nchunks; ++ch) {
-    if (ch + 1 < nchunks) load_chunk(ch + 1);
-    const uint16_t* Ks = img + (ch & 1) * L::buf_elems;
+    if constexpr (DMA) {
+      dma_wait_chunk(ch + 1 < nchunks);
+      if (ch + 2 < nchunks) {
+        const int s2 = stage == 0 ? 2 : stage - 1;
+        dma_issue_chunk(img + s2 * L::buf_elems, ch + 2, nkeys, wave_u, lane, key_row);
+      }
+    } else {
+      if (ch + 1 < nchunks) load_chunk(ch + 1);
+      stage = ch & 1;
+    }
+    const uint16_t* Ks = img + stage * L::buf_elems;
     const uint16_t* Vs = Ks + L::img_elems;
     const int k0 = ch * KC;
     const int nt = (nkeys - k0 + 15) / 16 < 4 ? (nkeys - k0 + 15) / 16 : 4;
@@ -457,8 +500,12 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : 3)) void space_stream_dq_kern
         o[1][dt] = mfma(kb, pa[1], o[1][dt]);
       }
     }
-    if (ch + 1 < nchunks) store_chunk((ch + 1) & 1);
-    __syncthreads();
+    if constexpr (DMA) {
+      stage = stage == NST - 1 ? 0 : stage + 1;
+    } else {
+      if (ch + 1 < nchunks) store_chunk((ch + 1) & 1);
+      __syncthreads();
+    }
   }
 
 #pragma unroll
@@ -485,7 +532,7 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : 3)) void space_stream_dq_kern
 // ------------------------------------------------------------------------------------------------------------
 // dK / dV
 // ------------------------------------------------------------------------------------------------------------
-template <typename P>
+template <typename P, bool DMA>
 __global__ __launch_bounds__(256, (P::kSplit ? 1 : 2)) void space_stream_dkv_kernel(
     const typename P::io_t* __restrict__ qkv, const typename P::io_t* __restrict__ dout,
     const float* __restrict__ lse, const float* __restrict__ delta, typename P::io_t* __restrict__ dqkv,
@@ -497,7 +544,9 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : 2)) void space_stream_dkv_ker
   constexpr int LO = L::lo_off;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint16_t* img = reinterpret_cast<uint16_t*>(smem);
-  float* vec = reinterpret_cast<float*>(smem + L::vec_off);      // [2 buffers][lse(64) | delta(64)]
+  // register staging: [2 buffers][lse(64, log2 units) | delta(64)] behind the images; DMA ring: [NST stages][4][64] raw
+  // lse | delta | (the same again: waves 2 and 3 issue the duplicates so that every wave has 5 fills per chunk)
+  float* vec = reinterpret_cast<float*>(smem + (DMA ? L::total_dma : L::vec_off));
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // XCD-aware decode: workgroup i runs on XCD i % 8 (observed, for speed only); the NB workgroups of a group take the
@@ -586,15 +635,54 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : 2)) void space_stream_dkv_ker
 
   const int nchunks = (nq + KC - 1) / KC;
   const int cls_chunk = N / KC, cls_half = (N % KC) >> 5, cls_sub = N & 31;     // where the cls query sits
-  load_chunk(0);
-  store_chunk(0);
-  __syncthreads();
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  auto query_row = [&](int qidx, int image) {       // Q (image 0) / dO (image 1) row of query qidx (row N = the cls query)
+    const int tk = qidx < N ? tok0 + qidx : 0;
+    return image == 0 ? reinterpret_cast<const uint16_t*>(base) + (size_t)tk * ts
+                      : reinterpret_cast<const uint16_t*>(dobase) + (size_t)tk * D;
+  };
+  // fifth fill of a chunk: the 64 lse (waves 0, 2) or delta (waves 1, 3) values of its rows, one float per lane
+  auto issue_vec = [&](int st, int ch) {
+    int qidx = ch * KC + lane;
+    qidx = qidx < nq ? qidx : nq - 1;
+    const int tk = qidx < N ? tok0 + qidx : 0;
+    const float* src = ((wave_u & 1) ? drow : lrow) + tk;
+    const uint32_t m0v = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(vec + (st * 4 + wave_u) * KC));
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(m0v), "v"(src) : "memory", "m0");
+  };
+  int stage = 0;
+  if constexpr (DMA) {
+    dma_issue_chunk(img, 0, nq, wave_u, lane, query_row);
+    issue_vec(0, 0);
+    if (nchunks > 1) {
+      dma_issue_chunk(img + L::buf_elems, 1, nq, wave_u, lane, query_row);
+      issue_vec(1, 1);
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)                    // no deferred compiler waits inside the loop (see the forward kernel)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) { pin_op(kk[t][hh]); pin_op(vv[t][hh]); }
+  } else {
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+  }
 #pragma unroll 1
   for (int ch = 0; ch < nchunks; ++ch) {
-    if (ch + 1 < nchunks) load_chunk(ch + 1);
-    const uint16_t* Qs = img + (ch & 1) * L::buf_elems;
+    if constexpr (DMA) {
+      dma_wait_chunk<5>(ch + 1 < nchunks);
+      if (ch + 2 < nchunks) {
+        const int s2 = stage == 0 ? 2 : stage - 1;
+        dma_issue_chunk(img + s2 * L::buf_elems, ch + 2, nq, wave_u, lane, query_row);
+        issue_vec(s2, ch + 2);
+      }
+    } else {
+      if (ch + 1 < nchunks) load_chunk(ch + 1);
+      stage = ch & 1;
+    }
+    const uint16_t* Qs = img + stage * L::buf_elems;
     const uint16_t* Gs = Qs + L::img_elems;
-    const float* lse_s = vec + (ch & 1) * 2 * KC;
+    const float* lse_s = DMA ? vec + stage * 4 * KC : vec + stage * 2 * KC;
     const float* del_s = lse_s + KC;
     const int q0 = ch * KC;
     const int nqt_c = (nq - q0 + 15) / 16 < 4 ? (nq - q0 + 15) / 16 : 4;       // query tiles of this chunk (uniform)
@@ -615,8 +703,16 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : 2)) void space_stream_dkv_ker
       const float4 ls1 = *reinterpret_cast<const float4*>(lse_s + qh * 32 + 16 + g * 4);
       const float4 de0 = *reinterpret_cast<const float4*>(del_s + qh * 32 + g * 4);
       const float4 de1 = *reinterpret_cast<const float4*>(del_s + qh * 32 + 16 + g * 4);
-      const float lsa[8] = {ls0.x, ls0.y, ls0.z, ls0.w, ls1.x, ls1.y, ls1.z, ls1.w};
+      float lsa[8] = {ls0.x, ls0.y, ls0.z, ls0.w, ls1.x, ls1.y, ls1.z, ls1.w};
       const float dea[8] = {de0.x, de0.y, de0.z, de0.w, de1.x, de1.y, de1.z, de1.w};
+      if constexpr (DMA) {
+        // the ring holds the raw lse of (clamped) rows: log2 units here; padded queries (last chunk) -> exp2(-inf) = 0
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int qidx = q0 + qh * 32 + (r >> 2) * 16 + g * 4 + (r & 3);
+          lsa[r] = qidx < nq ? lsa[r] * kLog2e : INFINITY;
+        }
+      }
       // (cls query, cls key) outside frame 0 is not attended: one element of the group's first key tile
       const bool kill_here = f != 0 && ch == cls_chunk && qh == cls_half;
       Op pa[2], da[2];
@@ -659,8 +755,12 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : 2)) void space_stream_dkv_ker
         adk[1][dt] = mfma(qb, da[1], adk[1][dt]);
       }
     }
-    if (ch + 1 < nchunks) store_chunk((ch + 1) & 1);
-    __syncthreads();
+    if constexpr (DMA) {
+      stage = stage == NST - 1 ? 0 : stage + 1;
+    } else {
+      if (ch + 1 < nchunks) store_chunk((ch + 1) & 1);
+      __syncthreads();
+    }
   }
 
   io_t* dkb = dqkv + (size_t)b * T * ts + D + h * 64;
@@ -727,16 +827,27 @@ int launch_stream_bwd(const void* qkv, const void* out, const void* dout, const 
   using L = StreamLds<P::kImages>;
   const int NBq = ((N + 15) / 16 + 1 + 7) / 8, NBk = ((N + 1 + 15) / 16 + 7) / 8;
   if (L::total_dkv > 64 * 1024) {
-    if (int rc = lvl_allow_lds<space_stream_dq_kernel<P>>()) return rc;
-    if (int rc = lvl_allow_lds<space_stream_dkv_kernel<P>>()) return rc;
+    if (int rc = lvl_allow_lds<space_stream_dq_kernel<P, false>>()) return rc;
+    if (int rc = lvl_allow_lds<space_stream_dkv_kernel<P, false>>()) return rc;
   }
   const int NG = B * F * H;
-  hipLaunchKernelGGL((space_stream_dq_kernel<P>), dim3((unsigned)((NG + 7) / 8 * 8 * NBq)), dim3(256), L::total_fwd, st,
-                     (const io_t*)qkv, (const io_t*)out, (const io_t*)dout, lse, (io_t*)dqkv, delta, atom_ws, F, N, H,
-                     NBq, NG);
+  const dim3 gq((unsigned)((NG + 7) / 8 * 8 * NBq)), gk((unsigned)((NG + 7) / 8 * 8 * NBk));
+  if constexpr (!P::kSplit) {
+    if (!(g_stream_variant.load() & 4)) {         // default: LDS-DMA rings
+      hipLaunchKernelGGL((space_stream_dq_kernel<P, true>), gq, dim3(256), L::total_dma, st, (const io_t*)qkv,
+                         (const io_t*)out, (const io_t*)dout, lse, (io_t*)dqkv, delta, atom_ws, F, N, H, NBq, NG);
+      LVL_CHECK_LAUNCH("space_stream_dq");
+      hipLaunchKernelGGL((space_stream_dkv_kernel<P, true>), gk, dim3(256), L::total_dma_dkv, st, (const io_t*)qkv,
+                         (const io_t*)dout, lse, delta, (io_t*)dqkv, atom_ws, F, N, H, NBk, NG);
+      LVL_CHECK_LAUNCH("space_stream_dkv");
+      return LVL_OK;
+    }
+  }
+  hipLaunchKernelGGL((space_stream_dq_kernel<P, false>), gq, dim3(256), L::total_fwd, st, (const io_t*)qkv,
+                     (const io_t*)out, (const io_t*)dout, lse, (io_t*)dqkv, delta, atom_ws, F, N, H, NBq, NG);
   LVL_CHECK_LAUNCH("space_stream_dq");
-  hipLaunchKernelGGL((space_stream_dkv_kernel<P>), dim3((unsigned)((NG + 7) / 8 * 8 * NBk)), dim3(256), L::total_dkv, st,
-                     (const io_t*)qkv, (const io_t*)dout, lse, delta, (io_t*)dqkv, atom_ws, F, N, H, NBk, NG);
+  hipLaunchKernelGGL((space_stream_dkv_kernel<P, false>), gk, dim3(256), L::total_dkv, st, (const io_t*)qkv,
+                     (const io_t*)dout, lse, delta, (io_t*)dqkv, atom_ws, F, N, H, NBk, NG);
   LVL_CHECK_LAUNCH("space_stream_dkv");
   return LVL_OK;
 }
