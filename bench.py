@@ -71,6 +71,9 @@ def parse():
                         '(VCLM_OPENAI_TIMESFORMER_BASE_GPT2 inference), an extra line outside the driver contract')
     p.add_argument('--returns', type=int, default=10, help='narrator: captions sampled per clip')
     p.add_argument('--length', type=int, default=77, help='narrator: caption length in tokens')
+    p.add_argument('--graph-only', action='store_true',
+                   help='internal: run only the graphed-step variant (lavila_amd/graph_step.py) and print its record; the '
+                        'default run spawns this in a child process so that nothing in it can touch the headline')
     p.add_argument('--reuse-tokens', action='store_true',
                    help='feed the SAME token tensor object every step (A/B only: the caption-length read-back of the '
                         'text tower is memoised per tensor object; the default hands over a new tensor per step, as a '
@@ -325,6 +328,63 @@ def _self_launch(args):
     return subprocess.call(cmd, env=env)
 
 
+def _graphed_child(args):
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), '--graph-only', '--batch', str(args.batch), '--frames',
+           str(args.frames), '--model', args.model, '--steps', str(args.steps), '--no-cpu-baseline']
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    except subprocess.TimeoutExpired:
+        return {'error': 'child timed out'}
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"graphed_step"')]
+    if r.returncode != 0 or not lines:
+        return {'error': f'child rc={r.returncode}', 'stderr_tail': r.stderr[-300:]}
+    return json.loads(lines[-1])['graphed_step']
+
+
+def graph_only_main(args, device):
+    """The pretraining iteration as one replayed hipGraph per caption-length bucket: the host's share of a step drops from
+    ~1100 Python-issued launches to one graph launch. The caption bound comes from the host side, as a DataLoader's token
+    tensor would give it (here: read once, outside the timed region)."""
+    from lavila.models.loss import CLIPLoss
+    from lavila_amd.graph_step import GraphedTrainStep
+    model = build_model(args, device)
+    img = model.visual.patch_embed.img_size[0]
+    crit = CLIPLoss(use_vissl=True, cache_labels=True, rank=0, world_size=1)
+    decay = [p for n, p in model.named_parameters() if not (p.ndim < 2 or 'bias' in n or 'ln' in n or 'bn' in n)]
+    no_decay = [p for n, p in model.named_parameters() if (p.ndim < 2 or 'bias' in n or 'ln' in n or 'bn' in n)]
+    opt = torch.optim.AdamW([{'params': decay, 'weight_decay': 0.01}, {'params': no_decay, 'weight_decay': 0.0}],
+                            lr=3e-5, betas=(0.9, 0.999), eps=1e-8, fused=True, capturable=True)
+    video, tokens = synthetic(args, 0, device, img)
+    gstep = GraphedTrainStep(model, crit, opt, tuple(video.shape), tuple(tokens.shape), device, video_dtype=video.dtype)
+    bound = int(tokens.argmax(dim=-1).max().item()) + 1
+    gstep.video = video                       # resident input, as in the eager loop (no per-step copy of the frames)
+    for _ in range(4):                        # eager initialisation step, capture + first replay, two more replays
+        out = gstep(video, tokens.clone(), text_len=bound)
+    torch.cuda.synchronize()
+    n, host, t0 = max(2, args.steps), 0.0, time.perf_counter()
+    for _ in range(n):
+        h0 = time.perf_counter()
+        out = gstep(video, tokens.clone(), text_len=bound)
+        host += time.perf_counter() - h0
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    # the replay call alone with the device idle (no queue back-pressure): what hipGraphLaunch itself costs the host
+    idle = []
+    for _ in range(3):
+        toks = tokens.clone()
+        torch.cuda.synchronize()
+        h0 = time.perf_counter()
+        out = gstep(video, toks, text_len=bound)
+        idle.append(time.perf_counter() - h0)
+        torch.cuda.synchronize()
+    rec = {'ms_per_step': round(1e3 * el / n, 3), 'pairs_per_s': round(args.batch * n / el, 1),
+           'host_enqueue_ms_per_step': round(1e3 * host / n, 2),
+           'replay_call_ms_device_idle': round(1e3 * min(idle), 2), 'steps': n, 'caption_bucket': gstep.buckets,
+           'final_loss': round(float(out['loss'].item()), 4)}
+    print(json.dumps({'graphed_step': rec}), flush=True)
+
+
 def main():
     args = parse()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -372,6 +432,9 @@ def main():
         if args.batch == 256:
             args.batch = 64                # main_infer_narrator.py:48
         return narrator_main(args, world, rank, device)
+
+    if args.graph_only:
+        return graph_only_main(args, device)
 
     from lavila_amd import ops
     from lavila.models.loss import CLIPLoss
@@ -479,6 +542,16 @@ def main():
         full_last = {'ms_per_step': round(1e3 * (time.perf_counter() - t3) / n3, 3), 'steps': n3}
         _t.CLS_ONLY_LAST_BLOCK = True
 
+    # the same iteration captured as one hipGraph per caption-length bucket and replayed (lavila_amd/graph_step.py), in a
+    # child process (its own model, optimizer and allocator: nothing in it can touch the numbers above)
+    graphed = None
+    if (os.environ.get('LAVILA_BENCH_GRAPH', '1') != '0' and world == 1 and not force_group and not args.no_events
+            and amp is not None and rank == 0):
+        try:
+            graphed = _graphed_child(args)
+        except Exception as exc:                # a variant record must never take the headline down
+            graphed = {'error': f'{type(exc).__name__}: {exc}'[:300]}
+
     if rank == 0:
         B, Fr = args.batch, args.frames
         N = model.visual.patches_per_frame
@@ -540,6 +613,8 @@ def main():
                        'host_ms_of_each_step': [round(1e3 * h, 1) for h in host_steps[:32]],
                        'text_trim_off': no_trim,
                        'full_last_block': full_last,
+                       # the same iteration as one replayed hipGraph per caption-length bucket (lavila_amd/graph_step.py)
+                       'graphed_step': graphed,
                        'exact_work_elimination': 'text positions behind the longest caption (causal: unread) and, in the LAST '
                                                  'block of each tower, the projection / LayerNorm / MLP rows that do not reach '
                                                  'the output (only norm(x)[:,0] / the EOT row leave the towers) are not computed; '

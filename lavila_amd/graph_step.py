@@ -1,0 +1,162 @@
+"""The pretraining iteration as ONE hipGraph: forward, loss, backward, optimizer step and the logit-scale clamp of
+`main_pretrain.py:482-530` captured once per caption-length bucket and replayed, instead of ~1100 launches enqueued from
+Python every step (61-73 ms of host work per 172 ms step at TSF-B, local batch 256).
+
+    step = GraphedTrainStep(model, criterion, optimizer, video_shape, tokens_shape, device)
+    for it, (frames, tokens) in enumerate(loader):          # host tensors, as the reference's DataLoader yields them
+        step.set_lr(lr_schedule[it])                        # main_pretrain.py:476-480 (a device scalar: no re-capture)
+        out = step(frames, tokens)                          # H2D copy into the static buffers + one graph launch
+        # out['loss'], out['clip_acc'] ...: device tensors owned by the graph, valid until the next call
+
+What has to be static for a replay, and how each piece of the eager step gets there:
+  * inputs: `step.video` / `step.tokens` are the buffers the graph reads; `__call__` copies into them (for host tensors
+    that IS the `.cuda(non_blocking=True)` of main_pretrain.py:497-498, not an extra pass);
+  * the text tower's caption trim needs the longest caption on the host. The eager path reads it back from the device
+    (one sync per step); here it is taken from the HOST token tensor before the upload (free), rounded up to
+    `text_bucket` positions, and one graph is kept per rounded length -- any length >= the longest caption gives
+    bit-identical rows (causal mask; models.CLIP.encode_text);
+  * the optimizer must be `capturable=True` (torch's fused AdamW then keeps `step` on the device); its learning rates
+    become device scalars so that the per-iteration schedule is a copy, not a re-capture;
+  * gradients are graph-owned: allocated inside the capture (`zero_grad(set_to_none=True)` before it), rewritten by every
+    replay; the weight copies of the GEMMs are cast inside the graph (ops.weight_copies bypasses its cache under capture).
+The first call runs `warmup` eager iterations' worth of lazy initialisation (optimizer state, kernel attributes) as ONE
+real eager step, so no iteration is lost or repeated: call k performs exactly training step k.
+
+A caller that ran eager iterations of the same model before (on another stream) must drop what it kept of them (the loss
+tensor holds the autograd graph) before the first capture; torch warns about the stream mismatch when it has not.
+
+Limits, loudly: `update_freq` (gradient accumulation) other than 1, stochastic depth / dropout (the RNG offset of a
+replay is not advanced here) and a changing batch shape are refused. DistributedDataParallel models are captured the way
+torch documents for NCCL (collectives inside the graph); that path has run on a one-rank RCCL group only.
+"""
+import torch
+
+from . import models as _models
+from . import ops
+
+
+class GraphedTrainStep:
+    def __init__(self, net, criterion, optimizer, video_shape, tokens_shape, device, amp_dtype=torch.bfloat16,
+                 video_dtype=torch.float32, forward_kwargs=None, text_bucket=8, clamp_logit_scale=(0.0, 4.6052),
+                 loss_key='loss'):
+        if not torch.cuda.is_available():
+            raise RuntimeError('GraphedTrainStep needs a HIP device (hipGraph capture)')
+        for grp in optimizer.param_groups:
+            if not grp.get('capturable', False):
+                raise ValueError('GraphedTrainStep: construct the optimizer with capturable=True (its step counter has to '
+                                 'live on the device to be replayed)')
+        self.net, self.criterion, self.optimizer = net, criterion, optimizer
+        self.model = net.module if hasattr(net, 'module') else net
+        for m in self.model.modules():
+            if isinstance(m, torch.nn.Dropout) and m.p > 0 and self.model.training:
+                raise NotImplementedError('GraphedTrainStep: dropout inside a replayed graph (RNG state is not advanced)')
+            if type(m).__name__ == 'DropPath' and getattr(m, 'drop_prob', 0.) > 0 and self.model.training:
+                raise NotImplementedError('GraphedTrainStep: stochastic depth inside a replayed graph')
+        self.device = torch.device(device)
+        self.amp_dtype = amp_dtype
+        self.kwargs = dict(use_checkpoint=False, norm_embed=True)
+        self.kwargs.update(forward_kwargs or {})
+        self.text_bucket = max(1, int(text_bucket))
+        self.clamp = clamp_logit_scale
+        self.loss_key = loss_key
+        self.video = torch.zeros(video_shape, dtype=video_dtype, device=self.device)
+        self.tokens = torch.zeros(tokens_shape, dtype=torch.long, device=self.device)
+        self.context = int(tokens_shape[-1])
+        # learning rates as device scalars (torch's capturable AdamW reads them on the device)
+        for grp in optimizer.param_groups:
+            if not torch.is_tensor(grp['lr']):
+                grp['lr'] = torch.tensor(float(grp['lr']), dtype=torch.float32, device=self.device)
+        self._graphs = {}            # rounded caption length -> (graph, outputs)
+        self._pool = None
+        # The eager first iteration and every capture run on ONE dedicated stream: autograd pins a parameter's
+        # AccumulateGrad node to the stream it was created on, and a node that outlives its iteration (kept alive by
+        # anything that still references that iteration's autograd graph) would otherwise run on a stream outside the
+        # capture -- which ends the capture with a crash inside hipStreamEndCapture, not with an error.
+        self._stream = torch.cuda.Stream(device=self.device)
+        self._warm = False
+        self.replays = 0
+
+    # ---- host side of one iteration -------------------------------------------------------------------------------
+    def set_lr(self, lr):
+        """One value for every group or one per group (main_pretrain.py:476-480: `param_group['lr'] = lr_schedule[it]`)."""
+        groups = self.optimizer.param_groups
+        values = [lr] * len(groups) if not isinstance(lr, (list, tuple)) else list(lr)
+        if len(values) != len(groups):
+            raise ValueError(f'set_lr: {len(values)} values for {len(groups)} parameter groups')
+        for grp, v in zip(groups, values):
+            grp['lr'].fill_(float(v))
+
+    def caption_length(self, tokens):
+        """1 + the largest EOT position (the EOT token has the highest id: models.py:158-160) of a HOST token tensor,
+        rounded up to the bucket; the full context for device tensors (reading them would be the sync this class removes)."""
+        if tokens.is_cuda:
+            return self.context
+        longest = int(tokens.argmax(dim=-1).max()) + 1
+        b = self.text_bucket
+        return min(self.context, (longest + b - 1) // b * b)
+
+    def __call__(self, video, tokens, text_len=None):
+        """One training iteration on (video, tokens) -- host or device tensors of the static shapes. `text_len`: a caller's
+        own bound on the caption length (>= 1 + the largest EOT position), for token tensors already on the device."""
+        if tuple(video.shape) != tuple(self.video.shape) or tuple(tokens.shape) != tuple(self.tokens.shape):
+            raise ValueError(f'GraphedTrainStep was built for {tuple(self.video.shape)} / {tuple(self.tokens.shape)}, got '
+                             f'{tuple(video.shape)} / {tuple(tokens.shape)} (a last, smaller batch runs eagerly)')
+        if text_len is None:
+            L = self.caption_length(tokens)
+        else:
+            b = self.text_bucket
+            L = min(self.context, (int(text_len) + b - 1) // b * b)
+        if video.data_ptr() != self.video.data_ptr():
+            self.video.copy_(video, non_blocking=True)
+        if tokens.data_ptr() != self.tokens.data_ptr():
+            self.tokens.copy_(tokens, non_blocking=True)
+        if not self._warm:
+            self._warm = True
+            return self._eager(L)                 # lazy initialisation happens in a real step
+        entry = self._graphs.get(L)
+        if entry is None:
+            entry = self._graphs[L] = self._capture(L)
+        entry[0].replay()
+        self.replays += 1
+        return entry[1]
+
+    # ---- the iteration itself -------------------------------------------------------------------------------------
+    def _iteration(self, L):
+        with _models.fixed_text_length(L):
+            with torch.autocast('cuda', dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
+                out = self.net(self.video, self.tokens, **self.kwargs)
+                losses = self.criterion(out)
+            losses[self.loss_key].backward()
+        self.optimizer.step()
+        if self.clamp is not None and hasattr(self.model, 'logit_scale'):
+            self.model.logit_scale.data.clamp_(*self.clamp)            # main_pretrain.py:527-528
+        # detached: nothing handed out may keep this iteration's autograd graph (and its AccumulateGrad nodes) alive
+        return {k: v.detach() for k, v in losses.items() if torch.is_tensor(v)}
+
+    def _eager(self, L):
+        cur = torch.cuda.current_stream(self.device)
+        self._stream.wait_stream(cur)
+        with torch.cuda.stream(self._stream):
+            self.optimizer.zero_grad(set_to_none=True)
+            out = self._iteration(L)
+            self.optimizer.zero_grad(set_to_none=True)
+        cur.wait_stream(self._stream)
+        for v in out.values():
+            v.record_stream(cur)
+        return out
+
+    def _capture(self, L):
+        self.optimizer.zero_grad(set_to_none=True)
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        if self._pool is None:
+            self._pool = torch.cuda.graph_pool_handle()
+        # one pool for every bucket: nothing a graph allocates is read after the next call (outputs are per call, the
+        # gradients are rewritten by each replay before its optimizer step reads them)
+        with torch.cuda.graph(graph, pool=self._pool, stream=self._stream):
+            out = self._iteration(L)
+        return graph, out
+
+    @property
+    def buckets(self):
+        return sorted(self._graphs)

@@ -8,6 +8,7 @@ lavila_amd.gpt2_gated). The per-frame ViT narrators (`VCLM_OPENAI_VIT*`), Distil
 """
 import contextlib
 import os
+import threading
 import weakref
 
 import numpy as np
@@ -49,6 +50,22 @@ _TEXT_STREAM = os.environ.get('LAVILA_TEXT_STREAM', '1') != '0'
 _TEXT_TRIM = os.environ.get('LAVILA_TEXT_TRIM', '1') != '0'
 _TEXT_AFTER_BLOCK = 1          # video blocks enqueued before the text tower's caption-length read-back
 _text_streams = {}
+
+
+_fixed_len = threading.local()
+
+
+@contextlib.contextmanager
+def fixed_text_length(length):
+    """Inside: the text tower runs on the first `length` positions, a HOST-known bound (>= 1 + the largest EOT position of
+    every batch it will see) instead of the per-batch read-back -- what a captured graph needs (graph_step.py). Any
+    bound >= the longest caption gives bit-identical rows (causal mask). None = no bound."""
+    prev = getattr(_fixed_len, 'value', None)
+    _fixed_len.value = None if length is None else int(length)
+    try:
+        yield
+    finally:
+        _fixed_len.value = prev
 
 
 _lmax_memos = weakref.WeakKeyDictionary()      # model -> (weakref to the token tensor, its version, longest caption)
@@ -146,7 +163,8 @@ class CLIP(nn.Module):
     def _eot_rows(self, text):
         """(EOT row of every caption, their maximum as a device scalar or None): enqueued without a host read."""
         rows = text.argmax(dim=-1)
-        trim = _TEXT_TRIM and text.is_cuda and not torch.cuda.is_current_stream_capturing()
+        trim = (_TEXT_TRIM and text.is_cuda and getattr(_fixed_len, 'value', None) is None
+                and not torch.cuda.is_current_stream_capturing())
         return rows, (rows.max() if trim else None)
 
     def encode_text(self, text, use_checkpoint=False, _eot=None):
@@ -158,7 +176,10 @@ class CLIP(nn.Module):
             # Costs one host read of a scalar (the reference driver reads loss.item() every step anyway);
             # LAVILA_TEXT_TRIM=0 (or stream capture) keeps all 77 positions.
             rows, rows_max = self._eot_rows(text) if _eot is None else _eot
-            if rows_max is not None:
+            bound = getattr(_fixed_len, 'value', None)
+            if bound is not None:
+                text = text[:, :max(1, min(bound, text.shape[1]))]
+            elif rows_max is not None:
                 text = text[:, :_longest_caption(self, text, rows, rows_max)]
             x = self.token_embedding(text) + self.positional_embedding[:text.shape[1]]          # [B, L, W]
             if x.dtype == torch.float16:                   # model.half(): compute in bf16 (f32 stream if asked for)

@@ -1,0 +1,126 @@
+"""GPU (-m gpu): lavila_amd.graph_step.GraphedTrainStep -- the pretraining iteration (main_pretrain.py:482-530: forward,
+CLIPLoss, backward, AdamW, logit-scale clamp) captured as one hipGraph per caption-length bucket.
+
+Two copies of one model see the same five batches: one through the eager loop (per-batch caption read-back, float
+learning rate written into the parameter groups), one through the graphed step (eager first call, then capture / replay,
+bucketed caption bound taken from the HOST tokens, learning rate as a device scalar). Every launch is the same kernel on
+the same operands, so losses and gradients agree to rounding noise of the float32 atomics (cls rows of the attention
+backward), and the replays really are replays (two graphs for two buckets, host time of a replay far below a step's)."""
+import copy
+
+import pytest
+import torch
+
+from helpers import build_model
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+CFG = dict(img=224, patch=16, frames=4, dim=768, depth=2, heads=12, t_width=512, t_heads=8, t_layers=2, vocab=1024,
+           embed=256, batch=4, gated=False)
+LENGTHS = [20, 23, 33, 20, 40]              # caption lengths (EOT position + 1): buckets of 8 -> 24, 24, 40, 24, 40
+LRS = [1e-4, 2e-4, 3e-4, 2e-4, 1e-4]
+
+
+def _batches():
+    g = torch.Generator().manual_seed(5)
+    out = []
+    for n in LENGTHS:
+        video = torch.randn(CFG['batch'], 3, CFG['frames'], CFG['img'], CFG['img'], generator=g)
+        tokens = torch.zeros(CFG['batch'], 77, dtype=torch.long)
+        for b in range(CFG['batch']):
+            ln = n if b == 0 else max(3, n - 2 * b)             # the first caption is the longest
+            tokens[b, :ln - 1] = torch.randint(1, CFG['vocab'] - 2, (ln - 1,), generator=g)
+            tokens[b, ln - 1] = CFG['vocab'] - 1                  # EOT = highest id
+        out.append((video, tokens))
+    return out
+
+
+def _groups(model):
+    decay = [p for n, p in model.named_parameters() if p.ndim >= 2]
+    rest = [p for n, p in model.named_parameters() if p.ndim < 2]
+    return [{'params': decay, 'weight_decay': 0.01}, {'params': rest, 'weight_decay': 0.0}]
+
+
+def test_graphed_step_equals_the_eager_loop():
+    from lavila.models.loss import CLIPLoss
+    from lavila_amd.graph_step import GraphedTrainStep
+    torch.manual_seed(3)
+    model_e = build_model(CFG).to(DEV).train()
+    model_g = copy.deepcopy(model_e)
+    crit = CLIPLoss(use_vissl=True, cache_labels=True, rank=0, world_size=1)
+    opt_e = torch.optim.AdamW(_groups(model_e), lr=1e-4, fused=True, capturable=True)
+    opt_g = torch.optim.AdamW(_groups(model_g), lr=1e-4, fused=True, capturable=True)
+    step = GraphedTrainStep(model_g, crit, opt_g, (CFG['batch'], 3, CFG['frames'], CFG['img'], CFG['img']),
+                            (CFG['batch'], 77), DEV)
+    losses_e, losses_g, grads_e, grads_g = [], [], [], []
+    for it, (video, tokens) in enumerate(_batches()):
+        # eager loop, as main_pretrain.py writes it
+        for grp in opt_e.param_groups:
+            grp['lr'] = LRS[it]
+        v, t = video.to(DEV), tokens.to(DEV)
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            le = crit(model_e(v, t, use_checkpoint=False, norm_embed=True))['loss']
+        le.backward()
+        grads_e.append(torch.cat([p.grad.flatten().float() for p in model_e.parameters()]).clone())
+        opt_e.step()
+        opt_e.zero_grad(set_to_none=True)
+        model_e.logit_scale.data.clamp_(0, 4.6052)
+        losses_e.append(float(le))
+        # graphed step on the HOST tensors
+        step.set_lr(LRS[it])
+        out = step(video, tokens)
+        losses_g.append(float(out['loss']))
+        if it > 0:                       # graph-owned gradients of the replay that just ran
+            grads_g.append(torch.cat([p.grad.flatten().float() for p in model_g.parameters()]).clone())
+        else:
+            grads_g.append(None)
+    assert step.buckets == [24, 40] and step.replays == 4
+    for it in range(len(LENGTHS)):
+        assert abs(losses_e[it] - losses_g[it]) <= 2e-3 * abs(losses_e[it]) + 1e-4, (it, losses_e, losses_g)
+    assert losses_e[-1] != losses_e[0]
+    # step 1 (first replay) starts from states that differ by atomics noise at most: gradients agree in aggregate
+    for it in (1, 2):
+        ge, gg = grads_e[it], grads_g[it]
+        rel = float((ge - gg).norm() / ge.norm())
+        assert rel < 2e-2, (it, rel)
+    # parameters after five steps: Adam turns a rounding-noise gradient into a +-lr move, so compare in aggregate
+    pe = torch.cat([p.detach().flatten().float() for p in model_e.parameters()])
+    pg = torch.cat([p.detach().flatten().float() for p in model_g.parameters()])
+    moved = float((pe - pg).abs().max())
+    assert moved <= 2.0 * sum(LRS) + 1e-6, moved
+    frac = float(((pe - pg).abs() > 0.25 * max(LRS)).float().mean())
+    assert frac < 0.02, frac
+
+
+def test_replay_is_host_light_and_refuses_what_it_cannot_replay():
+    import time
+    from lavila.models.loss import CLIPLoss
+    from lavila_amd.graph_step import GraphedTrainStep
+    torch.manual_seed(4)
+    model = build_model(CFG).to(DEV).train()
+    crit = CLIPLoss(use_vissl=True, cache_labels=True, rank=0, world_size=1)
+    with pytest.raises(ValueError, match='capturable'):
+        GraphedTrainStep(model, crit, torch.optim.AdamW(model.parameters(), lr=1e-4, fused=True), (1,), (1, 77), DEV)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, fused=True, capturable=True)
+    shape_v, shape_t = (CFG['batch'], 3, CFG['frames'], CFG['img'], CFG['img']), (CFG['batch'], 77)
+    step = GraphedTrainStep(model, crit, opt, shape_v, shape_t, DEV)
+    video, tokens = _batches()[0]
+    with pytest.raises(ValueError, match='built for'):
+        step(video[:2], tokens[:2])
+    for _ in range(3):
+        step(video, tokens)
+    torch.cuda.synchronize()
+    # a replay: the host returns long before the device has finished the step
+    t0 = time.perf_counter()
+    out = step(video, tokens)
+    host = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    total = time.perf_counter() - t0
+    assert torch.isfinite(out['loss'])
+    assert host < 0.5 * total or total < 5e-3, (host, total)
+    # a device token tensor without a bound: the full context (no read-back), one more bucket
+    step(video.to(DEV), tokens.to(DEV))
+    assert step.buckets == [24, 77]
+    step(video.to(DEV), tokens.to(DEV), text_len=21)
+    assert step.buckets == [24, 77]
