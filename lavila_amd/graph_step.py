@@ -19,15 +19,17 @@ What has to be static for a replay, and how each piece of the eager step gets th
     become device scalars so that the per-iteration schedule is a copy, not a re-capture;
   * gradients are graph-owned: allocated inside the capture (`zero_grad(set_to_none=True)` before it), rewritten by every
     replay; the weight copies of the GEMMs are cast inside the graph (ops.weight_copies bypasses its cache under capture).
-The first call runs `warmup` eager iterations' worth of lazy initialisation (optimizer state, kernel attributes) as ONE
-real eager step, so no iteration is lost or repeated: call k performs exactly training step k.
+The first call is a real EAGER step -- optimizer state and kernel attributes are initialised there -- so no iteration is
+lost or repeated: call k performs training step k.
 
 A caller that ran eager iterations of the same model before (on another stream) must drop what it kept of them (the loss
 tensor holds the autograd graph) before the first capture; torch warns about the stream mismatch when it has not.
 
 Limits, loudly: `update_freq` (gradient accumulation) other than 1, stochastic depth / dropout (the RNG offset of a
-replay is not advanced here) and a changing batch shape are refused. DistributedDataParallel models are captured the way
-torch documents for NCCL (collectives inside the graph); that path has run on a one-rank RCCL group only.
+replay is not advanced here), a changing batch shape, and DistributedDataParallel models are refused: with a process group
+alive, torch's NCCL watchdog thread polls events while the stream is capturing and this ROCm build answers with
+hipErrorStreamCaptureUnsupported and an abort (tried on a one-rank RCCL group: tools/gpu_runs/gpu_r4o.sh). The graphed step
+is a single-process feature here; multi-GPU jobs keep the eager loop.
 """
 import torch
 
@@ -38,7 +40,14 @@ from . import ops
 class GraphedTrainStep:
     def __init__(self, net, criterion, optimizer, video_shape, tokens_shape, device, amp_dtype=torch.bfloat16,
                  video_dtype=torch.float32, forward_kwargs=None, text_bucket=8, clamp_logit_scale=(0.0, 4.6052),
-                 loss_key='loss'):
+                 loss_key='loss', stream=None, eager_calls=None):
+        if isinstance(net, torch.nn.parallel.DistributedDataParallel):
+            # measured on this build (torch 2.10 + ROCm 7, one-rank RCCL group, wrapper constructed on the capture stream,
+            # 11 eager iterations first): ProcessGroupNCCL's watchdog thread polls its work events with hipEventQuery
+            # while the stream is capturing -> hipErrorStreamCaptureUnsupported -> the process aborts
+            raise NotImplementedError('GraphedTrainStep: a DistributedDataParallel model cannot be captured on this '
+                                      'torch / ROCm build (the process-group watchdog queries events during the '
+                                      'capture and aborts the process); multi-GPU jobs use the eager loop')
         if not torch.cuda.is_available():
             raise RuntimeError('GraphedTrainStep needs a HIP device (hipGraph capture)')
         for grp in optimizer.param_groups:
@@ -72,8 +81,8 @@ class GraphedTrainStep:
         # AccumulateGrad node to the stream it was created on, and a node that outlives its iteration (kept alive by
         # anything that still references that iteration's autograd graph) would otherwise run on a stream outside the
         # capture -- which ends the capture with a crash inside hipStreamEndCapture, not with an error.
-        self._stream = torch.cuda.Stream(device=self.device)
-        self._warm = False
+        self._stream = stream if stream is not None else torch.cuda.Stream(device=self.device)
+        self._eager_left = int(eager_calls) if eager_calls is not None else 1
         self.replays = 0
 
     # ---- host side of one iteration -------------------------------------------------------------------------------
@@ -110,9 +119,9 @@ class GraphedTrainStep:
             self.video.copy_(video, non_blocking=True)
         if tokens.data_ptr() != self.tokens.data_ptr():
             self.tokens.copy_(tokens, non_blocking=True)
-        if not self._warm:
-            self._warm = True
-            return self._eager(L)                 # lazy initialisation happens in a real step
+        if self._eager_left > 0:
+            self._eager_left -= 1
+            return self._eager(L)                 # lazy initialisation happens in real steps
         entry = self._graphs.get(L)
         if entry is None:
             entry = self._graphs[L] = self._capture(L)

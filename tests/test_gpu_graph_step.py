@@ -124,3 +124,4 @@ def test_replay_is_host_light_and_refuses_what_it_cannot_replay():
     assert step.buckets == [24, 77]
     step(video.to(DEV), tokens.to(DEV), text_len=21)
     assert step.buckets == [24, 77]
+

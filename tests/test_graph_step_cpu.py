@@ -34,3 +34,10 @@ def test_graphed_step_is_loud_without_a_device():
     lin = torch.nn.Linear(4, 4)
     with pytest.raises(RuntimeError, match='HIP device'):
         GraphedTrainStep(lin, None, torch.optim.AdamW(lin.parameters()), (1, 3, 1, 8, 8), (1, 77), 'cpu')
+
+
+def test_distributed_data_parallel_models_are_refused():
+    """Measured on the GPU box (one-rank RCCL group): the process-group watchdog aborts the process during a capture."""
+    ddp = torch.nn.parallel.DistributedDataParallel.__new__(torch.nn.parallel.DistributedDataParallel)
+    with pytest.raises(NotImplementedError, match='DistributedDataParallel'):
+        GraphedTrainStep(ddp, None, None, (1, 3, 1, 8, 8), (1, 77), 'cpu')
