@@ -333,7 +333,7 @@ def _graphed_child(args):
     cmd = [sys.executable, os.path.abspath(__file__), '--graph-only', '--batch', str(args.batch), '--frames',
            str(args.frames), '--model', args.model, '--steps', str(args.steps), '--no-cpu-baseline']
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     except subprocess.TimeoutExpired:
         return {'error': 'child timed out'}
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{"graphed_step"')]
