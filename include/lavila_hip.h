@@ -145,7 +145,9 @@ int lvl_debug_f32_generic(int on);
  * kernels for EVERY space group, -1 = never (the LDS-resident kernels up to 592 keys, as in round 3), 0 = the shipped
  * choice. Results agree to rounding (bf16) / f32 summation order. */
 int lvl_debug_space_stream(int mode);
-/* Measurement hook: register budget of the streaming forward kernel (0 = 3 workgroups per compute unit, 1 = 4). */
+/* Measurement hook, bf16 streaming kernels: bit 0 = the forward's 3-workgroup cut with a three-stage LDS-DMA ring (default:
+ * 4 workgroups per compute unit, two stages); bit 2 = register staging instead of the LDS-DMA rings (all three kernels;
+ * bit 0 then selects the forward's 4-workgroup register-staged cut). Same results. */
 int lvl_debug_stream_variant(int v);
 /* Test hook: how many lvl_divided_attn_* / lvl_causal_attn_* calls of this process were served by the shape-generic
  * kernels so far (reset != 0: read and clear). */

@@ -74,6 +74,30 @@ __device__ __forceinline__ void dma_issue_chunk(uint16_t* stage, int ch, int nro
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(src) : "memory", "m0");
   }
 }
+// The common case of a fill: chunk rows that are consecutive tokens and all inside the group. The per-lane part of the
+// address (row within the 8-row fill, swizzled slot) is the same for every fill of every chunk -- one 32-bit VGPR offset
+// computed once -- and everything else rides in the scalar base: no vector arithmetic per fill.
+//   voff  = (lane >> 3) * row_bytes + (((lane & 7) ^ ((lane >> 3) & 7)) << 4)
+//   base0 = first byte of row (wave's first 8-row block) of the chunk in the wave's image; + i * 8 rows per fill
+__device__ __forceinline__ void dma_issue_linear(uint16_t* stage, int wave_u, const char* base0, uint32_t voff,
+                                                 uint32_t rows8_bytes) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int f = wave_u * 4 + i;
+    const int image = f >> 3, blk = f & 7;
+    const uint32_t m0v = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(stage + image * (KC * RS)) + (uint32_t)blk * 1024u);
+    const char* b = base0 + (size_t)i * rows8_bytes;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(voff), "s"(b)
+                 : "memory", "m0");
+  }
+}
+// max without the canonicalising v_max x,x that fmaxf puts in front of values the compiler cannot prove quiet (MFMA
+// results): the scores are never NaN (finite operands; -inf only through the masks below)
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+  float d;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
 // forces the compiler to have the operand's registers loaded here (an empty asm that "modifies" them)
 __device__ __forceinline__ void pin_op(uint4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
 __device__ __forceinline__ void pin_op(Op2& v) {
@@ -180,10 +204,14 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : OCC)) void space_stream_fwd_k
   auto key_row = [&](int kidx, int image) {          // K (image 0) / V (image 1) row of key kidx, as bf16 elements
     return reinterpret_cast<const uint16_t*>(base) + (size_t)(kidx == 0 ? 0 : tok0 + kidx - 1) * ts + D * (1 + image);
   };
+  // ring depth: three stages (two chunks of run-ahead) at 3 workgroups per CU; the 4-workgroup cut has LDS for two
+  // stages (4 x 32 KiB): the next chunk is requested behind the barrier that frees its stage and has one whole chunk of
+  // arithmetic to land
+  constexpr int NS = OCC >= 4 ? 2 : NST;
   int stage = 0;
   if constexpr (DMA) {
     dma_issue_chunk(img, 0, nkeys, wave_u, lane, key_row);
-    if (nchunks > 1) dma_issue_chunk(img + L::buf_elems, 1, nkeys, wave_u, lane, key_row);
+    if (NS == 3 && nchunks > 1) dma_issue_chunk(img + L::buf_elems, 1, nkeys, wave_u, lane, key_row);
     // Pin the query fragments NOW. hipcc defers the wait for their loads to the first use INSIDE the loop, where its
     // s_waitcnt vmcnt(0) (it does not count the asm fills) would drain the run-ahead fills in every iteration.
 #pragma unroll
@@ -195,13 +223,24 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : OCC)) void space_stream_fwd_k
     store_chunk(0);
     __syncthreads();
   }
+  // linear fills (chunks >= 2 that lie inside the group): the lane's constant offset and the wave's scalar row base
+  const uint32_t row_bytes = (uint32_t)(ts * sizeof(io_t));
+  const uint32_t dma_voff = (uint32_t)(lane >> 3) * row_bytes + (uint32_t)(((lane & 7) ^ ((lane >> 3) & 7)) << 4);
+  const char* dma_row0 = reinterpret_cast<const char*>(base + (size_t)(tok0 - 1) * ts + D * (1 + (wave_u >> 1))) +
+                         (size_t)((wave_u & 1) * 32) * row_bytes;          // key row 0 would sit here (rows >= 1 do)
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll 1
   for (int ch = 0; ch < nchunks; ++ch) {
     if constexpr (DMA) {
-      dma_wait_chunk(ch + 1 < nchunks);
-      if (ch + 2 < nchunks) {          // into the stage chunk ch-1 used: every wave has passed the barrier behind it
-        const int s2 = stage == 0 ? 2 : stage - 1;
-        dma_issue_chunk(img + s2 * L::buf_elems, ch + 2, nkeys, wave_u, lane, key_row);
+      dma_wait_chunk(NS == 3 && ch + 1 < nchunks);
+      constexpr int AHEAD = NS - 1;
+      if (ch + AHEAD < nchunks) {      // into the stage chunk ch-1 used: every wave has passed the barrier behind it
+        const int s2 = stage == 0 ? NS - 1 : stage - 1;
+        if ((ch + AHEAD + 1) * KC <= nkeys)    // every row of that chunk is a key of the group: no clamp, no cls row
+          dma_issue_linear(img + s2 * L::buf_elems, wave_u, dma_row0 + (size_t)((ch + AHEAD) * KC) * row_bytes, dma_voff,
+                           8u * row_bytes);
+        else
+          dma_issue_chunk(img + s2 * L::buf_elems, ch + AHEAD, nkeys, wave_u, lane, key_row);
       }
     } else {
       if (ch + 1 < nchunks) load_chunk(ch + 1);
@@ -212,51 +251,75 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : OCC)) void space_stream_fwd_k
     const int k0 = ch * KC;
     const int nt = (nkeys - k0 + 15) / 16 < 4 ? (nkeys - k0 + 15) / 16 : 4;      // key tiles of this chunk (uniform)
     f32x4 s[2][4];
+    if (k0 + KC <= nkeys) {
+      // a full chunk (all but the last one or two): eight fragment reads up front, sixteen MFMAs, no masks
+      Op ka[4][2];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (k < nt) {
-        const Op ka0 = P::tile_op(Ks, LO, k, fo.a[0]), ka1 = P::tile_op(Ks, LO, k, fo.a[1]);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          s[t][k] = mfma(ka0, qf[t][0], f32x4{0.f, 0.f, 0.f, 0.f});
-          s[t][k] = mfma(ka1, qf[t][1], s[t][k]);
-        }
-      } else {
-        s[0][k] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        s[1][k] = s[0][k];
+      for (int k = 0; k < 4; ++k) {
+        ka[k][0] = P::tile_op(Ks, LO, k, fo.a[0]);
+        ka[k][1] = P::tile_op(Ks, LO, k, fo.a[1]);
       }
-    }
-    // s[t][k][r] = raw S[query c of tile t][key k0 + k*16 + g*4 + r]
-    Op pa[2][2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      if (k0 + nt * 16 > nkeys) {                 // the chunk holds padded keys (zero rows): mask them
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) s[t][k] = mfma(ka[k][0], qf[t][0], f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) s[t][k] = mfma(ka[k][1], qf[t][1], s[t][k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (k < nt) {
+          const Op ka0 = P::tile_op(Ks, LO, k, fo.a[0]), ka1 = P::tile_op(Ks, LO, k, fo.a[1]);
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            s[t][k] = mfma(ka0, qf[t][0], f32x4{0.f, 0.f, 0.f, 0.f});
+            s[t][k] = mfma(ka1, qf[t][1], s[t][k]);
+          }
+        } else {
+          s[0][k] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+          s[1][k] = s[0][k];
+        }
+      }
+      // the chunk holds padded keys (zero rows): mask them
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int k = 0; k < 4; ++k)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             s[t][k][r] = (k0 + k * 16 + g * 4 + r < nkeys) ? s[t][k][r] : -INFINITY;
-      }
+    }
+    // s[t][k][r] = raw S[query c of tile t][key k0 + k*16 + g*4 + r]
+    Op pa[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
       // the cls query sees the cls key (key 0) only in frame 0, so that the F partials count it once
       if (ch == 0 && cls_t[t] && f != 0 && g == 0) s[t][0][0] = -INFINITY;
-      float mg = -INFINITY;
+      float mg = max3_raw(s[t][0][0], s[t][0][1], s[t][0][2]);         // 16 scores: eight three-way maxima
 #pragma unroll
-      for (int k = 0; k < 4; ++k) mg = fmaxf(mg, fmaxf(fmaxf(s[t][k][0], s[t][k][1]), fmaxf(s[t][k][2], s[t][k][3])));
+      for (int i = 3; i < 15; i += 2) mg = max3_raw(mg, s[t][i >> 2][i & 3], s[t][(i + 1) >> 2][(i + 1) & 3]);
+      mg = fmaxf(mg, s[t][3][3]);
       mg = rows4_max(mg);
       const float mn = fmaxf(m[t], mg);
       const float al = (m[t] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((m[t] - mn) * kExp2);
       const float mk = (mn == -INFINITY) ? 0.f : mn * kExp2;
       m[t] = mn;
-      float ls = 0.f;
+      // p = exp2(s * kExp2 - mk), two scores per packed multiply-add; the row sum as packed adds
+      const f32x2 sc2 = {kExp2, kExp2}, nm2 = {-mk, -mk};
+      f32x2 ls2 = {0.f, 0.f};
 #pragma unroll
       for (int k = 0; k < 4; ++k)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = __builtin_amdgcn_exp2f(fmaf(s[t][k][r], kExp2, -mk));
-          s[t][k][r] = p;
-          ls += p;
+        for (int r = 0; r < 4; r += 2) {
+          const f32x2 e = f32x2{s[t][k][r], s[t][k][r + 1]} * sc2 + nm2;
+          const f32x2 pp = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+          s[t][k][r] = pp[0];
+          s[t][k][r + 1] = pp[1];
+          ls2 += pp;
         }
-      l[t] = l[t] * al + ls;
+      l[t] = l[t] * al + (ls2[0] + ls2[1]);
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
@@ -279,7 +342,7 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : OCC)) void space_stream_fwd_k
       }
     }
     if constexpr (DMA) {
-      stage = stage == NST - 1 ? 0 : stage + 1;
+      stage = stage == NS - 1 ? 0 : stage + 1;
     } else {
       if (ch + 1 < nchunks) store_chunk((ch + 1) & 1);
       __syncthreads();
@@ -436,13 +499,22 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : 3)) void space_stream_dq_kern
     store_chunk(0);
     __syncthreads();
   }
+  // linear fills (see the forward kernel): chunks whose rows are all keys of the group need no per-fill vector arithmetic
+  const uint32_t row_bytes = (uint32_t)(ts * sizeof(io_t));
+  const uint32_t dma_voff = (uint32_t)(lane >> 3) * row_bytes + (uint32_t)(((lane & 7) ^ ((lane >> 3) & 7)) << 4);
+  const char* dma_row0 = reinterpret_cast<const char*>(base + (size_t)(tok0 - 1) * ts + D * (1 + (wave_u >> 1))) +
+                         (size_t)((wave_u & 1) * 32) * row_bytes;
 #pragma unroll 1
   for (int ch = 0; ch < nchunks; ++ch) {
     if constexpr (DMA) {
       dma_wait_chunk(ch + 1 < nchunks);
       if (ch + 2 < nchunks) {
         const int s2 = stage == 0 ? 2 : stage - 1;
-        dma_issue_chunk(img + s2 * L::buf_elems, ch + 2, nkeys, wave_u, lane, key_row);
+        if ((ch + 3) * KC <= nkeys)
+          dma_issue_linear(img + s2 * L::buf_elems, wave_u, dma_row0 + (size_t)((ch + 2) * KC) * row_bytes, dma_voff,
+                           8u * row_bytes);
+        else
+          dma_issue_chunk(img + s2 * L::buf_elems, ch + 2, nkeys, wave_u, lane, key_row);
       }
     } else {
       if (ch + 1 < nchunks) load_chunk(ch + 1);
@@ -667,14 +739,31 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : 2)) void space_stream_dkv_ker
     store_chunk(0);
     __syncthreads();
   }
+  // linear fills: chunks of patch queries only (the cls query, row N, sits in the last chunk). Waves 0, 1 stream Q rows
+  // (stride 3D), waves 2, 3 dO rows (stride D); the lse / delta fill is 64 consecutive floats
+  const uint32_t row_bytes = (uint32_t)(((wave_u >> 1) ? (size_t)D : ts) * sizeof(io_t));
+  const uint32_t dma_voff = (uint32_t)(lane >> 3) * row_bytes + (uint32_t)(((lane & 7) ^ ((lane >> 3) & 7)) << 4);
+  const char* dma_row0 = ((wave_u >> 1) ? reinterpret_cast<const char*>(dobase + (size_t)tok0 * D)
+                                        : reinterpret_cast<const char*>(base + (size_t)tok0 * ts)) +
+                         (size_t)((wave_u & 1) * 32) * row_bytes;
+  const char* vec_row0 = reinterpret_cast<const char*>(((wave_u & 1) ? drow : lrow) + tok0);
 #pragma unroll 1
   for (int ch = 0; ch < nchunks; ++ch) {
     if constexpr (DMA) {
       dma_wait_chunk<5>(ch + 1 < nchunks);
       if (ch + 2 < nchunks) {
         const int s2 = stage == 0 ? 2 : stage - 1;
-        dma_issue_chunk(img + s2 * L::buf_elems, ch + 2, nq, wave_u, lane, query_row);
-        issue_vec(s2, ch + 2);
+        if ((ch + 3) * KC <= N) {
+          dma_issue_linear(img + s2 * L::buf_elems, wave_u, dma_row0 + (size_t)((ch + 2) * KC) * row_bytes, dma_voff,
+                           8u * row_bytes);
+          const uint32_t m0v = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)(vec + (s2 * 4 + wave_u) * KC));
+          const char* vb = vec_row0 + (size_t)((ch + 2) * KC) * 4;
+          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2" ::"s"(m0v), "v"((uint32_t)lane * 4u),
+                       "s"(vb) : "memory", "m0");
+        } else {
+          dma_issue_chunk(img + s2 * L::buf_elems, ch + 2, nq, wave_u, lane, query_row);
+          issue_vec(s2, ch + 2);
+        }
       }
     } else {
       if (ch + 1 < nchunks) load_chunk(ch + 1);
@@ -789,8 +878,8 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : 2)) void space_stream_dkv_ker
 }
 
 std::atomic<int> g_stream_mode{0};      // 0 auto (groups the resident kernels do not take two-per-CU), 1 always, -1 never
-// bit 0: register-staged forward kernel cut for 4 workgroups per CU (default 3); bit 2: register staging instead of the
-// LDS-DMA ring (bf16)
+// bf16 kernels. bit 0: the forward's 3-workgroup cut with a three-stage LDS-DMA ring (default: 4 workgroups per CU, two
+// stages); bit 2: register staging instead of the LDS-DMA rings (forward: bit 0 then picks its 4-workgroup cut)
 std::atomic<int> g_stream_variant{0};
 
 template <typename P>
@@ -804,8 +893,14 @@ int launch_stream_fwd(const void* qkv, void* out, float* lse, float* ws, int B, 
   const dim3 grid((unsigned)((NG + 7) / 8 * 8 * NB));
   if constexpr (!P::kSplit) {
     if (!(g_stream_variant.load() & 4)) {         // default: LDS-DMA ring (bit 2 of the variant: register staging)
-      hipLaunchKernelGGL((space_stream_fwd_kernel<P, 3, true>), grid, dim3(256), L::total_dma, st, (const io_t*)qkv,
-                         (io_t*)out, lse, ws, F, N, H, NB, NG);
+      // default: the 4-workgroup cut (two-stage ring, 128 registers: 0.359 ms against 0.367 at 16 x 577 keys, batch 8);
+      // bit 0: the 3-workgroup cut with the three-stage ring
+      if (g_stream_variant.load() & 1)
+        hipLaunchKernelGGL((space_stream_fwd_kernel<P, 3, true>), grid, dim3(256), L::total_dma, st, (const io_t*)qkv,
+                           (io_t*)out, lse, ws, F, N, H, NB, NG);
+      else
+        hipLaunchKernelGGL((space_stream_fwd_kernel<P, 4, true>), grid, dim3(256), L::total_fwd, st, (const io_t*)qkv,
+                           (io_t*)out, lse, ws, F, N, H, NB, NG);
       LVL_CHECK_LAUNCH("space_stream_fwd");
       return LVL_OK;
     }

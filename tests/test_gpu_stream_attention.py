@@ -114,3 +114,32 @@ def test_large_groups_take_the_streaming_kernels_and_agree_with_the_resident_one
     torch.testing.assert_close(res[0][0], res[1][0], atol=2e-2, rtol=2e-2)
     torch.testing.assert_close(res[0][1], res[1][1], atol=6e-2, rtol=3e-2)
     assert ((res[0][1] - res[1][1]).norm() / res[1][1].norm()).item() < 1e-2
+
+
+@pytest.mark.parametrize('variant', [1, 4, 5])
+@pytest.mark.parametrize('B,Fr,N,H', [(1, 2, 576, 2), (1, 1, 591, 1), (1, 3, 127, 1), (2, 2, 64, 2), (1, 2, 5, 1)])
+def test_streaming_staging_variants_compute_the_same(variant, B, Fr, N, H):
+    """lvl_debug_stream_variant: bit 0 = the forward's 3-workgroup cut (three-stage LDS-DMA ring; default 4 workgroups, two
+    stages), bit 2 = register staging instead of the LDS-DMA rings. Staging decides how rows reach the LDS, not what is computed: outputs are bit-equal to
+    the default variant's, gradients equal up to the order of the cls rows' float32 atomics."""
+    from lavila_amd import _cabi as C
+    from lavila_amd import ops
+    g = torch.Generator().manual_seed(11 + N)
+    T, D = 1 + Fr * N, 64 * H
+    qkv = (torch.randn(B, T, 3 * D, generator=g) * 1.5).to(DEV, torch.bfloat16)
+    dout = torch.randn(B, T, D, generator=g).to(DEV, torch.bfloat16)
+    res = []
+    with stream_mode(1):
+        for v in (0, variant):
+            C.lib().lvl_debug_stream_variant(v)
+            try:
+                q = qkv.clone().requires_grad_(True)
+                o = ops.divided_attention(q, Fr, N, H, 'space')
+                o.backward(dout)
+                torch.cuda.synchronize()
+                res.append((o.detach().clone(), q.grad.clone()))
+            finally:
+                C.lib().lvl_debug_stream_variant(0)
+    assert torch.equal(res[0][0], res[1][0])
+    torch.testing.assert_close(res[0][1].float(), res[1][1].float(), atol=2e-2, rtol=2e-2)
+    assert torch.equal(res[0][1][:, 1:], res[1][1][:, 1:]) or (res[0][1][:, 1:] != res[1][1][:, 1:]).float().mean() < 1e-3
