@@ -179,6 +179,8 @@ class CLIP(nn.Module):
             bound = getattr(_fixed_len, 'value', None)
             if bound is not None:
                 text = text[:, :max(1, min(bound, text.shape[1]))]
+                # a bound below the real longest caption is the caller's bug; it must not become an out-of-range gather
+                rows = rows.clamp(max=text.shape[1] - 1)
             elif rows_max is not None:
                 text = text[:, :_longest_caption(self, text, rows, rows_max)]
             x = self.token_embedding(text) + self.positional_embedding[:text.shape[1]]          # [B, L, W]
