@@ -17,6 +17,12 @@ LIB = os.path.join(LIBDIR, 'liblavila_hip.so')
 ARCH = 'gfx950'
 
 
+# Per-file flags. -fno-honor-nans for the MFMA attention kernels: without it every fmaxf on an MFMA result gets a
+# canonicalising v_max x,x in front (a quarter of the softmax's VALU instructions); their scores are never NaN (finite
+# operands, -inf only through the masks, every inf - inf guarded by a select) -- attn_mfma_common.h, max3_raw.
+EXTRA_FLAGS = {'attn_space_mfma.hip': ['-fno-honor-nans'], 'attn_space_stream.hip': ['-fno-honor-nans']}
+
+
 def _hipcc():
     for cand in (os.environ.get('HIPCC'), shutil.which('hipcc'), '/opt/rocm/bin/hipcc'):
         if cand and os.path.exists(cand):
@@ -34,6 +40,7 @@ def _digest():
             [os.path.join(HERE, '..', 'include', 'lavila_hip.h')]:
         with open(p, 'rb') as f:
             h.update(p.encode() + b'\0' + f.read())
+    h.update(repr(sorted(EXTRA_FLAGS.items())).encode())
     return h.hexdigest()
 
 
@@ -49,7 +56,7 @@ def build(force=False, verbose=True):
     for src in sources():
         obj = os.path.join(LIBDIR, os.path.basename(src)[:-4] + '.o')
         cmd = [hipcc, f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-fvisibility=hidden',
-               '-Wall', '-Wno-unused-function', '-c', src, '-o', obj]
+               '-Wall', '-Wno-unused-function'] + EXTRA_FLAGS.get(os.path.basename(src), []) + ['-c', src, '-o', obj]
         if verbose:
             print('[lavila_amd.build]', ' '.join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

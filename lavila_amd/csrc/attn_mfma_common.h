@@ -30,6 +30,13 @@ __device__ __forceinline__ f32x4 mfma(uint4 a, uint4 b, f32x4 c) {
 // Reductions over the four 16-lane rows of a wave (the C layout of a 16x16 MFMA tile spreads one query / key column over
 // lanes c, c+16, c+32, c+48): two gfx950 row swaps (v_permlane16_swap, v_permlane32_swap: plain VALU, no LDS crossbar
 // round trip like the ds_bpermute a __shfl_xor compiles to) and every lane holds the result.
+// max of three. fmaxf puts a canonicalising v_max x,x in front of every value the compiler cannot prove quiet -- every
+// MFMA result -- unless the translation unit is compiled with -fno-honor-nans (lavila_amd/build.py does that for the
+// attention kernels: their scores are never NaN -- finite operands, -inf only through the masks, and every inf - inf is
+// guarded by a select). NOT inline asm: the hazard recogniser does not look into asm, and a VALU read of an MFMA result
+// needs wait states it would then not insert (measured: NaNs in the split-operand kernels).
+__device__ __forceinline__ float max3_raw(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float rows4_max(float x) {
   auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
   x = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));

@@ -549,18 +549,25 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : 2)) void space_bwd_fused_kern
         p0 = mfma(vf[0][1], gf[t][1], p0);
         s1 = mfma(kf[1][1], qf[t][1], s1);
         p1 = mfma(vf[1][1], gf[t][1], p1);
+        // score pairs: v_pk_fma_f32 for the exponent, v_pk_mul_f32 for dS = P (dP - delta)
         float d0[4], d1[4];
+        const f32x2 k2 = {kExp2, kExp2}, nl2 = {-Lk[t], -Lk[t]};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float e0 = __builtin_amdgcn_exp2f(fmaf(s0[r], kExp2, -Lk[t]));
-          float e1 = __builtin_amdgcn_exp2f(fmaf(s1[r], kExp2, -Lk[t]));
-          if (j == 0 && r == 0) e0 = kill0[t] ? 0.f : e0;
+        for (int r = 0; r < 4; r += 2) {
+          const f32x2 a0 = f32x2{s0[r], s0[r + 1]} * k2 + nl2, a1 = f32x2{s1[r], s1[r + 1]} * k2 + nl2;
+          f32x2 e0 = {__builtin_amdgcn_exp2f(a0[0]), __builtin_amdgcn_exp2f(a0[1])};
+          f32x2 e1 = {__builtin_amdgcn_exp2f(a1[0]), __builtin_amdgcn_exp2f(a1[1])};
+          if (j == 0 && r == 0) e0[0] = kill0[t] ? 0.f : e0[0];
           if (j == NKP - 1) {            // the padded key rows are zero, but exp2(-lse) may overflow: mask them
-            e0 = (2 * j) * 16 + g * 4 + r < nkeys ? e0 : 0.f;
-            e1 = (2 * j + 1) * 16 + g * 4 + r < nkeys ? e1 : 0.f;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              e0[u] = (2 * j) * 16 + g * 4 + r + u < nkeys ? e0[u] : 0.f;
+              e1[u] = (2 * j + 1) * 16 + g * 4 + r + u < nkeys ? e1[u] : 0.f;
+            }
           }
-          d0[r] = e0 * p0[r];
-          d1[r] = e1 * p1[r];
+          const f32x2 x0 = e0 * f32x2{p0[r], p0[r + 1]}, x1 = e1 * f32x2{p1[r], p1[r + 1]};
+          d0[r] = x0[0]; d0[r + 1] = x0[1];
+          d1[r] = x1[0]; d1[r + 1] = x1[1];
         }
         pa[t] = P::pack(d0, d1);
       }
@@ -670,16 +677,24 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : 2)) void space_bwd_fused_kern
         p0 = mfma(ga[0][1], vv[t][1], p0);
         p1 = mfma(ga[1][1], vv[t][1], p1);
         float e0[4], e1[4], d0[4], d1[4];
+        const f32x2 k2 = {kExp2, kExp2};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          e0[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], kExp2, -lsa[r]));
-          e1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], kExp2, -lsa[4 + r]));
-          if (t == 0) {
-            e0[r] = (kill_pair && g * 4 + r == cls_sub) ? 0.f : e0[r];
-            e1[r] = (kill_pair && 16 + g * 4 + r == cls_sub) ? 0.f : e1[r];
+        for (int r = 0; r < 4; r += 2) {          // score pairs: packed multiply-add / multiply
+          const f32x2 a0 = f32x2{s0[r], s0[r + 1]} * k2 - f32x2{lsa[r], lsa[r + 1]};
+          const f32x2 a1 = f32x2{s1[r], s1[r + 1]} * k2 - f32x2{lsa[4 + r], lsa[5 + r]};
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            e0[r + u] = __builtin_amdgcn_exp2f(a0[u]);
+            e1[r + u] = __builtin_amdgcn_exp2f(a1[u]);
+            if (t == 0) {
+              e0[r + u] = (kill_pair && g * 4 + r + u == cls_sub) ? 0.f : e0[r + u];
+              e1[r + u] = (kill_pair && 16 + g * 4 + r + u == cls_sub) ? 0.f : e1[r + u];
+            }
           }
-          d0[r] = e0[r] * p0[r];
-          d1[r] = e1[r] * p1[r];
+          const f32x2 x0 = f32x2{e0[r], e0[r + 1]} * f32x2{p0[r], p0[r + 1]};
+          const f32x2 x1 = f32x2{e1[r], e1[r + 1]} * f32x2{p1[r], p1[r + 1]};
+          d0[r] = x0[0]; d0[r + 1] = x0[1];
+          d1[r] = x1[0]; d1[r + 1] = x1[1];
         }
         pa[t] = P::pack(e0, e1);
         da[t] = P::pack(d0, d1);

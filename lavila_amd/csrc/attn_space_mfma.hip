@@ -154,7 +154,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 1 : ((NKT <= 13 && !P::kSplit) 
               acc[k][r] = vis ? acc[k][r] : -INFINITY;
             }
           }
-          mg = fmaxf(mg, fmaxf(fmaxf(acc[k][0], acc[k][1]), fmaxf(acc[k][2], acc[k][3])));
+          mg = max3_raw(mg, acc[k][0], acc[k][1]);         // (no canonicalising v_max x,x in front of MFMA results)
+          mg = max3_raw(mg, acc[k][2], acc[k][3]);
         }
       }
       mg = rows4_max(mg);
@@ -174,17 +175,23 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 1 : ((NKT <= 13 && !P::kSplit) 
         m = mg;
       }
       const float mk = (m == -INFINITY) ? 0.f : m * kExp2;
+      // p = exp2(s * kExp2 - mk) and the row sum on score pairs (v_pk_fma_f32 / v_pk_add_f32)
+      const f32x2 sc2 = {kExp2, kExp2}, nm2 = {-mk, -mk};
+      f32x2 l2 = {0.f, 0.f};
 #pragma unroll
       for (int k = 0; k < GS; ++k) {
         if (k < gn) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float p = __builtin_amdgcn_exp2f(fmaf(acc[k][r], kExp2, -mk));
-            acc[k][r] = p;
-            l += p;
+          for (int r = 0; r < 4; r += 2) {
+            const f32x2 e = f32x2{acc[k][r], acc[k][r + 1]} * sc2 + nm2;
+            const f32x2 pp = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+            acc[k][r] = pp[0];
+            acc[k][r + 1] = pp[1];
+            l2 += pp;
           }
         }
       }
+      l += l2[0] + l2[1];
 #pragma unroll
       for (int j = 0; j < (GS + 1) / 2; ++j) {
         if (2 * j < gn) {

@@ -91,13 +91,6 @@ __device__ __forceinline__ void dma_issue_linear(uint16_t* stage, int wave_u, co
                  : "memory", "m0");
   }
 }
-// max without the canonicalising v_max x,x that fmaxf puts in front of values the compiler cannot prove quiet (MFMA
-// results): the scores are never NaN (finite operands; -inf only through the masks below)
-__device__ __forceinline__ float max3_raw(float a, float b, float c) {
-  float d;
-  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-  return d;
-}
 // forces the compiler to have the operand's registers loaded here (an empty asm that "modifies" them)
 __device__ __forceinline__ void pin_op(uint4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
 __device__ __forceinline__ void pin_op(Op2& v) {
@@ -228,7 +221,6 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : OCC)) void space_stream_fwd_k
   const uint32_t dma_voff = (uint32_t)(lane >> 3) * row_bytes + (uint32_t)(((lane & 7) ^ ((lane >> 3) & 7)) << 4);
   const char* dma_row0 = reinterpret_cast<const char*>(base + (size_t)(tok0 - 1) * ts + D * (1 + (wave_u >> 1))) +
                          (size_t)((wave_u & 1) * 32) * row_bytes;          // key row 0 would sit here (rows >= 1 do)
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll 1
   for (int ch = 0; ch < nchunks; ++ch) {
     if constexpr (DMA) {
@@ -549,16 +541,22 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : 3)) void space_stream_dq_kern
         s1 = mfma(kf[1][1], qf[t][1], s1);
         p1 = mfma(vf[1][1], gf[t][1], p1);
         float d0[4], d1[4];
+        const f32x2 k2 = {kExp2, kExp2}, nl2 = {-Lk[t], -Lk[t]};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float e0 = __builtin_amdgcn_exp2f(fmaf(s0[r], kExp2, -Lk[t]));
-          float e1 = __builtin_amdgcn_exp2f(fmaf(s1[r], kExp2, -Lk[t]));
-          const int key0 = k0 + (2 * j) * 16 + g * 4 + r, key1 = key0 + 16;
-          e0 = key0 < nkeys ? e0 : 0.f;           // padded key rows are zero, but exp2(-lse) may overflow: mask
-          e1 = key1 < nkeys ? e1 : 0.f;
-          if (cls_t[t] && f != 0 && key0 == 0) e0 = 0.f;        // (cls query, cls key) outside frame 0
-          d0[r] = e0 * p0[r];
-          d1[r] = e1 * p1[r];
+        for (int r = 0; r < 4; r += 2) {            // score pairs: packed multiply-add / multiply
+          const f32x2 a0 = f32x2{s0[r], s0[r + 1]} * k2 + nl2, a1 = f32x2{s1[r], s1[r + 1]} * k2 + nl2;
+          f32x2 e0 = {__builtin_amdgcn_exp2f(a0[0]), __builtin_amdgcn_exp2f(a0[1])};
+          f32x2 e1 = {__builtin_amdgcn_exp2f(a1[0]), __builtin_amdgcn_exp2f(a1[1])};
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int key0 = k0 + (2 * j) * 16 + g * 4 + r + u, key1 = key0 + 16;
+            e0[u] = key0 < nkeys ? e0[u] : 0.f;     // padded key rows are zero, but exp2(-lse) may overflow: mask
+            e1[u] = key1 < nkeys ? e1[u] : 0.f;
+            if (cls_t[t] && f != 0 && key0 == 0) e0[u] = 0.f;      // (cls query, cls key) outside frame 0
+          }
+          const f32x2 x0 = e0 * f32x2{p0[r], p0[r + 1]}, x1 = e1 * f32x2{p1[r], p1[r + 1]};
+          d0[r] = x0[0]; d0[r + 1] = x0[1];
+          d1[r] = x1[0]; d1[r + 1] = x1[1];
         }
         pa[t] = P::pack(d0, d1);
       }
@@ -820,14 +818,22 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : 2)) void space_stream_dkv_ker
         // s0[r] = S[query q0 + qh*32 + g*4 + r][key kt[t]*16 + c], s1: queries + 16
         const bool kill_pair = kill_here && kt[t] == 0 && c == 0;
         float e0[4], e1[4], d0[4], d1[4];
+        const f32x2 k2 = {kExp2, kExp2};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          e0[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], kExp2, -lsa[r]));
-          e1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], kExp2, -lsa[4 + r]));
-          e0[r] = (kill_pair && g * 4 + r == cls_sub) ? 0.f : e0[r];
-          e1[r] = (kill_pair && 16 + g * 4 + r == cls_sub) ? 0.f : e1[r];
-          d0[r] = e0[r] * p0[r];
-          d1[r] = e1[r] * p1[r];
+        for (int r = 0; r < 4; r += 2) {            // score pairs: packed multiply-add / multiply
+          const f32x2 a0 = f32x2{s0[r], s0[r + 1]} * k2 - f32x2{lsa[r], lsa[r + 1]};
+          const f32x2 a1 = f32x2{s1[r], s1[r + 1]} * k2 - f32x2{lsa[4 + r], lsa[5 + r]};
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            e0[r + u] = __builtin_amdgcn_exp2f(a0[u]);
+            e1[r + u] = __builtin_amdgcn_exp2f(a1[u]);
+            e0[r + u] = (kill_pair && g * 4 + r + u == cls_sub) ? 0.f : e0[r + u];
+            e1[r + u] = (kill_pair && 16 + g * 4 + r + u == cls_sub) ? 0.f : e1[r + u];
+          }
+          const f32x2 x0 = f32x2{e0[r], e0[r + 1]} * f32x2{p0[r], p0[r + 1]};
+          const f32x2 x1 = f32x2{e1[r], e1[r + 1]} * f32x2{p1[r], p1[r + 1]};
+          d0[r] = x0[0]; d0[r + 1] = x0[1];
+          d1[r] = x1[0]; d1[r + 1] = x1[1];
         }
         pa[t] = P::pack(e0, e1);
         da[t] = P::pack(d0, d1);
