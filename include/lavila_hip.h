@@ -149,6 +149,14 @@ int lvl_debug_space_stream(int mode);
  * 4 workgroups per compute unit, two stages); bit 2 = register staging instead of the LDS-DMA rings (all three kernels;
  * bit 0 then selects the forward's 4-workgroup register-staged cut). Same results. */
 int lvl_debug_stream_variant(int v);
+/* The "fp8 MFMA QK^T path" BASELINE.json names for TSF-L/14 at 336 (configs[3]): on = the streaming space kernels (bf16
+ * tensors) compute their score products q.k with v_mfma_f32_16x16x32_fp8_fp8 on q / k fragments rounded to OCP e4m3 in
+ * registers (saturating at +-448), forward AND the backward's recomputation of P, so lse and P stay consistent; every
+ * other product (P V, dP, dQ, dK, dV) stays a bf16 MFMA, tensors stay bf16. Off by default (LAVILA_FP8_QK=1 in the
+ * environment turns it on at first use): e4m3 scores cost accuracy and, at head dim 64, buy no time.
+ * Groups the streaming kernels do not take (<= 288 keys, unless lvl_debug_space_stream(1)) and float32 tensors are
+ * unaffected. */
+int lvl_set_fp8_qk(int on);
 /* Test hook: how many lvl_divided_attn_* / lvl_causal_attn_* calls of this process were served by the shape-generic
  * kernels so far (reset != 0: read and clear). */
 int lvl_debug_generic_attention_calls(int reset);

@@ -40,6 +40,7 @@ SIGNATURES = {
     'lvl_debug_f32_generic': (_I, [_I]),
     'lvl_debug_space_stream': (_I, [_I]),
     'lvl_debug_stream_variant': (_I, [_I]),
+    'lvl_set_fp8_qk': (_I, [_I]),
     'lvl_debug_generic_attention_calls': (_I, [_I]),
     'lvl_causal_attn_fwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     'lvl_causal_attn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

@@ -129,8 +129,31 @@ __device__ __forceinline__ void split8(const float (&x)[8], uint4& h, uint4& l) 
                  f32x2_to_bf16x2(r[6], r[7]));
 }
 
+// bf16 x 8 fragment -> OCP e4m3 x 8 (gfx950's fp8), saturating at +-448: the operand of v_mfma_f32_16x16x32_fp8_fp8 holds
+// the same 8 contraction elements per lane as the bf16 instruction's, in 8 bytes
+__device__ __forceinline__ uint2 bf16x8_to_fp8x8(const uint4& v) {
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+  float f[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = __builtin_amdgcn_fmed3f(__uint_as_float(w[i] << 16), -448.f, 448.f);
+    f[2 * i + 1] = __builtin_amdgcn_fmed3f(__uint_as_float(w[i] & 0xffff0000u), -448.f, 448.f);
+  }
+  int lo = 0, hi = 0;
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], lo, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], hi, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+  return make_uint2((uint32_t)lo, (uint32_t)hi);
+}
+__device__ __forceinline__ f32x4 mfma_fp8(const uint2& a, const uint2& b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(__builtin_bit_cast(long, a), __builtin_bit_cast(long, b), c, 0, 0, 0);
+}
+
 struct PrecBf16 {
   static constexpr bool kSplit = false;
+  // the QK^T products of the streaming kernels go through this hook (PrecFp8QK overrides it)
+  static __device__ __forceinline__ f32x4 mfma_qk(const uint4& a, const uint4& b, f32x4 c) { return mfma(a, b, c); }
   static constexpr int kImages = 1;       // LDS images per staged operand
   using io_t = uint16_t;
   using Op = uint4;
@@ -171,8 +194,20 @@ struct PrecBf16 {
   }
 };
 
+// BASELINE configs[3] names an "fp8 MFMA QK^T path" for TSF-L/14 at 336: PrecBf16 with the score products on the fp8
+// matrix instruction. q and k fragments are rounded to e4m3 in registers (tensors, LDS images and every other product
+// stay bf16; P V, dP, dQ, dK, dV are bf16 MFMAs as before); the backward kernels recompute P through the same hook, so
+// the saved lse and the recomputed scores are consistent. An accuracy / speed trade measured in DESIGN.md section 4:
+// opt-in (LAVILA_FP8_QK=1 / lvl_set_fp8_qk), streaming kernels only.
+struct PrecFp8QK : PrecBf16 {
+  static __device__ __forceinline__ f32x4 mfma_qk(const uint4& a, const uint4& b, f32x4 c) {
+    return mfma_fp8(bf16x8_to_fp8x8(a), bf16x8_to_fp8x8(b), c);
+  }
+};
+
 struct PrecSplit {
   static constexpr bool kSplit = true;
+  static __device__ __forceinline__ f32x4 mfma_qk(const Op2& a, const Op2& b, f32x4 c) { return mfma(a, b, c); }
   static constexpr int kImages = 2;
   using io_t = float;
   using Op = Op2;

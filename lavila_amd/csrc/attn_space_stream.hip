@@ -254,11 +254,11 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : OCC)) void space_stream_fwd_k
 #pragma unroll
       for (int k = 0; k < 4; ++k)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) s[t][k] = mfma(ka[k][0], qf[t][0], f32x4{0.f, 0.f, 0.f, 0.f});
+        for (int t = 0; t < 2; ++t) s[t][k] = P::mfma_qk(ka[k][0], qf[t][0], f32x4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
       for (int k = 0; k < 4; ++k)
 #pragma unroll
-        for (int t = 0; t < 2; ++t) s[t][k] = mfma(ka[k][1], qf[t][1], s[t][k]);
+        for (int t = 0; t < 2; ++t) s[t][k] = P::mfma_qk(ka[k][1], qf[t][1], s[t][k]);
     } else {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -266,8 +266,8 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : OCC)) void space_stream_fwd_k
           const Op ka0 = P::tile_op(Ks, LO, k, fo.a[0]), ka1 = P::tile_op(Ks, LO, k, fo.a[1]);
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
-            s[t][k] = mfma(ka0, qf[t][0], f32x4{0.f, 0.f, 0.f, 0.f});
-            s[t][k] = mfma(ka1, qf[t][1], s[t][k]);
+            s[t][k] = P::mfma_qk(ka0, qf[t][0], f32x4{0.f, 0.f, 0.f, 0.f});
+            s[t][k] = P::mfma_qk(ka1, qf[t][1], s[t][k]);
           }
         } else {
           s[0][k] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
@@ -532,13 +532,13 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : 3)) void space_stream_dq_kern
       for (int t = 0; t < 2; ++t) {
         f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
         f32x4 p0 = {-dl[t], -dl[t], -dl[t], -dl[t]}, p1 = p0;     // dP - delta: delta rides in the accumulator
-        s0 = mfma(kf[0][0], qf[t][0], s0);
+        s0 = P::mfma_qk(kf[0][0], qf[t][0], s0);
         p0 = mfma(vf[0][0], gf[t][0], p0);
-        s1 = mfma(kf[1][0], qf[t][0], s1);
+        s1 = P::mfma_qk(kf[1][0], qf[t][0], s1);
         p1 = mfma(vf[1][0], gf[t][0], p1);
-        s0 = mfma(kf[0][1], qf[t][1], s0);
+        s0 = P::mfma_qk(kf[0][1], qf[t][1], s0);
         p0 = mfma(vf[0][1], gf[t][1], p0);
-        s1 = mfma(kf[1][1], qf[t][1], s1);
+        s1 = P::mfma_qk(kf[1][1], qf[t][1], s1);
         p1 = mfma(vf[1][1], gf[t][1], p1);
         float d0[4], d1[4];
         const f32x2 k2 = {kExp2, kExp2}, nl2 = {-Lk[t], -Lk[t]};
@@ -807,12 +807,12 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : 2)) void space_stream_dkv_ker
       for (int t = 0; t < 2; ++t) {
         f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
         f32x4 p0 = {-dea[0], -dea[1], -dea[2], -dea[3]}, p1 = {-dea[4], -dea[5], -dea[6], -dea[7]};    // dP - delta
-        s0 = mfma(qa[0][0], kk[t][0], s0);
-        s1 = mfma(qa[1][0], kk[t][0], s1);
+        s0 = P::mfma_qk(qa[0][0], kk[t][0], s0);
+        s1 = P::mfma_qk(qa[1][0], kk[t][0], s1);
         p0 = mfma(ga[0][0], vv[t][0], p0);
         p1 = mfma(ga[1][0], vv[t][0], p1);
-        s0 = mfma(qa[0][1], kk[t][1], s0);
-        s1 = mfma(qa[1][1], kk[t][1], s1);
+        s0 = P::mfma_qk(qa[0][1], kk[t][1], s0);
+        s1 = P::mfma_qk(qa[1][1], kk[t][1], s1);
         p0 = mfma(ga[0][1], vv[t][1], p0);
         p1 = mfma(ga[1][1], vv[t][1], p1);
         // s0[r] = S[query q0 + qh*32 + g*4 + r][key kt[t]*16 + c], s1: queries + 16
@@ -893,30 +893,36 @@ int launch_stream_fwd(const void* qkv, void* out, float* lse, float* ws, int B, 
   using io_t = typename P::io_t;
   using L = StreamLds<P::kImages>;
   const int NB = ((N + 15) / 16 + 1 + 7) / 8;
-  if (L::total_fwd > 64 * 1024)
-    if (int rc = lvl_allow_lds<space_stream_fwd_kernel<P, 3, false>>()) return rc;
   const int NG = B * F * H;                       // groups; the grid is padded to whole rounds of 8 XCDs
   const dim3 grid((unsigned)((NG + 7) / 8 * 8 * NB));
-  if constexpr (!P::kSplit) {
-    if (!(g_stream_variant.load() & 4)) {         // default: LDS-DMA ring (bit 2 of the variant: register staging)
-      // default: the 4-workgroup cut (two-stage ring, 128 registers: 0.359 ms against 0.367 at 16 x 577 keys, batch 8);
-      // bit 0: the 3-workgroup cut with the three-stage ring
-      if (g_stream_variant.load() & 1)
+  if constexpr (std::is_same<P, PrecFp8QK>::value) {
+    // one cut: LDS-DMA ring, 3 workgroups per CU (the fragment conversions do not fit the 128-register cut)
+    hipLaunchKernelGGL((space_stream_fwd_kernel<P, 3, true>), grid, dim3(256), L::total_dma, st, (const io_t*)qkv,
+                       (io_t*)out, lse, ws, F, N, H, NB, NG);
+  } else if constexpr (P::kSplit) {
+    if (L::total_fwd > 64 * 1024)
+      if (int rc = lvl_allow_lds<space_stream_fwd_kernel<P, 3, false>>()) return rc;
+    hipLaunchKernelGGL((space_stream_fwd_kernel<P, 3, false>), grid, dim3(256), L::total_fwd, st, (const io_t*)qkv,
+                       (io_t*)out, lse, ws, F, N, H, NB, NG);
+  } else {
+    const int v = g_stream_variant.load();
+    if (!(v & 4)) {
+      // default: LDS-DMA, the 4-workgroup cut (two-stage ring, 128 registers: 0.359 ms against 0.367 at 16 x 577 keys,
+      // batch 8); bit 0: the 3-workgroup cut with the three-stage ring
+      if (v & 1)
         hipLaunchKernelGGL((space_stream_fwd_kernel<P, 3, true>), grid, dim3(256), L::total_dma, st, (const io_t*)qkv,
                            (io_t*)out, lse, ws, F, N, H, NB, NG);
       else
         hipLaunchKernelGGL((space_stream_fwd_kernel<P, 4, true>), grid, dim3(256), L::total_fwd, st, (const io_t*)qkv,
                            (io_t*)out, lse, ws, F, N, H, NB, NG);
-      LVL_CHECK_LAUNCH("space_stream_fwd");
-      return LVL_OK;
+    } else if (v & 1) {
+      hipLaunchKernelGGL((space_stream_fwd_kernel<P, 4, false>), grid, dim3(256), L::total_fwd, st, (const io_t*)qkv,
+                         (io_t*)out, lse, ws, F, N, H, NB, NG);
+    } else {
+      hipLaunchKernelGGL((space_stream_fwd_kernel<P, 3, false>), grid, dim3(256), L::total_fwd, st, (const io_t*)qkv,
+                         (io_t*)out, lse, ws, F, N, H, NB, NG);
     }
   }
-  if (!P::kSplit && (g_stream_variant.load() & 1))
-    hipLaunchKernelGGL((space_stream_fwd_kernel<P, 4, false>), grid, dim3(256), L::total_fwd, st, (const io_t*)qkv,
-                       (io_t*)out, lse, ws, F, N, H, NB, NG);
-  else
-    hipLaunchKernelGGL((space_stream_fwd_kernel<P, 3, false>), grid, dim3(256), L::total_fwd, st, (const io_t*)qkv,
-                       (io_t*)out, lse, ws, F, N, H, NB, NG);
   LVL_CHECK_LAUNCH("space_stream_fwd");
   return LVL_OK;
 }
@@ -927,14 +933,17 @@ int launch_stream_bwd(const void* qkv, const void* out, const void* dout, const 
   using io_t = typename P::io_t;
   using L = StreamLds<P::kImages>;
   const int NBq = ((N + 15) / 16 + 1 + 7) / 8, NBk = ((N + 1 + 15) / 16 + 7) / 8;
-  if (L::total_dkv > 64 * 1024) {
-    if (int rc = lvl_allow_lds<space_stream_dq_kernel<P, false>>()) return rc;
-    if (int rc = lvl_allow_lds<space_stream_dkv_kernel<P, false>>()) return rc;
+  if constexpr (P::kSplit) {
+    if (L::total_dkv > 64 * 1024) {
+      if (int rc = lvl_allow_lds<space_stream_dq_kernel<P, false>>()) return rc;
+      if (int rc = lvl_allow_lds<space_stream_dkv_kernel<P, false>>()) return rc;
+    }
   }
   const int NG = B * F * H;
   const dim3 gq((unsigned)((NG + 7) / 8 * 8 * NBq)), gk((unsigned)((NG + 7) / 8 * 8 * NBk));
   if constexpr (!P::kSplit) {
-    if (!(g_stream_variant.load() & 4)) {         // default: LDS-DMA rings
+    // default: LDS-DMA rings (the fp8 QK^T policy has no other cut)
+    if (std::is_same<P, PrecFp8QK>::value || !(g_stream_variant.load() & 4)) {
       hipLaunchKernelGGL((space_stream_dq_kernel<P, true>), gq, dim3(256), L::total_dma, st, (const io_t*)qkv,
                          (const io_t*)out, (const io_t*)dout, lse, (io_t*)dqkv, delta, atom_ws, F, N, H, NBq, NG);
       LVL_CHECK_LAUNCH("space_stream_dq");
@@ -944,12 +953,14 @@ int launch_stream_bwd(const void* qkv, const void* out, const void* dout, const 
       return LVL_OK;
     }
   }
-  hipLaunchKernelGGL((space_stream_dq_kernel<P, false>), gq, dim3(256), L::total_fwd, st, (const io_t*)qkv,
-                     (const io_t*)out, (const io_t*)dout, lse, (io_t*)dqkv, delta, atom_ws, F, N, H, NBq, NG);
-  LVL_CHECK_LAUNCH("space_stream_dq");
-  hipLaunchKernelGGL((space_stream_dkv_kernel<P, false>), gk, dim3(256), L::total_dkv, st, (const io_t*)qkv,
-                     (const io_t*)dout, lse, delta, (io_t*)dqkv, atom_ws, F, N, H, NBk, NG);
-  LVL_CHECK_LAUNCH("space_stream_dkv");
+  if constexpr (!std::is_same<P, PrecFp8QK>::value) {
+    hipLaunchKernelGGL((space_stream_dq_kernel<P, false>), gq, dim3(256), L::total_fwd, st, (const io_t*)qkv,
+                       (const io_t*)out, (const io_t*)dout, lse, (io_t*)dqkv, delta, atom_ws, F, N, H, NBq, NG);
+    LVL_CHECK_LAUNCH("space_stream_dq");
+    hipLaunchKernelGGL((space_stream_dkv_kernel<P, false>), gk, dim3(256), L::total_dkv, st, (const io_t*)qkv,
+                       (const io_t*)dout, lse, delta, (io_t*)dqkv, atom_ws, F, N, H, NBk, NG);
+    LVL_CHECK_LAUNCH("space_stream_dkv");
+  }
   return LVL_OK;
 }
 
@@ -973,6 +984,22 @@ extern "C" int lvl_debug_stream_variant(int v) {
 
 // the shipped choice: groups of more than 288 keys (bf16: the resident kernels would run one 4-wave workgroup per CU;
 // float32: their four images do not fit the LDS at all)
+// fp8 QK^T (PrecFp8QK): -1 = not decided yet (LAVILA_FP8_QK in the environment, default off), 0 / 1 = off / on
+std::atomic<int> g_fp8_qk{-1};
+static bool fp8_qk() {
+  int v = g_fp8_qk.load();
+  if (v < 0) {
+    const char* e = getenv("LAVILA_FP8_QK");
+    v = (e != nullptr && e[0] == '1') ? 1 : 0;
+    g_fp8_qk.store(v);
+  }
+  return v == 1;
+}
+extern "C" int lvl_set_fp8_qk(int on) {
+  g_fp8_qk.store(on ? 1 : 0);
+  return LVL_OK;
+}
+
 bool lvl_space_stream_wanted(int F, int N, int dtype) {
   const int mode = g_stream_mode.load();
   if (mode != 0) return mode > 0;
@@ -982,6 +1009,7 @@ bool lvl_space_stream_wanted(int F, int N, int dtype) {
 int lvl_space_stream_fwd(const void* qkv, void* out, float* lse, float* ws, int B, int F, int N, int H, int dtype,
                          hipStream_t st) {
   const int rc = dtype == LVL_F32 ? launch_stream_fwd<PrecSplit>(qkv, out, lse, ws, B, F, N, H, st)
+                 : fp8_qk()       ? launch_stream_fwd<PrecFp8QK>(qkv, out, lse, ws, B, F, N, H, st)
                                   : launch_stream_fwd<PrecBf16>(qkv, out, lse, ws, B, F, N, H, st);
   if (rc != LVL_OK) return rc;
   lvl_launch_cls_combine(ws, out, lse, B, H, F, 1 + F * N, dtype, st);
@@ -999,7 +1027,8 @@ int lvl_space_stream_bwd(const void* qkv, const void* out, const void* dout, con
   if (e != hipSuccess) return lvl_fail(LVL_EHIP, "space_stream_bwd memset: %s", hipGetErrorString(e));
   const int rc = dtype == LVL_F32
                      ? launch_stream_bwd<PrecSplit>(qkv, out, dout, lse, dqkv, delta, atom_ws, B, F, N, H, st)
-                     : launch_stream_bwd<PrecBf16>(qkv, out, dout, lse, dqkv, delta, atom_ws, B, F, N, H, st);
+                 : fp8_qk() ? launch_stream_bwd<PrecFp8QK>(qkv, out, dout, lse, dqkv, delta, atom_ws, B, F, N, H, st)
+                            : launch_stream_bwd<PrecBf16>(qkv, out, dout, lse, dqkv, delta, atom_ws, B, F, N, H, st);
   if (rc != LVL_OK) return rc;
   lvl_launch_cls_grad_finalize(atom_ws, dqkv, B, T, H, dtype, st);
   LVL_CHECK_LAUNCH("cls_grad_finalize");

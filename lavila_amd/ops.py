@@ -712,6 +712,13 @@ def embed_tokens(pe, cls_token, pos_embed, temporal_embed, frames, n_per_frame):
 # --------------------------------------------------------------------------------------------------
 # attention cores
 # --------------------------------------------------------------------------------------------------
+def set_fp8_qk(on: bool):
+    """BASELINE configs[3]'s "fp8 MFMA QK^T path": the streaming space kernels (groups of more than 288 keys, bf16) compute
+    their scores with the fp8 matrix instruction on e4m3-rounded q / k fragments, forward and backward consistently
+    (include/lavila_hip.h: lvl_set_fp8_qk). Off by default; LAVILA_FP8_QK=1 in the environment is the same switch."""
+    C.check(C.lib().lvl_set_fp8_qk(1 if on else 0), 'lvl_set_fp8_qk')
+
+
 def _qkv_bias_grad(dqkv, dout, dtype):
     """d(bias) of the qkv Linear that feeds an attention core = column sums of dqkv, without reading the k and v
     thirds: every softmax row sums to 1, so sum_rows(dv) = sum_rows(dout) exactly, and the scores do not change when a

@@ -143,3 +143,54 @@ def test_streaming_staging_variants_compute_the_same(variant, B, Fr, N, H):
     assert torch.equal(res[0][0], res[1][0])
     torch.testing.assert_close(res[0][1].float(), res[1][1].float(), atol=2e-2, rtol=2e-2)
     assert torch.equal(res[0][1][:, 1:], res[1][1][:, 1:]) or (res[0][1][:, 1:] != res[1][1][:, 1:]).float().mean() < 1e-3
+
+
+@contextlib.contextmanager
+def fp8_qk():
+    from lavila_amd import ops
+    ops.set_fp8_qk(True)
+    try:
+        yield
+    finally:
+        ops.set_fp8_qk(False)
+
+
+@pytest.mark.parametrize('B,Fr,N,H', [(1, 2, 576, 2), (1, 1, 300, 1), (2, 2, 70, 2)])
+def test_fp8_qk_path_matches_its_emulation(B, Fr, N, H):
+    """BASELINE configs[3]: "fp8 MFMA QK^T path". The kernels round the q / k fragments to OCP e4m3 and take the score
+    products on the fp8 matrix instruction; everything else stays bf16. Emulation: the oracle on q, k rounded to
+    float8_e4m3fn (scores, softmax, P V in double) -- the forward output and dV (= P^T dO: P from the rounded scores) must
+    agree to bf16 rounding; dQ / dK multiply dS with the UNROUNDED bf16 k / q in the kernels (straight-through), so they
+    are held against the plain oracle at e4m3's accuracy, and the whole path against it as well."""
+    from lavila_amd import ops
+    g = torch.Generator().manual_seed(3 + N)
+    T, D = 1 + Fr * N, 64 * H
+    qkv = (torch.randn(B, T, 3 * D, generator=g) * 1.5).to(torch.bfloat16).float()
+    dout = torch.randn(B, T, D, generator=g).to(torch.bfloat16).float()
+    rounded = qkv.clone()
+    rounded[..., :2 * D] = qkv[..., :2 * D].to(torch.float8_e4m3fn).float()
+    qe = rounded.double().requires_grad_(True)
+    oe = O.divided_attention_core(qe, H, Fr, N, 'space')
+    oe.backward(dout.double())
+    qo = qkv.double().requires_grad_(True)
+    oo = O.divided_attention_core(qo, H, Fr, N, 'space')
+    oo.backward(dout.double())
+    with stream_mode(1), fp8_qk():
+        qg = qkv.to(DEV, torch.bfloat16).requires_grad_(True)
+        o = ops.divided_attention(qg, Fr, N, H, 'space')
+        o.backward(dout.to(DEV, torch.bfloat16))
+        torch.cuda.synchronize()
+    with stream_mode(1):
+        qb = qkv.to(DEV, torch.bfloat16).requires_grad_(True)
+        ob = ops.divided_attention(qb, Fr, N, H, 'space')
+    got, grad = o.detach().float().cpu(), qg.grad.float().cpu()
+    # forward and dV against the emulation: bf16 rounding only
+    torch.testing.assert_close(got, oe.detach().float(), atol=6e-2, rtol=3e-2)
+    torch.testing.assert_close(grad[..., 2 * D:], qe.grad[..., 2 * D:].float(), atol=0.18, rtol=3e-2)
+    # the path really is the fp8 one: it differs from the bf16 kernels' output, by about what e4m3 scores cost
+    dev = (got - ob.detach().float().cpu()).abs().max().item()
+    assert dev > 1e-3, 'fp8 QK^T switch had no effect'
+    rel_o = ((got.double() - oo.detach()).norm() / oo.detach().norm()).item()
+    rel_g = ((grad.double() - qo.grad).norm() / qo.grad.norm()).item()
+    assert rel_o < 0.15 and rel_g < 0.25, (rel_o, rel_g)
+    assert torch.isfinite(grad).all()
