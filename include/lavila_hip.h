@@ -32,7 +32,7 @@ extern "C" {
 enum { LVL_F32 = 0, LVL_BF16 = 1 };
 enum { LVL_OK = 0, LVL_EINVAL = -22, LVL_ENOSYS = -38, LVL_EHIP = -5 };
 enum { LVL_ATTN_SPACE = 0, LVL_ATTN_TIME = 1, LVL_ATTN_CAUSAL = 2 /* lvl_attention_fast_path only */ };
-enum { LVL_EPI_BIAS = 0, LVL_EPI_BIAS_QUICKGELU = 1, LVL_EPI_QUICKGELU_BWD = 2 };
+enum { LVL_EPI_BIAS = 0, LVL_EPI_BIAS_QUICKGELU = 1, LVL_EPI_QUICKGELU_BWD = 2, LVL_EPI_BIAS_RESIDUAL = 3 };
 /* activations of the narrator decoder's MLPs (lvl_act_inplace) */
 enum { LVL_ACT_GELU_NEW = 0, LVL_ACT_SQRELU = 1 };
 
@@ -318,6 +318,9 @@ int lvl_sample_next_token(const void* logits, int64_t row_stride, int rows, int 
  *                            timesformer.py:52-54, openai_model.py:177-179; u is kept for the backward)
  *   LVL_EPI_QUICKGELU_BWD    y = acc * d quickgelu(aux_in); colsum[N] f32 = column sums of y (= d fc1.bias);
  *                            acc = dA = dY . W2 is the input gradient of fc2, y = d(fc1 output)
+ *   LVL_EPI_BIAS_RESIDUAL    y = acc + bias + aux_in: the Linear's output added to the residual stream, in f32 before the
+ *                            one rounding of the sum -- `x + attn(norm1(x))`, `x + mlp(norm2(x))` (timesformer.py:183-196;
+ *                            openai_model.py:199-200) leave proj / fc2 as the new stream; aux_in [M,N], y's dtype
  * aux_out / aux_in: [M,N] bf16. N % 256 == 0 and K % 64 == 0 (operands < 4 GiB), else LVL_ENOSYS. Workspace (QUICKGELU_BWD only):
  * lvl_workspace_floats("linear_tn", M, N) floats.
  * dtype = LVL_F32 selects the F32-CLASS MODE of the same kernel (the parity configuration, north_star "within 1e-3

@@ -11,6 +11,10 @@
 //   1  u = acc + bias -> aux_out ; y = u * sigmoid(1.702 u)                Mlp.fc1 + QuickGELU (timesformer.py:52-54)
 //   2  y = acc * quickgelu'(aux_in) ; column sums of y -> partial slab     backward of the same: fc2's input gradient
 //                                                                          becomes d(fc1 output); sums = d(fc1 bias)
+//   3  y = acc (+ bias) + aux_in                                           proj / fc2 + residual: the block's
+//                                                                          `x + attn(...)`, `x + mlp(...)` adds
+//                                                                          (timesformer.py:183-196) leave the GEMM as
+//                                                                          the new residual stream
 //
 // f32-CLASS MODE (template F32O, C-ABI dtype LVL_F32): the SAME kernel -- tile walk, LDS-DMA ring, swizzle, MFMA phases,
 // bias image, epilogue arithmetic -- with float32 results. The operands are bf16 TERM IMAGES of float32 matrices
@@ -315,7 +319,8 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
     float csum[32];
     // EPI 2: the 8 pre-activation pieces of a row group are loaded one row group AHEAD (issued before the previous
     // group's stores, so their latency overlaps its arithmetic instead of serialising eight round trips per tile)
-    uint2 ub_next[EPI == 2 ? 8 : 1];
+    constexpr bool AUXIN = EPI == 2 || EPI == 3;      // aux_in rows ride one row group ahead of the stores
+    uint2 ub_next[AUXIN ? 8 : 1];
     auto load_u = [&](int j) {
       const int64_t m = m0 + (j >> 1) * 128 + wm * 64 + (j & 1) * 32 + r5;
       const uint16_t* urow = reinterpret_cast<const uint16_t*>(aux_in) + (m < M ? m : M - 1) * (int64_t)N + n0 + wn * 64 + 4 * hi;
@@ -327,6 +332,8 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
     if (EPI == 2) {
 #pragma unroll
       for (int c = 0; c < 32; ++c) csum[c] = 0.f;
+    }
+    if (AUXIN) {
       if constexpr (!F32O) load_u(0);
     }
     if constexpr (F32O) {
@@ -352,6 +359,13 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = quick_gelu(v[e]);
             }
+            if (EPI == 3) {
+              const float4 r = *reinterpret_cast<const float4*>(aux_in + o);
+              v[0] += r.x;
+              v[1] += r.y;
+              v[2] += r.z;
+              v[3] += r.w;
+            }
             if (EPI == 2) {
               const float4 u = *reinterpret_cast<const float4*>(aux_in + o);
               v[0] *= quick_gelu_grad(u.x);
@@ -371,8 +385,8 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
 #pragma unroll
     for (int j = 0; j < 4; ++j) {          // row group (qm, mt): 32 rows
       const int64_t mg = m0 + (j >> 1) * 128 + wm * 64 + (j & 1) * 32;
-      uint2 ub_cur[EPI == 2 ? 8 : 1];
-      if (EPI == 2) {
+      uint2 ub_cur[AUXIN ? 8 : 1];
+      if (AUXIN) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) ub_cur[q] = ub_next[q];
         if (j < 3) load_u(j + 1);
@@ -395,6 +409,13 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
             v[1] = quick_gelu(__uint_as_float(upk[rq].x & 0xffff0000u));
             v[2] = quick_gelu(__uint_as_float(upk[rq].y << 16));
             v[3] = quick_gelu(__uint_as_float(upk[rq].y & 0xffff0000u));
+          }
+          if (EPI == 3) {              // + the residual row (bf16), in f32 before the one rounding of the sum
+            const uint2 rb = ub_cur[i * 4 + rq];
+            v[0] += __uint_as_float(rb.x << 16);
+            v[1] += __uint_as_float(rb.x & 0xffff0000u);
+            v[2] += __uint_as_float(rb.y << 16);
+            v[3] += __uint_as_float(rb.y & 0xffff0000u);
           }
           if (EPI == 2) {
             const bool valid = mg + r5 < M;
@@ -686,6 +707,9 @@ extern "C" int lvl_linear_tn(const void* x, const void* w, const float* bias, vo
       case LVL_EPI_BIAS_QUICKGELU:
         LVL_REQUIRE(aux_out != nullptr, "linear_tn: the QuickGELU epilogue writes the pre-activation to aux_out");
         return launch_tn<1, true>(x, w, bias, y, aux_out, nullptr, nullptr, M, N, K, sched, st);
+      case LVL_EPI_BIAS_RESIDUAL:
+        LVL_REQUIRE(aux_in != nullptr, "linear_tn: the residual epilogue reads the residual rows from aux_in");
+        return launch_tn<3, true>(x, w, bias, y, nullptr, aux_in, nullptr, M, N, K, sched, st);
       case LVL_EPI_QUICKGELU_BWD: {
         LVL_REQUIRE(aux_in != nullptr && colsum != nullptr && ws != nullptr && lvl_aligned16(ws),
                     "linear_tn: the QuickGELU-backward epilogue needs aux_in, colsum and a workspace");
@@ -704,6 +728,9 @@ extern "C" int lvl_linear_tn(const void* x, const void* w, const float* bias, vo
     case LVL_EPI_BIAS_QUICKGELU:
       LVL_REQUIRE(aux_out != nullptr, "linear_tn: the QuickGELU epilogue writes the pre-activation to aux_out");
       return launch_tn<1>(x, w, bias, y, aux_out, nullptr, nullptr, M, N, K, sched, st);
+    case LVL_EPI_BIAS_RESIDUAL:
+      LVL_REQUIRE(aux_in != nullptr, "linear_tn: the residual epilogue reads the residual rows from aux_in");
+      return launch_tn<3>(x, w, bias, y, nullptr, aux_in, nullptr, M, N, K, sched, st);
     case LVL_EPI_QUICKGELU_BWD: {
       LVL_REQUIRE(aux_in != nullptr && colsum != nullptr && ws != nullptr && lvl_aligned16(ws),
                   "linear_tn: the QuickGELU-backward epilogue needs aux_in, colsum and a workspace");

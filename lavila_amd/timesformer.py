@@ -212,6 +212,34 @@ class VarAttention(nn.Module):
         return _like_caller(ops.linear(self.core(x, mode, frames, n), self.proj.weight, self.proj.bias), x)
 
 
+class PendingMlp:
+    """A block's `x1 + mlp(norm2(x1))` that has not been computed yet: with ops.RESIDUAL_EPILOGUE the MLP's second GEMM adds
+    the residual in its epilogue and the NEXT consumer's LayerNorm reads the sum, so the MLP is enqueued by that consumer
+    (ops.mlp_residual_layer_norm). Travels in the `pend` slot of the fused residual chain; the fc2 bias in `pend_bias`."""
+
+    __slots__ = ('h', 'mlp')
+
+    def __init__(self, h, mlp):
+        self.h, self.mlp = h, mlp
+
+    def materialize(self):
+        """The MLP branch as a tensor (fc2's bias still pending), for consumers that want the composed form."""
+        m = self.mlp
+        return ops.mlp_quickgelu(self.h, m.fc1.weight, m.fc1.bias, m.fc2.weight)
+
+
+def _close_pending(res, pend, pend_bias, norm):
+    """(s, h) = (res + pend + pend_bias, norm(s)) for a tensor or a PendingMlp in the `pend` slot."""
+    if isinstance(pend, PendingMlp):
+        m = pend.mlp
+        fused = ops.mlp_residual_layer_norm(pend.h, m.fc1.weight, m.fc1.bias, m.fc2.weight, pend_bias, res, norm.weight,
+                                            norm.bias, norm.eps)
+        if fused is not None:
+            return fused
+        pend = pend.materialize()
+    return ops.add_layer_norm(res, pend, pend_bias, norm.weight, norm.bias, norm.eps, keep_sum=True)
+
+
 class SpaceTimeBlock(nn.Module):
     """timesformer.py:147-198, 'frozen-in-time' wiring:
          t = x + [tanh(alpha)] * timeattn(norm3(x));  x1 = x + attn(norm1(t));  out = x1 + mlp(norm2(x1))
@@ -241,7 +269,7 @@ class SpaceTimeBlock(nn.Module):
         return self.training and ((isinstance(self.drop_path, DropPath) and self.drop_path.drop_prob > 0.) or
                                   self.mlp.drop.p > 0.)
 
-    def chain(self, res, pend, pend_bias, frames, n_per_frame):
+    def chain(self, res, pend, pend_bias, frames, n_per_frame, defer_mlp=False):
         """One block on the fused residual chain.
 
         The block input is x = res + pend + pend_bias (pend/pend_bias may be None); that add is fused into
@@ -254,7 +282,7 @@ class SpaceTimeBlock(nn.Module):
             x = res
             h3 = ops.layer_norm(x, n3.weight, n3.bias, n3.eps)
         else:
-            x, h3 = ops.add_layer_norm(res, pend, pend_bias, n3.weight, n3.bias, n3.eps, keep_sum=True)
+            x, h3 = _close_pending(res, pend, pend_bias, n3)
         ta, sa = self.timeattn, self.attn
         o_t = ta.core(h3, 'time', frames, n_per_frame)
         if hasattr(self, 'alpha_timeattn'):
@@ -265,14 +293,23 @@ class SpaceTimeBlock(nn.Module):
         # norm1's backward kernel instead of a separate add
         x, h1 = ops.add_layer_norm_pass(x, y_t, b_t, n1.weight, n1.bias, n1.eps)
         o_s = sa.core(h1, 'space', frames, n_per_frame)
-        if self._dropping():
-            y_s, b_s = self.drop_path(ops.linear(o_s, sa.proj.weight, sa.proj.bias)), None
+        fused = None
+        if not self._dropping():
+            # ops.RESIDUAL_EPILOGUE: x1 leaves the projection GEMM (residual epilogue), norm2 reads it
+            fused = ops.linear_residual_layer_norm(o_s, sa.proj.weight, sa.proj.bias, x, n2.weight, n2.bias, n2.eps)
+        if fused is not None:
+            x1, h2 = fused
         else:
-            y_s, b_s = ops.linear(o_s, sa.proj.weight), sa.proj.bias
-        x1, h2 = ops.add_layer_norm(x, y_s, b_s, n2.weight, n2.bias, n2.eps, keep_sum=True)
+            if self._dropping():
+                y_s, b_s = self.drop_path(ops.linear(o_s, sa.proj.weight, sa.proj.bias)), None
+            else:
+                y_s, b_s = ops.linear(o_s, sa.proj.weight), sa.proj.bias
+            x1, h2 = ops.add_layer_norm(x, y_s, b_s, n2.weight, n2.bias, n2.eps, keep_sum=True)
         if self._dropping():
             return x1, self.drop_path(self.mlp(h2)), None
         if self.mlp._fused_act:
+            if defer_mlp and ops.RESIDUAL_EPILOGUE and h2.dtype == torch.bfloat16 and x1.dtype == torch.bfloat16:
+                return x1, PendingMlp(h2, self.mlp), self.mlp.fc2.bias      # enqueued by the next consumer (_close_pending)
             return x1, ops.mlp_quickgelu(h2, self.mlp.fc1.weight, self.mlp.fc1.bias, self.mlp.fc2.weight), self.mlp.fc2.bias
         return x1, ops.linear(self.mlp.hidden(h2), self.mlp.fc2.weight), self.mlp.fc2.bias
 
@@ -289,7 +326,7 @@ class SpaceTimeBlock(nn.Module):
             x = res
             h3 = ops.layer_norm(x, n3.weight, n3.bias, n3.eps)
         else:
-            x, h3 = ops.add_layer_norm(res, pend, pend_bias, n3.weight, n3.bias, n3.eps, keep_sum=True)
+            x, h3 = _close_pending(res, pend, pend_bias, n3)
         ta, sa = self.timeattn, self.attn
         o_t = ta.core(h3, 'time', frames, n_per_frame)
         if hasattr(self, 'alpha_timeattn'):
@@ -435,7 +472,12 @@ class SpaceTimeTransformer(nn.Module):
             fn = blk.chain_cls if (cls_at_last and i == last and CLS_ONLY_LAST_BLOCK and not blk._dropping()
                                    and blk.attention_style == 'frozen-in-time') else blk.chain
             if use_checkpoint:
+                if isinstance(pend, PendingMlp):
+                    pend = pend.materialize()
                 res, pend, pend_b = checkpoint.checkpoint(fn, res, pend, pend_b, frames, n, use_reentrant=False)
+            elif fn == blk.chain and i != last:
+                # the block's MLP may wait for the next block's norm3 (ops.RESIDUAL_EPILOGUE: residual add in fc2's epilogue)
+                res, pend, pend_b = fn(res, pend, pend_b, frames, n, defer_mlp=True)
             else:
                 res, pend, pend_b = fn(res, pend, pend_b, frames, n)
             if hook is not None and i == hook[0]:

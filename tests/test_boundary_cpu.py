@@ -363,7 +363,7 @@ def test_gemm_tile_counter_reply_register_is_untouched_in_isa(tmp_path):
     also be free of scratch spills (a spill reload is a vector-memory operation inside the counted vmcnt schedule)."""
     lines = _isa(tmp_path, 'gemm_tn_mfma')
     bodies = list(_kernel_bodies(lines, 'gemm_tn_kernel'))
-    assert len(bodies) == 6                 # 3 epilogues x {bf16, f32-class (Lb1E: float32 results)}
+    assert len(bodies) == 8                 # 4 epilogues x {bf16, f32-class (Lb1E: float32 results)}
     for name, body in bodies:
         assert 'ILi2E' in name or 'Lb1E' in name or not any('scratch_' in l for l in body), \
             'VGPR spills in the bias / fc1 GEMM kernels'

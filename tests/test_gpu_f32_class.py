@@ -95,6 +95,10 @@ def test_linear_tn_f32_class_vs_float64(M, N, K):
     assert torch.equal(u, y)
     aref = ref * torch.sigmoid(1.702 * ref)
     assert ((a.double() - aref).abs() <= 1.5 * bound + 2e-6 * aref.abs()).all()
+    # residual epilogue: + aux_in (float32), same bound
+    rin = torch.randn(M, N, generator=g).to(DEV)
+    yr = ops.linear_tn_raw(x3, w3, b, C.EPI_BIAS_RESIDUAL, aux_in=rin, f32=True)
+    assert ((yr.double() - (ref + rin.double())).abs() <= bound + 2e-7 * (ref + rin.double()).abs()).all()
     # backward epilogue: acc * quickgelu'(aux_in), column sums
     uin = torch.randn(M, N, generator=g).to(DEV)
     dy, cs = ops.linear_tn_raw(x3, w3, None, C.EPI_QUICKGELU_BWD, aux_in=uin, f32=True)

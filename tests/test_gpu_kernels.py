@@ -436,3 +436,102 @@ def test_kernel_argument_errors_are_loud():
     yh = ops.layer_norm(xh, torch.ones(128, device=DEV), torch.zeros(128, device=DEV), 1e-5)
     assert yh.dtype == torch.bfloat16
     torch.testing.assert_close(yh.float(), torch.nn.functional.layer_norm(xh.float(), (128,)), atol=3e-2, rtol=3e-2)
+
+
+def test_block_with_residual_epilogue_equals_the_composed_block():
+    """ops.RESIDUAL_EPILOGUE: the space attention's projection adds the residual in its GEMM epilogue and norm2 reads the
+    sum (ops._LinearResidualLayerNormFn) -- same block output and parameter / input gradients as projection + fused
+    add + LayerNorm, to one bf16 rounding of x1 (the epilogue adds in f32 BEFORE rounding; the composed form rounds the
+    projection's output first)."""
+    from lavila.models.openai_model import QuickGELU
+    from lavila.models.timesformer import SpaceTimeBlock
+    from lavila_amd import ops
+    torch.manual_seed(2)
+    Fr, N, D, H, B = 4, 196, 768, 12, 2
+    blk = SpaceTimeBlock(D, H, qkv_bias=True, act_layer=QuickGELU, time_init='rand').to(DEV)
+    with torch.no_grad():
+        for p in blk.parameters():
+            if p.ndim > 1:
+                p.normal_(0, 0.02)
+            else:
+                p.add_(torch.randn_like(p) * 0.05)
+    x = torch.randn(B, 1 + Fr * N, D, device=DEV, dtype=torch.bfloat16)
+    gout = torch.randn(B, 1 + Fr * N, D, device=DEV, dtype=torch.bfloat16)
+    res = []
+    shipped = ops.RESIDUAL_EPILOGUE
+    for flag in (False, True):
+        ops.RESIDUAL_EPILOGUE = flag
+        try:
+            for p in blk.parameters():
+                p.grad = None
+            xi = x.clone().requires_grad_(True)
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                x1, y, b = blk.chain(xi, None, None, Fr, N)
+                out = x1 + y + b.to(y.dtype)
+            out.backward(gout)
+            res.append((out.detach().float(), xi.grad.float(), {n: p.grad.float().clone() for n, p in blk.named_parameters()}))
+        finally:
+            ops.RESIDUAL_EPILOGUE = shipped
+    (o0, g0, p0), (o1, g1, p1) = res
+    assert not torch.equal(o0, o1)          # the flag took the other path (x1 is rounded once instead of twice)
+    torch.testing.assert_close(o1, o0, atol=6e-2, rtol=2e-2)
+    assert ((o1 - o0).norm() / o0.norm()).item() < 4e-3
+    assert ((g1 - g0).norm() / g0.norm()).item() < 1e-2
+    for n in p0:
+        d = (p1[n] - p0[n]).norm().item()
+        assert d <= 1e-2 * p0[n].norm().item() + 1e-6, (n, d, p0[n].norm().item())
+
+
+def test_tower_with_residual_epilogues_equals_the_composed_tower():
+    """ops.RESIDUAL_EPILOGUE through a 3-block tower: the space projection's and (deferred to the next block's norm3:
+    timesformer.PendingMlp) the MLP's residual adds ride in GEMM epilogues. Same features and gradients as the composed
+    form up to the roundings that moved (the stream is rounded once per add instead of product-then-sum)."""
+    import contextlib
+    import io
+    import torch.nn as nn
+    from lavila.models.openai_model import QuickGELU
+    from lavila.models.timesformer import SpaceTimeTransformer
+    from lavila_amd import ops
+    torch.manual_seed(5)
+    with contextlib.redirect_stdout(io.StringIO()):
+        vis = SpaceTimeTransformer(img_size=224, patch_size=16, embed_dim=768, depth=3, num_heads=12, num_frames=4,
+                                   time_init='zeros', attention_style='frozen-in-time', ln_pre=True, act_layer=QuickGELU,
+                                   is_tanh_gating=False)
+    vis.head = vis.pre_logits = vis.fc = nn.Identity()
+    vis = vis.to(DEV).train()
+    with torch.no_grad():
+        for n, p in vis.named_parameters():
+            if p.ndim > 1 and 'timeattn' in n:
+                p.normal_(0, 0.02)          # time attention is zero-initialised: make every branch carry signal
+    video = torch.randn(2, 3, 4, 224, 224, device=DEV)
+    res = []
+    shipped = ops.RESIDUAL_EPILOGUE
+    for flag, amp in ((False, False), (False, True), (True, True)):        # float32 reference, composed bf16, epilogue bf16
+        ops.RESIDUAL_EPILOGUE = flag
+        try:
+            for p in vis.parameters():
+                p.grad = None
+            with torch.autocast('cuda', dtype=torch.bfloat16, enabled=amp):
+                feat = vis(video)
+            feat.float().square().sum().backward()
+            res.append((feat.detach().float(), {n: p.grad.float().clone() for n, p in vis.named_parameters()
+                                                if p.grad is not None}))
+        finally:
+            ops.RESIDUAL_EPILOGUE = shipped
+    (fr, pr), (f0, p0), (f1, p1) = res
+    assert set(p0) == set(p1) == set(pr)
+    assert not torch.equal(f0, f1)                                         # the flag took the other path
+
+    def err(f, p):
+        tot = sum(v.norm().item() ** 2 for v in pr.values()) ** 0.5
+        dif = sum((p[n] - pr[n]).norm().item() ** 2 for n in pr) ** 0.5
+        return ((f - fr).norm() / fr.norm()).item(), dif / tot
+
+    (ef0, eg0), (ef1, eg1) = err(f0, p0), err(f1, p1)
+    # two bf16 evaluations of one function differ from each other by about their distance to float32; what the epilogue
+    # form must not be is FURTHER from float32 than the composed form (it rounds the stream once per add instead of twice)
+    assert ef1 < 1.25 * ef0 + 1e-4 and eg1 < 1.25 * eg0 + 1e-4, (ef0, ef1, eg0, eg1)
+    for n in ('blocks.1.mlp.fc2.bias', 'blocks.0.mlp.fc2.bias', 'blocks.1.attn.proj.bias', 'blocks.2.norm3.weight'):
+        d0 = (p0[n] - pr[n]).norm().item() / pr[n].norm().item()
+        d1 = (p1[n] - pr[n]).norm().item() / pr[n].norm().item()
+        assert d1 < 1.5 * d0 + 2e-3, (n, d0, d1)

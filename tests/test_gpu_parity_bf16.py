@@ -117,6 +117,36 @@ def test_linear_tn_exact_on_integer_operands(M, N, K):
     assert torch.equal(y.float().cpu(), want)
 
 
+@pytest.mark.parametrize('M,N,K', [(1000, 768, 768), (70001, 256, 192), (513, 768, 3072), (1, 256, 64)])
+def test_linear_tn_residual_epilogue_exact_on_integer_operands(M, N, K):
+    """LVL_EPI_BIAS_RESIDUAL: y = x W^T + b + res (`x + attn(...)`, `x + mlp(...)`, timesformer.py:183-196) -- exact on small
+    integers (tail tiles, one-row problems included), and with a None bias."""
+    from lavila_amd import _cabi as C
+    from lavila_amd import ops
+    g = torch.Generator().manual_seed(M + 1)
+    x = torch.randint(-2, 3, (M, K), generator=g).float()
+    w = torch.randint(-1, 2, (N, K), generator=g).float() * (torch.rand(N, K, generator=g) < 0.08)
+    b = torch.randint(-8, 9, (N,), generator=g).float()
+    res = torch.randint(-60, 61, (M, N), generator=g).float()
+    want = x @ w.t() + b + res
+    assert want.abs().max() < 256
+    xd, wd, rd = x.to(DEV).bfloat16(), w.to(DEV).bfloat16(), res.to(DEV).bfloat16()
+    y = ops.linear_tn_raw(xd, wd, b.to(DEV), C.EPI_BIAS_RESIDUAL, aux_in=rd)
+    assert torch.equal(y.float().cpu(), want)
+    y0 = ops.linear_tn_raw(xd, wd, None, C.EPI_BIAS_RESIDUAL, aux_in=rd)
+    assert torch.equal(y0.float().cpu(), x @ w.t() + res)
+    # random operands: the sum is rounded ONCE (f32 accumulator + f32 residual), so it is at least as close to the
+    # float64 result as rounding the product first and adding then
+    xr = torch.randn(M, K, generator=g).to(DEV).bfloat16()
+    wr = (torch.randn(N, K, generator=g) * K ** -0.5).to(DEV).bfloat16()
+    rr = (torch.randn(M, N, generator=g) * 4).to(DEV).bfloat16()
+    ref = xr.double() @ wr.double().t() + b.to(DEV).double() + rr.double()
+    got = ops.linear_tn_raw(xr, wr, b.to(DEV), C.EPI_BIAS_RESIDUAL, aux_in=rr).double()
+    two = (ops.linear_tn_raw(xr, wr, b.to(DEV), C.EPI_BIAS).float() + rr.float()).bfloat16().double()
+    assert (got - ref).abs().max() <= 2.0 ** -8 * ref.abs().max() + 1e-6
+    assert (got - ref).norm() <= (two - ref).norm() * 1.0001
+
+
 @pytest.mark.parametrize('M,N,K', [(4096, 768, 768), (20000, 384, 192), (33, 2304, 768)])
 def test_linear_wgrad_exact_on_integer_operands(M, N, K):
     from lavila_amd import ops
