@@ -72,8 +72,14 @@ class ResidualAttentionBlock(nn.Module):
             x, h = ops.add_layer_norm(res, pend, pend_bias, l1.weight, l1.bias, l1.eps, keep_sum=True)
         o = ops.causal_attention(ops.linear(h, at.in_proj_weight, at.in_proj_bias.detach()), at.num_heads,
                                  bias=at.in_proj_bias)
-        y = ops.linear(o, at.out_proj.weight)
-        x1, h2 = ops.add_layer_norm(x, y, at.out_proj.bias, l2.weight, l2.bias, l2.eps, keep_sum=True)
+        # x + attn(ln_1(x)) (openai_model.py:199): the residual add rides in out_proj's GEMM epilogue when the shapes
+        # are the MFMA GEMM's (ops.RESIDUAL_EPILOGUE), ln_2 reads the sum
+        fused = ops.linear_residual_layer_norm(o, at.out_proj.weight, at.out_proj.bias, x, l2.weight, l2.bias, l2.eps)
+        if fused is not None:
+            x1, h2 = fused
+        else:
+            y = ops.linear(o, at.out_proj.weight)
+            x1, h2 = ops.add_layer_norm(x, y, at.out_proj.bias, l2.weight, l2.bias, l2.eps, keep_sum=True)
         return x1, ops.mlp_quickgelu(h2, self.mlp.c_fc.weight, self.mlp.c_fc.bias, self.mlp.c_proj.weight), \
             self.mlp.c_proj.bias
 
