@@ -87,9 +87,10 @@ class KernelTimer:
     def __init__(self):
         self.pairs = []
         self.work = []           # algorithmic work (bytes or flops) of each timed launch
+        self.tags = []           # optional label of each timed launch (which epilogue, ...)
         self.enabled = False
 
-    def wrap(self, fn, select, work=None):
+    def wrap(self, fn, select, work=None, tag=None):
         def timed(*a, **k):
             if not (self.enabled and select(*a, **k)):
                 return fn(*a, **k)
@@ -100,6 +101,7 @@ class KernelTimer:
             self.pairs.append((s, e))
             if work is not None:
                 self.work.append(work(*a, **k))
+            self.tags.append(tag(*a, **k) if tag is not None else None)
             return out
         return timed
 
@@ -447,8 +449,11 @@ def main():
     # the cls-row launches of the last block (one row per clip) are not in the aggregate
     video_rows = args.batch * (1 + args.frames * model.visual.patches_per_frame)
     gtimer = KernelTimer()
+    def _epilogue_of(x, w, bias=None, epilogue=0, *a, **k):
+        return epilogue
     ops.linear_tn_raw = gtimer.wrap(ops.linear_tn_raw, lambda x, w, *a, **k: x.shape[0] == video_rows,
-                                    work=lambda x, w, *a, **k: 2.0 * x.shape[0] * w.shape[0] * w.shape[1])
+                                    work=lambda x, w, *a, **k: 2.0 * x.shape[0] * w.shape[0] * w.shape[1],
+                                    tag=_epilogue_of)
     wtimer = KernelTimer()
     ops.linear_wgrad_raw = wtimer.wrap(ops.linear_wgrad_raw, lambda dy, x, *a, **k: dy.shape[0] == video_rows,
                                        work=lambda dy, x, *a, **k: 2.0 * dy.shape[0] * dy.shape[1] * x.shape[1])
@@ -571,6 +576,21 @@ def main():
                             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
                             'traffic': traffic, 'avg_ms': round(kms, 4), 'launches': len(timer.pairs),
                             'alg_bytes_per_launch': alg_bytes}
+        def _by_epilogue(tm):
+            """The launches that carry the residual epilogue (LVL_EPI_BIAS_RESIDUAL = 3: +1 read of a [rows, N] tensor per
+            launch, the LayerNorm pass it replaces is gone from the step) priced apart from the others."""
+            if not any(t == 3 for t in tm.tags):
+                return {}
+            out = {}
+            for name, want in (('residual_epilogue_launches', True), ('other_launches', False)):
+                idx = [i for i, t in enumerate(tm.tags) if (t == 3) == want]
+                ms = sum(tm.pairs[i][0].elapsed_time(tm.pairs[i][1]) for i in idx)
+                fl = sum(tm.work[i] for i in idx)
+                if idx and ms > 0:
+                    out[name] = {'launches': len(idx), 'avg_ms': round(ms / len(idx), 4),
+                                 'frac': round(fl / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
+            return {'by_epilogue': out}
+
         def mfma_roofline(tm, kernel, tfile):
             if not tm.pairs:
                 return None
@@ -589,7 +609,8 @@ def main():
                     # rates sustains on random bf16 data on this part (power-limited), measured by
                     # tools/probes/mfma_ceiling.hip
                     'measured_loop_ceiling': {'value': 1434.0, 'unit': 'TFLOP/s',
-                                              'source': 'profiles/r02_mfma_ceiling_microbench.txt'}}
+                                              'source': 'profiles/r02_mfma_ceiling_microbench.txt'},
+                    **_by_epilogue(tm)}
         # dominant kernel: the forward / input-gradient GEMM, aggregated over all its launches in the timed region
         roofline = mfma_roofline(gtimer, 'lvl_linear_tn (gemm_tn_kernel<0|1|2>, all video-tower forward and '
                                  'input-gradient GEMMs incl. their fused epilogues)', 'traffic_gemm_tn.json') \
