@@ -612,7 +612,7 @@ def main():
                                               'source': 'profiles/r02_mfma_ceiling_microbench.txt'},
                     **_by_epilogue(tm)}
         # dominant kernel: the forward / input-gradient GEMM, aggregated over all its launches in the timed region
-        roofline = mfma_roofline(gtimer, 'lvl_linear_tn (gemm_tn_kernel<0|1|2>, all video-tower forward and '
+        roofline = mfma_roofline(gtimer, 'lvl_linear_tn (gemm_tn_kernel<0|1|2|3>, all video-tower forward and '
                                  'input-gradient GEMMs incl. their fused epilogues)', 'traffic_gemm_tn.json') \
             or roofline_hbm
         roofline_wgrad = mfma_roofline(wtimer, 'lvl_linear_wgrad (wgrad_kernel<4,2,6,6,false> + its partial-tile '
