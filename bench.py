@@ -116,11 +116,17 @@ class KernelTimer:
 
 def _traffic_file(stem):
     """Newest committed PMC traffic summary of a kernel family (profiles/rNN_<stem>, tools/pmc_bench_traffic.sh)."""
-    for rnd in ('r04', 'r03', 'r02'):
+    for rnd in ('r05', 'r04', 'r03', 'r02'):
         path = os.path.join(ROOT, 'profiles', f'{rnd}_{stem}')
         if os.path.isfile(path):
             return path
-    return os.path.join(ROOT, 'profiles', 'r04_' + stem)
+    return os.path.join(ROOT, 'profiles', 'r05_' + stem)
+
+
+def _traffic_source(path):
+    """`traffic` in a roofline object is NOT measured by this run (PMC counters need their own rocprofv3 passes,
+    tools/pmc_bench_traffic.sh): it is read from the committed summary of those passes, and says so."""
+    return 'committed PMC passes of this command, not this run: ' + os.path.relpath(path, ROOT)
 
 
 def build_model(args, device):
@@ -458,7 +464,7 @@ def main():
     ops.linear_wgrad_raw = wtimer.wrap(ops.linear_wgrad_raw, lambda dy, x, *a, **k: dy.shape[0] == video_rows,
                                        work=lambda dy, x, *a, **k: 2.0 * dy.shape[0] * dy.shape[1] * x.shape[1])
     net = model
-    if world > 1 or force_group:
+    if (world > 1 or force_group) and os.environ.get('LAVILA_BENCH_NO_DDP') != '1':     # NO_DDP: bisecting the wrapper's cost
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev_index], bucket_cap_mb=200,
                                                         gradient_as_bucket_view=True)
     crit = CLIPLoss(use_vissl=True, cache_labels=True, rank=rank, world_size=world)
@@ -574,7 +580,8 @@ def main():
             achieved = alg_bytes / (kms * 1e-3) / 1e9
             roofline_hbm = {'bound': 'hbm', 'kernel': 'lvl_divided_attn_fwd[space]', 'achieved': round(achieved, 1),
                             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
-                            'traffic': traffic, 'avg_ms': round(kms, 4), 'launches': len(timer.pairs),
+                            'traffic': traffic, 'traffic_source': _traffic_source(tfile) if traffic else None,
+                            'avg_ms': round(kms, 4), 'launches': len(timer.pairs),
                             'alg_bytes_per_launch': alg_bytes}
         def _by_epilogue(tm):
             """The launches that carry the residual epilogue (LVL_EPI_BIAS_RESIDUAL = 3: +1 read of a [rows, N] tensor per
@@ -603,6 +610,7 @@ def main():
             ach = tot_fl / (tot_ms * 1e-3) / 1e12
             return {'bound': 'mfma', 'kernel': kernel, 'achieved': round(ach, 1), 'peak': MFMA_PEAK_TFLOPS,
                     'unit': 'TFLOP/s', 'frac': round(ach / MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
+                    'traffic_source': _traffic_source(path) if traffic else None,
                     'avg_ms': round(tot_ms / len(tm.pairs), 4), 'launches': len(tm.pairs),
                     'alg_flops_per_launch': round(tot_fl / len(tm.pairs)), 'traffic_note': note,
                     # not the roofline peak: what an MFMA + fragment-read + barrier + LDS-DMA loop at this kernel's

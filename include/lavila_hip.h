@@ -261,6 +261,15 @@ int lvl_mq_cross_attn_fwd(const void* q, int64_t q_batch_stride, const void* kv,
  * Beyond 128 rows, and for N >= 8192 (lm_head), K % 64 == 0: LDS-staged 64 x 64 / 64 x 128 tiles (whole-line loads, three K
  * blocks in flight). N % 16 == 0 and K % 32 == 0, else LVL_ENOSYS; any M >= 0. */
 int lvl_linear_skinny(const void* x, const void* w, const float* bias, void* y, int M, int N, int K, int act, void* stream);
+/* lvl_linear_skinny_f32c (round 5): the same product for FLOAT32 operands in f32-class mode -- x3 [M, K3] and w3 [N, K3]
+ * are the bf16 term images of the float32 x [M, K] / w [N, K] (K3 = 3 K; lvl_split_bf16x3 role 0 for x, role 1 for w:
+ * h|h|l against h|l|h, so one pass over K3 accumulates h.h' + h.l' + l.h'), y [M, N] float32, bias float32, activation on
+ * the unrounded sum. Replaces the float32 `x @ W + b` of the reference's Conv1D / nn.Linear (gpt2_gated.py:184-188,
+ * 383-384,1010; coca.py:78-88) where the widths are not multiples of 256 (lvl_linear_tn's f32-class mode takes those):
+ * the narrator's float32 decoder, its lm_head and the float32 inference Linears of small towers. ~2^-17 relative per
+ * product. N % 16 == 0 and K % 32 == 0, else LVL_ENOSYS. */
+int lvl_linear_skinny_f32c(const void* x3, const void* w3, const float* bias, float* y, int M, int N, int K3, int act,
+                           void* stream);
 /* lvl_linear_skinny_ln: out[M,N] = act(LayerNorm(res + (*gate) * y) . w^T + bias), res_out = bf16(res + (*gate) * y) --
  * lvl_gated_add_layernorm folded into the prologue of the Conv1D that consumes it (q_attn / c_attn / the two c_fc of a
  * GPT2Block, gpt2_gated.py:441-487): a workgroup of lvl_linear_skinny owns whole rows of its input, so it forms the sum,

@@ -57,6 +57,7 @@ SIGNATURES = {
     'lvl_mq_cross_attn_fwd': (_I, [_P, _L, _P, _P, _I, _I, _I, _I, _I, _P]),
     'lvl_qkv_bias_grad': (_I, [_P, _P, _P, _P, _L, _I, _I, _P]),
     'lvl_linear_skinny': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    'lvl_linear_skinny_f32c': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'lvl_linear_skinny_ln': (_I, [_P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'lvl_debug_skinny_variant': (_I, [_I]),
     'lvl_debug_cross_attn_waves': (_I, [_I]),

@@ -34,12 +34,17 @@ def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.hip'))
 
 
-def _digest():
+def _headers():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')) + \
+        [os.path.join(HERE, '..', 'include', 'lavila_hip.h')]
+
+
+def _digest(srcs=None):
+    """Content hash of the sources (file NAMES, not paths: the stamp of one checkout is valid in another)."""
     h = hashlib.sha256()
-    for p in sources() + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')) + \
-            [os.path.join(HERE, '..', 'include', 'lavila_hip.h')]:
+    for p in (sources() if srcs is None else srcs) + _headers():
         with open(p, 'rb') as f:
-            h.update(p.encode() + b'\0' + f.read())
+            h.update(os.path.basename(p).encode() + b'\0' + f.read())
     h.update(repr(sorted(EXTRA_FLAGS.items())).encode())
     return h.hexdigest()
 
@@ -53,14 +58,20 @@ def build(force=False, verbose=True):
     hipcc = _hipcc()
     objs = []
     procs = []
+    stamps = {}
     for src in sources():
         obj = os.path.join(LIBDIR, os.path.basename(src)[:-4] + '.o')
+        objs.append(obj)
+        # per-object stamp: a translation unit is recompiled when it, a header or the flags changed
+        odig, ostamp = _digest([src]), obj + '.stamp'
+        if not force and os.path.exists(obj) and os.path.exists(ostamp) and open(ostamp).read().strip() == odig:
+            continue
+        stamps[ostamp] = odig
         cmd = [hipcc, f'--offload-arch={ARCH}', '-O3', '-std=c++17', '-fPIC', '-fno-gpu-rdc', '-fvisibility=hidden',
                '-Wall', '-Wno-unused-function'] + EXTRA_FLAGS.get(os.path.basename(src), []) + ['-c', src, '-o', obj]
         if verbose:
             print('[lavila_amd.build]', ' '.join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
-        objs.append(obj)
     failed = False
     for src, p in procs:
         out, _ = p.communicate()
@@ -71,6 +82,9 @@ def build(force=False, verbose=True):
             print(f'[lavila_amd.build] FAILED: {src}', file=sys.stderr)
     if failed:
         raise RuntimeError('hipcc failed')
+    for ostamp, odig in stamps.items():
+        with open(ostamp, 'w') as f:
+            f.write(odig)
     cmd = [hipcc, f'--offload-arch={ARCH}', '-shared', '-fPIC', '-o', LIB] + objs
     if verbose:
         print('[lavila_amd.build]', ' '.join(cmd), flush=True)

@@ -55,7 +55,10 @@ __device__ __forceinline__ float sk_act(float v) {
 
 // The 8 partial accumulators of every output block meet in LDS; wave q (and q + 8, ...) finishes block (nb, rb) =
 // (q / RB, q % RB): v[r] = y[row m0 + rb*16 + c][column n0 + nb*16 + g*4 + r] -> + bias, activation, bf16 store.
-template <int NB, int RB, int ACT>
+// F32O (round 5, the f32-class mode): x / w are bf16 TERM IMAGES of float32 operands ([M, 3K] = h|h|l, [N, 3K] = h|l|h, see
+// lvl_split_bf16x3), the contraction over 3K accumulates the three products of the split, and the result leaves as
+// float32 -- 16-byte stores, activation on the unrounded sum.
+template <int NB, int RB, int ACT, bool F32O = false>
 __device__ __forceinline__ void skinny_finish(sk_f32x4 (*part)[NB * RB][64], const sk_f32x4 (&acc)[NB][RB],
                                               const float* __restrict__ bias, uint16_t* __restrict__ y, int M, int N,
                                               int n0, int m0) {
@@ -83,14 +86,19 @@ __device__ __forceinline__ void skinny_finish(sk_f32x4 (*part)[NB * RB][64], con
         const float4 b = *reinterpret_cast<const float4*>(bias + n);
         v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
       }
-      const uint2 o = make_uint2(f32x2_to_bf16x2(sk_act<ACT>(v[0]), sk_act<ACT>(v[1])),
-                                 f32x2_to_bf16x2(sk_act<ACT>(v[2]), sk_act<ACT>(v[3])));
-      *reinterpret_cast<uint2*>(y + (int64_t)row * N + n) = o;
+      if (F32O) {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(y) + (int64_t)row * N + n) =
+            make_float4(sk_act<ACT>(v[0]), sk_act<ACT>(v[1]), sk_act<ACT>(v[2]), sk_act<ACT>(v[3]));
+      } else {
+        const uint2 o = make_uint2(f32x2_to_bf16x2(sk_act<ACT>(v[0]), sk_act<ACT>(v[1])),
+                                   f32x2_to_bf16x2(sk_act<ACT>(v[2]), sk_act<ACT>(v[3])));
+        *reinterpret_cast<uint2*>(y + (int64_t)row * N + n) = o;
+      }
     }
   }
 }
 
-template <int NB, int RB, int ACT, bool PAIR, int CH = 6>
+template <int NB, int RB, int ACT, bool PAIR, int CH = 6, bool F32O = false>
 __global__ __launch_bounds__(512) void skinny_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ w,
                                                      const float* __restrict__ bias, uint16_t* __restrict__ y, int M,
                                                      int N, int K, int nstrips, int nmb) {
@@ -143,7 +151,7 @@ __global__ __launch_bounds__(512) void skinny_kernel(const uint16_t* __restrict_
       }
     }
   }
-  skinny_finish<NB, RB, ACT>(part, acc, bias, y, M, N, n0, m0);
+  skinny_finish<NB, RB, ACT, F32O>(part, acc, bias, y, M, N, n0, m0);
 }
 
 // ---- the same GEMM with the residual add and the LayerNorm of its INPUT in the prologue ---------------------------------
@@ -317,7 +325,7 @@ __global__ __launch_bounds__(512) void skinny_ln_kernel(const uint16_t* __restri
   skinny_finish<NB, RB, ACT>(part, acc, bias, out, M, N, n0, m0);
 }
 
-template <int NB, int RB, bool PAIR, int CHV = 6>
+template <int NB, int RB, bool PAIR, int CHV = 6, bool F32O = false>
 int launch_skinny(const void* x, const void* w, const float* bias, void* y, int M, int N, int K, int act,
                   hipStream_t st) {
   const int nstrips = N / (16 * NB), nmb = (M + 16 * RB - 1) / (16 * RB);
@@ -326,9 +334,9 @@ int launch_skinny(const void* x, const void* w, const float* bias, void* y, int 
 #define LVL_SK(A)                                                                                                 \
   do {                                                                                                            \
     if (lds > 64 * 1024)                                                                                          \
-      if (int rc = lvl_allow_lds<skinny_kernel<NB, RB, A, PAIR, CHV>>()) return rc;                               \
-    hipLaunchKernelGGL((skinny_kernel<NB, RB, A, PAIR, CHV>), grid, dim3(64 * WAVES), lds, st, (const uint16_t*)x, \
-                       (const uint16_t*)w, bias, (uint16_t*)y, M, N, K, nstrips, nmb);                            \
+      if (int rc = lvl_allow_lds<skinny_kernel<NB, RB, A, PAIR, CHV, F32O>>()) return rc;                         \
+    hipLaunchKernelGGL((skinny_kernel<NB, RB, A, PAIR, CHV, F32O>), grid, dim3(64 * WAVES), lds, st,              \
+                       (const uint16_t*)x, (const uint16_t*)w, bias, (uint16_t*)y, M, N, K, nstrips, nmb);        \
   } while (0)
   if (act == LVL_ACT_GELU_NEW) LVL_SK(LVL_ACT_GELU_NEW);
   else if (act == LVL_ACT_SQRELU) LVL_SK(LVL_ACT_SQRELU);
@@ -613,6 +621,31 @@ extern "C" int lvl_linear_skinny(const void* x, const void* w, const float* bias
   }
   if (N >= 2048 && N % 64 == 0) return launch_skinny<4, 2, false>(x, w, bias, y, M, N, K, act, st);
   return launch_skinny<1, 1, true>(x, w, bias, y, M, N, K, act, st);
+}
+
+// f32-class mode (round 5): the narrator's float32 decoder and every float32 inference Linear whose widths the
+// 256-column-panel kernel does not tile (reference: x @ W + b in float32, gpt2_gated.py:184-188,383-384). x3 [M, K3] and
+// w3 [N, K3] are the bf16 term images of the float32 operands (K3 = 3 K, lvl_split_bf16x3 roles 0 / 1), y is float32.
+// The strip kernels only (fragments straight from memory, float32 partial sums through LDS): this is the parity
+// configuration, the shapes are small or the call is rare.
+extern "C" int lvl_linear_skinny_f32c(const void* x3, const void* w3, const float* bias, float* y, int M, int N, int K3,
+                                      int act, void* stream) {
+  LVL_REQUIRE(M == 0 || (x3 && w3 && y), "linear_skinny_f32c: null pointer");
+  LVL_REQUIRE(M >= 0 && N > 0 && K3 > 0, "linear_skinny_f32c: bad shape M=%d N=%d K3=%d", M, N, K3);
+  LVL_REQUIRE(act == -1 || act == LVL_ACT_GELU_NEW || act == LVL_ACT_SQRELU, "linear_skinny_f32c: unknown activation %d", act);
+  if (N % 16 != 0 || K3 % 96 != 0 || (int64_t)(N / 16 + 8) * ((M + 15) / 16) >= (1ll << 31))
+    return lvl_fail(LVL_ENOSYS, "linear_skinny_f32c: needs N %% 16 == 0 and K3 = 3 K with K %% 32 == 0 (N=%d K3=%d)", N, K3);
+  LVL_REQUIRE(lvl_aligned16(x3) && lvl_aligned16(w3) && lvl_aligned16(y) && lvl_aligned16(bias),
+              "linear_skinny_f32c: pointers must be 16-byte aligned");
+  if (M == 0) return LVL_OK;
+  const hipStream_t st = (hipStream_t)stream;
+  if (M > 128) {
+    if (N % 64 == 0) return launch_skinny<4, 4, false, 3, true>(x3, w3, bias, y, M, N, K3, act, st);
+    return N % 32 == 0 ? launch_skinny<2, 4, false, 6, true>(x3, w3, bias, y, M, N, K3, act, st)
+                       : launch_skinny<1, 2, false, 6, true>(x3, w3, bias, y, M, N, K3, act, st);
+  }
+  if (N >= 2048 && N % 64 == 0) return launch_skinny<4, 2, false, 6, true>(x3, w3, bias, y, M, N, K3, act, st);
+  return launch_skinny<1, 1, true, 6, true>(x3, w3, bias, y, M, N, K3, act, st);
 }
 
 extern "C" int lvl_debug_skinny_variant(int v) {

@@ -193,7 +193,9 @@ class _Pack:
     """Inference image of the decoder's parameters for one compute dtype: bf16 -> every Conv1D as a contiguous [out, in]
     bf16 matrix (what lvl_linear_tn streams), the token table padded to a multiple of 256 rows (it doubles as the
     lm_head operand when tied), position table in bf16, biases / LayerNorm parameters / tanh(alpha) gates in f32.
-    f32 -> references to the masters (library GEMM, x @ W)."""
+    f32 (the parity configuration; round 5) -> every Conv1D as the bf16 TERM IMAGES [out, 3 in] of its float32 [out, in]
+    matrix (ops.split3 role 1): the products run on the own MFMA kernels in f32-class mode (lvl_linear_skinny_f32c, or
+    lvl_linear_tn where it tiles), ~2^-17 relative per product -- no library GEMM on the decoder's float32 path either."""
 
     def __init__(self, model, dtype):
         tr = model.transformer
@@ -206,11 +208,15 @@ class _Pack:
         self.eps = float(tr.ln_f.eps)
         lowp = dtype == torch.bfloat16
         f32 = lambda p: p.detach().to(torch.float32).contiguous()
+        # float32: every Conv1D width is a multiple of the model width (a multiple of 64): the f32-class kernels take them all
+        self.own = (not lowp) and ops.F32_MFMA and self.D % 32 == 0
 
         def conv(m):      # -> (matrix, bias f32, out, in)
             w = m.weight.detach()
             if lowp:
                 return (w.t().to(torch.bfloat16).contiguous(), f32(m.bias), w.shape[1], w.shape[0])
+            if self.own:
+                return (ops.split3(f32(w.t()), 1), f32(m.bias), w.shape[1], w.shape[0])
             return (f32(w), f32(m.bias), w.shape[1], w.shape[0])
 
         def ln(m):
@@ -237,9 +243,11 @@ class _Pack:
             self.wte = _pad_rows(wte.to(torch.bfloat16), 256)
             self.wpe = tr.wpe.weight.detach().to(torch.bfloat16).contiguous()
             self.head = self.wte if tied else _pad_rows(head.to(torch.bfloat16), 256)
+            self.head3 = None
         else:
             self.wte, self.wpe = f32(wte), f32(tr.wpe.weight)
             self.head = self.wte if tied else f32(head)
+            self.head3 = ops.split3(_pad_rows(self.head, 256), 1) if self.own else None
 
     # ---- primitives --------------------------------------------------------------------------------
     def _skinny(self, x2, w, b, act):
@@ -260,7 +268,9 @@ class _Pack:
                 ops.warn_once(('conv1d', n_out, n_in), f'decoder Conv1D [{n_in}->{n_out}] on {rows} rows runs on the '
                               'library GEMM (lvl_linear_tn needs out % 256 == 0 and in % 64 == 0)')
                 y = F.linear(x2, w, b.to(torch.bfloat16))
-        else:
+        elif self.own:                                  # float32 decoder, term images: own kernels in f32-class mode
+            return ops.linear_f32_rows(x2, w, b, act)
+        else:                                           # LAVILA_F32_MFMA=0 (A/B): library GEMM against the [in, out] master
             y = torch.addmm(b, x2, w)
         return y if act is None else self.act(y, act)
 
@@ -275,6 +285,8 @@ class _Pack:
                 return self._skinny(h2, self.head, None, None)[:, :self.vocab]
             if ops._tn_ok(h2.shape[0], self.head.shape[0], self.D):
                 return ops.linear_tn_raw(h2, self.head, None, C.EPI_BIAS)[:, :self.vocab]
+        elif self.head3 is not None:                    # float32: f32-class mode of the own kernels
+            return ops.linear_f32_rows(h2, self.head3)[:, :self.vocab]
         return F.linear(h2, self.head)[:, :self.vocab]
 
     def embed(self, ids, L, pos_dev=None):

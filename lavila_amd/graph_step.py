@@ -65,6 +65,13 @@ class GraphedTrainStep:
         self.amp_dtype = amp_dtype
         self.kwargs = dict(use_checkpoint=False, norm_embed=True)
         self.kwargs.update(forward_kwargs or {})
+        if self.kwargs.get('use_checkpoint'):
+            # torch.utils.checkpoint saves / restores the RNG state around the recomputation (preserve_rng_state): a
+            # device-state read that is illegal while the stream is capturing. With every activation of the
+            # bench configuration resident the graphed step has no use for checkpointing.
+            raise NotImplementedError('GraphedTrainStep: use_checkpoint=True is not capturable (activation checkpointing '
+                                      'reads the RNG state during the capture); run checkpointed models with the eager loop')
+        self._packed = [m for m in self.model.modules() if hasattr(m, 'invalidate_packed_weights')]
         self.text_bucket = max(1, int(text_bucket))
         self.clamp = clamp_logit_scale
         self.loss_key = loss_key
@@ -127,7 +134,18 @@ class GraphedTrainStep:
             entry = self._graphs[L] = self._capture(L)
         entry[0].replay()
         self.replays += 1
+        self._parameters_changed()
         return entry[1]
+
+    def _parameters_changed(self):
+        """A replay updates the parameters on the device behind Python's back: no version counter moves and the optimizer's
+        post-step hook (which bumps ops' weight-copy generation in an eager step) only ran at capture time. Without this an
+        evaluation between two replays would hit ops.weight_copies' cache and run every Linear on the bf16 copies of an
+        EARLIER parameter state while LayerNorms / embeddings are current (ADVICE r4). One integer increment per replay;
+        packed decoder images (narrator models) are dropped the same way."""
+        ops.invalidate_weight_cache()
+        for m in self._packed:
+            m.invalidate_packed_weights()
 
     # ---- the iteration itself -------------------------------------------------------------------------------------
     def _iteration(self, L):

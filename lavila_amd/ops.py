@@ -437,6 +437,32 @@ def linear_skinny_raw(x, w, bias=None, act=None):
     return y
 
 
+def linear_skinny_f32c_raw(x3, w3, bias=None, act=None):
+    """One lvl_linear_skinny_f32c call: y[M,N] float32 = act(x . w^T + bias) for float32 x [M,K], w [N,K] handed over as
+    their bf16 term images x3 = split3(x, 0) [M,3K], w3 = split3(w, 1) [N,3K] (f32-class mode, ~2^-17 per product)."""
+    C.require_device(x3, w3, bias)
+    M, K3 = x3.shape
+    y = torch.empty(M, w3.shape[0], dtype=torch.float32, device=x3.device)
+    C.check(C.lib().lvl_linear_skinny_f32c(C.ptr(x3), C.ptr(w3), C.ptr(bias), C.ptr(y), M, w3.shape[0], K3,
+                                           -1 if act is None else act, C.stream_ptr()), 'lvl_linear_skinny_f32c')
+    return y
+
+
+def linear_f32_rows(x2, w3, bias=None, act=None):
+    """float32 x2 [M,K] against the term images w3 [N,3K] of a float32 weight: the 256-column-panel kernel's f32-class mode
+    where it tiles and there are enough rows to fill it, lvl_linear_skinny_f32c otherwise (N % 16 == 0, K % 32 == 0).
+    Inference helper (no autograd): the narrator's float32 decoder and ops.linear under no_grad."""
+    M, K = x2.shape
+    N = w3.shape[0]
+    x3 = split3(x2 if x2.is_contiguous() else x2.contiguous(), 0)
+    if M > 256 and _tn_ok(M, N, 3 * K):
+        y = linear_tn_raw(x3, w3, bias, C.EPI_BIAS, f32=True)
+        if act is not None:
+            C.check(C.lib().lvl_act_inplace(C.ptr(y), y.numel(), act, C.dtype_code(y), C.stream_ptr()), 'lvl_act_inplace')
+        return y
+    return linear_skinny_f32c_raw(x3, w3, bias, act)
+
+
 def project(x, proj):
     """x @ proj for the [width, embed_dim] projection parameters (models.py:146,161): the Linear kernels against the
     transposed view (its gradient flows back to `proj` through the view)."""
@@ -457,6 +483,16 @@ def linear(x, weight, bias=None):
             x2 = x.reshape(-1, n_in)
             return linear_skinny_raw(x2 if x2.is_contiguous() else x2.contiguous(), weight_copies(weight)[0],
                                      _f32(bias)).reshape(*x.shape[:-1], n_out)
+    if F32_MFMA and x.dtype == torch.float32 and x.is_cuda and weight.dtype == torch.float32 and not (
+            torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or
+                                         (bias is not None and bias.requires_grad))):
+        # float32 inference on widths the panel kernel does not tile (small towers, the narrator's pooling projections,
+        # round 5): the strip kernel's f32-class mode instead of the library GEMM
+        rows, n_in, n_out = x.numel() // x.shape[-1], x.shape[-1], weight.shape[0]
+        if (rows > 0 and not _tn_ok_f32(rows, n_out, n_in) and n_out % 16 == 0 and n_in % 32 == 0
+                and rows * max(3 * n_in, n_out) * 4 < (1 << 31)):
+            return linear_f32_rows(x.reshape(-1, n_in), weight_copies(weight, f32=True)[0],
+                                   _f32(bias)).reshape(*x.shape[:-1], n_out)
     return _LinearFn.apply(x, weight, bias)
 
 

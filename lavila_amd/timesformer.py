@@ -150,7 +150,16 @@ class VideoPatchEmbed(nn.Module):
             # lvl_linear_wgrad; the weight gradient comes back through the pad's slice
             pad = 64 - k % 64
             patches = F.pad(patches, (0, pad))
-            w2 = F.pad(w2, (0, pad))
+            if torch.is_grad_enabled() and w.requires_grad:
+                w2 = F.pad(w2, (0, pad))        # part of the autograd graph: one pad (and one cast) per training step
+            else:
+                # inference: ONE padded copy per parameter state, so that ops.weight_copies' cache (keyed on the tensor it
+                # is handed) hits on every later call instead of re-padding and re-casting per forward
+                key = (w._version, w.data_ptr(), ops._generation, w.dtype)
+                hit = _padded_patch_weights.get(self.proj)
+                if hit is None or hit[0] != key:
+                    hit = _padded_patch_weights[self.proj] = (key, F.pad(w2.detach(), (0, pad)))
+                w2 = hit[1]
         return ops.linear(patches, w2, self.proj.bias)
 
     def forward(self, x):
@@ -160,6 +169,9 @@ class VideoPatchEmbed(nn.Module):
         tok = _like_caller(self.tokens_from_btchw(x), x, self.proj.weight)
         gh, gw = H // self.patch_size[0], W // self.patch_size[1]
         return tok.reshape(B * Fr, gh, gw, -1).permute(0, 3, 1, 2)
+
+
+_padded_patch_weights = __import__('weakref').WeakKeyDictionary()     # Conv2d module -> (state key, zero-padded [D, 640] weight)
 
 
 class VarAttention(nn.Module):

@@ -45,6 +45,24 @@ CONFIGS = {
                           t_heads=12, t_layers=12, vocab=49408, embed=256, batch=2, gated=False),
     'tsfl14_336_b2': dict(img=336, patch=14, frames=2, dim=1024, depth=24, heads=16, t_width=768,
                           t_heads=12, t_layers=12, vocab=49408, embed=256, batch=2, gated=False),
+    # round 5: "spread" fixtures (oracle.synthetic_batch / procedural_weights with spread=True: samples that do NOT
+    # collapse onto one embedding, ragged captions, attention scores of a few units) with every 1-D gradient of six
+    # blocks + row slices of their weight gradients stored in full (fixture format 2, compared per tensor on the
+    # tensor's own scale). BASELINE configs[1]'s clip shape, both TSF-L/14 shapes, and the true 16-frame shapes of
+    # configs[2] (TSF-B/16, 16 x 224^2: T = 3137) and configs[3] (TSF-L/14 at 336, 16 frames: T = 9217).
+    'config2_tsfb_224_b8_spread': dict(img=224, patch=16, frames=4, dim=768, depth=12, heads=12, t_width=512,
+                                       t_heads=8, t_layers=12, vocab=49408, embed=256, batch=8, gated=False, spread=True),
+    'tsfl14_224_b2_spread': dict(img=224, patch=14, frames=4, dim=1024, depth=24, heads=16, t_width=768,
+                                 t_heads=12, t_layers=12, vocab=49408, embed=256, batch=2, gated=False, spread=True),
+    'tsfl14_336_b2_spread': dict(img=336, patch=14, frames=2, dim=1024, depth=24, heads=16, t_width=768,
+                                 t_heads=12, t_layers=12, vocab=49408, embed=256, batch=2, gated=False, spread=True),
+    'tsfb_224_f16_b2_spread': dict(img=224, patch=16, frames=16, dim=768, depth=12, heads=12, t_width=512,
+                                   t_heads=8, t_layers=12, vocab=49408, embed=256, batch=2, gated=False, spread=True),
+    # 9217 tokens per clip: the reference runs with use_checkpoint=True (its own activation checkpointing of the two
+    # attention modules, timesformer.py:175-187: same values, ~1/2 of the 60+ GB the plain backward would keep)
+    'tsfl14_336_f16_b2_spread': dict(img=336, patch=14, frames=16, dim=1024, depth=24, heads=16, t_width=768,
+                                     t_heads=12, t_layers=12, vocab=49408, embed=256, batch=2, gated=False, spread=True,
+                                     checkpoint=True),
 }
 
 
@@ -65,7 +83,7 @@ def build_reference_model(ref, c):
 
 
 def synthetic_inputs(c, seed=1234):
-    video, tokens = O.synthetic_batch(c['batch'], c['frames'], c['img'], seed=seed)
+    video, tokens = O.synthetic_batch(c['batch'], c['frames'], c['img'], seed=seed, spread=c.get('spread', False))
     if c['vocab'] < 49408:      # tiny vocab: remap ids, keep EOT as the maximum id
         tokens = tokens.clone()
         body = tokens[:, 1:31] % (c['vocab'] - 2) + 1
@@ -75,11 +93,35 @@ def synthetic_inputs(c, seed=1234):
     return video, tokens
 
 
+def select_gradients(grads, c):
+    """Format-2 fixtures: which gradients are stored in full. Every tensor outside the block stacks that is small
+    (cls / positional / temporal embeddings, the LayerNorms, logit_scale), every 1-D gradient (LayerNorm gains and
+    biases, Linear biases) of three video blocks and three text blocks (first, middle, last), and -- `slices` -- four
+    rows (0, 1, a middle one, the last) of every weight gradient of those blocks and of the two projections, the patch
+    embedding and the token table's used rows: direction information for the big tensors at a few KB each."""
+    vb = sorted({0, c['depth'] // 2, c['depth'] - 1})
+    tb = sorted({0, c['t_layers'] // 2, c['t_layers'] - 1})
+    pref = [f'visual.blocks.{i}.' for i in vb] + [f'transformer.resblocks.{i}.' for i in tb]
+    full, slices = {}, {}
+    for k, g in grads.items():
+        in_blocks = k.startswith('visual.blocks.') or k.startswith('transformer.resblocks.')
+        chosen = any(k.startswith(p) for p in pref)
+        if g.ndim <= 1 or k in ('visual.cls_token', 'visual.temporal_embed'):
+            if not in_blocks or chosen:
+                full[k] = g.clone()
+        elif chosen or k in ('image_projection', 'text_projection', 'visual.patch_embed.proj.weight', 'visual.pos_embed',
+                             'positional_embedding'):
+            g2 = g.reshape(-1, g.shape[-1]) if k in ('visual.pos_embed', 'positional_embedding') else g.reshape(g.shape[0], -1)
+            rows = sorted({0, 1, g2.shape[0] // 2, g2.shape[0] - 1})
+            slices[k] = (rows, g2[rows].clone())
+    return full, slices
+
+
 def run_model_golden(ref, name, c):
     torch.manual_seed(0)
     model = build_reference_model(ref, c)
     shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
-    weights = O.procedural_weights(shapes, seed=7)
+    weights = O.procedural_weights(shapes, seed=7, spread=c.get('spread', False))
     model.load_state_dict(weights, strict=True)
     model.train()
     video, tokens = synthetic_inputs(c)
@@ -96,7 +138,7 @@ def run_model_golden(ref, name, c):
           model.visual.blocks[-1].register_forward_hook(hook('blk_last_out')),
           model.transformer.resblocks[0].register_forward_hook(hook('txt_blk0_out_LND'))]
 
-    out = model(video, tokens, norm_embed=True)
+    out = model(video, tokens, use_checkpoint=bool(c.get('checkpoint', False)), norm_embed=True)
     crit = ref.loss.CLIPLoss(use_vissl=False, cache_labels=True, rank=0, world_size=1)
     ld = crit(out)
     ld['loss'].backward()
@@ -120,6 +162,20 @@ def run_model_golden(ref, name, c):
         with torch.no_grad():       # narrator-style call: all tokens, not only the cls row (timesformer.py:377-381)
             fixture['features_all_tokens'] = model.visual.forward_features(
                 video.permute(0, 2, 1, 3, 4).contiguous(), use_checkpoint=False, cls_at_last=False).detach().clone()
+    elif c.get('spread'):      # fixture format 2 (round 5)
+        fixture['format'] = 2
+        fixture['grad_norms'] = {k: g.norm().item() for k, g in grads.items()}
+        fixture['grad_absmax'] = {k: g.abs().max().item() for k, g in grads.items()}
+        full, slices = select_gradients(grads, c)
+        fixture['grads'] = full
+        fixture['grad_slices'] = slices
+        fixture['acts'] = {k: v[:, :3].clone() if v.ndim == 3 else v for k, v in acts.items()}
+        e_i, e_t = out['image_embed'].detach(), out['text_embed'].detach()
+        off = ~torch.eye(e_i.shape[0], dtype=torch.bool)
+        fixture['sample_cosines'] = {'image_mean': (e_i @ e_i.T)[off].mean().item(), 'image_max': (e_i @ e_i.T)[off].max().item(),
+                                     'text_mean': (e_t @ e_t.T)[off].mean().item(), 'text_max': (e_t @ e_t.T)[off].max().item()}
+        print(f'[golden] {name}: {len(full)} full gradients, {len(slices)} weight-gradient slices, sample cosines '
+              f'{fixture["sample_cosines"]}, pred {fixture["pred"].tolist()}')
     else:      # full-size model: keep per-parameter grad norms + a few full small grads
         fixture['grad_norms'] = {k: g.norm().item() for k, g in grads.items()}
         keep = ['logit_scale', 'visual.cls_token', 'visual.temporal_embed', 'visual.norm.weight',

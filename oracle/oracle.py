@@ -471,23 +471,51 @@ def ssl_synthetic_inputs(G: int, E: int, seed: int):
 # deterministic synthetic weights / inputs shared by the golden generator, tests and bench
 # --------------------------------------------------------------------------------------
 def synthetic_batch(batch: int, frames: int, img: int, seed: int = 1234, real_tokens: int = 32,
-                    ctx: int = 77):
+                    ctx: int = 77, spread: bool = False):
     """randn frames [B,3,F,H,W]; tokens [B,77] = SOT, 30 random ids, EOT at 31,
-    zero padding (EOT=49407 is the max id so argmax finds it, tokenizer.py:147-162)."""
+    zero padding (EOT=49407 is the max id so argmax finds it, tokenizer.py:147-162).
+
+    spread=True (round 5 fixtures): the same noise plus what makes the SAMPLES differ after the towers' pooling -- iid
+    noise alone averages out over a clip's patches and every clip lands on the same embedding (cosines 0.99 between
+    samples, one argmax for the whole batch): a per-(sample, channel, frame) offset, a smooth per-sample pattern, and
+    captions of ragged lengths (EOT anywhere in 5..real_tokens, so the EOT row, the causal trim and the padding differ
+    per sample)."""
     g = torch.Generator().manual_seed(seed)
     video = torch.randn(batch, 3, frames, img, img, generator=g)
     tokens = torch.zeros(batch, ctx, dtype=torch.long)
     tokens[:, 0] = 49406
-    tokens[:, 1:real_tokens - 1] = torch.randint(1, 49406, (batch, real_tokens - 2), generator=g)
-    tokens[:, real_tokens - 1] = 49407
+    if not spread:
+        tokens[:, 1:real_tokens - 1] = torch.randint(1, 49406, (batch, real_tokens - 2), generator=g)
+        tokens[:, real_tokens - 1] = 49407
+        return video, tokens
+    video = video + 2.0 * torch.randn(batch, 3, frames, 1, 1, generator=g)
+    yy = torch.linspace(0, 1, img).view(1, 1, 1, -1, 1)
+    xx = torch.linspace(0, 1, img).view(1, 1, 1, 1, -1)
+    k = (torch.arange(batch).float() % 7 + 1).view(batch, 1, 1, 1, 1)
+    ph = torch.rand(batch, 3, 1, 1, 1, generator=g) * 6.2831853
+    video = video + 2.0 * torch.sin(k * 6.2831853 * xx + ph) * torch.cos((8 - k) * 3.1415927 * yy + ph.roll(1, 1))
+    lens = torch.randint(5, real_tokens + 1, (batch,), generator=g)
+    lens[0] = real_tokens                           # the longest caption is in the batch
+    for b in range(batch):
+        n = int(lens[b])
+        tokens[b, 1:n - 1] = torch.randint(1, 49406, (n - 2,), generator=g)
+        tokens[b, n - 1] = 49407
     return video, tokens
 
 
-def procedural_weights(shapes: Dict[str, tuple], seed: int = 0) -> Dict[str, Tensor]:
+def procedural_weights(shapes: Dict[str, tuple], seed: int = 0, spread: bool = False) -> Dict[str, Tensor]:
     """Deterministic weights from (name -> shape): every tensor gets its own CPU generator seeded by
     (seed, index in sorted-name order) so that the golden script, the tests and bench.py can rebuild
     identical weights without shipping them. Scales are chosen so the temporal path is live
-    (the shipped zeros-init makes temporal attention a no-op)."""
+    (the shipped zeros-init makes temporal attention a no-op).
+
+    spread=True (round 5 fixtures): token embeddings of std 0.1, 3x larger in_proj weights in the text tower and 2x
+    larger qkv weights in the video tower -- attention scores of a few units instead of near-uniform attention, which in
+    a randomly initialised deep transformer collapses every sample onto one embedding. With
+    synthetic_batch(spread=True): mean cosine between samples 0.4 (video) / 0.2 (text) instead of 0.99, distinct argmax
+    per row, and a softmax that is no longer flat. (3x in the video tower is past the edge of chaos: float32 and float64
+    evaluations of the SAME network then differ by 5e-2 -- nothing can be pinned to 1e-3 there; at 2x they agree to
+    1e-5.)"""
     out = {}
     for idx, name in enumerate(sorted(shapes)):
         shape = tuple(shapes[name])
@@ -508,11 +536,15 @@ def procedural_weights(shapes: Dict[str, tuple], seed: int = 0) -> Dict[str, Ten
         elif leaf in ('cls_token', 'pos_embed', 'temporal_embed', 'positional_embedding'):
             t = 0.02 * torch.randn(shape, generator=g)
         elif name == 'token_embedding.weight':
-            t = 0.02 * torch.randn(shape, generator=g)
+            t = (0.1 if spread else 0.02) * torch.randn(shape, generator=g)
         elif 'patch_embed' in name:
             t = torch.randn(shape, generator=g) * (shape[1] * shape[2] * shape[3]) ** -0.5
         else:                                               # Linear / in_proj weights [out, in]
             t = torch.randn(shape, generator=g) * shape[-1] ** -0.5
+            if spread and leaf == 'in_proj_weight':
+                t = t * 3.0
+            elif spread and name.endswith('qkv.weight'):
+                t = t * 2.0
         out[name] = t
     return out
 

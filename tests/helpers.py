@@ -35,6 +35,42 @@ def build_model(c, quiet=True):
     return model
 
 
+def fixture_weights(fx):
+    """The procedural weights a model fixture was generated with (format-2 / "spread" fixtures: oracle.procedural_weights
+    with spread=True)."""
+    return O.procedural_weights(fx['shapes'], seed=fx['weight_seed'], spread=fx['config'].get('spread', False))
+
+
+def check_fixture_gradients(fx, grads, rtol, norm_rtol, tag=''):
+    """Parameter gradients against a model fixture. Format 1 (rounds 1-4): ten full tensors at atol 1e-4 + every norm.
+    Format 2 (round 5): every stored full gradient (1-D tensors of six blocks, the embeddings, the LayerNorms: 69 tensors)
+    and four rows of every stored weight gradient, each on ITS OWN scale -- max |got - ref| <= rtol * max |ref| and relative
+    L2 <= rtol -- so that a gradient of magnitude 1e-4 is checked as tightly as one of magnitude 1, and a direction error
+    cannot hide behind a matching norm; plus every parameter's norm. Returns the worst relative distance seen."""
+    worst = 0.0
+    if fx.get('format', 1) == 2:
+        items = [(k, grads[k].detach().float().cpu(), g) for k, g in fx['grads'].items()]
+        for k, (rows, g) in fx['grad_slices'].items():
+            got = grads[k].detach().float().cpu()
+            got = got.reshape(-1, got.shape[-1]) if k in ('visual.pos_embed', 'positional_embedding') else got.reshape(got.shape[0], -1)
+            items.append((k + '[rows]', got[rows], g))
+        assert len(items) >= 40
+        for k, got, ref in items:
+            scale = ref.abs().max().item()
+            assert scale > 0, f'{tag}{k}: the reference gradient is identically zero -- nothing is checked'
+            d = (got - ref).abs().max().item() / scale
+            l2 = ((got - ref).norm() / ref.norm()).item()
+            worst = max(worst, d, l2)
+            assert d <= rtol and l2 <= rtol, f'{tag}{k}: max |d| / max |ref| = {d:.2e}, relative L2 = {l2:.2e} (bar {rtol:.0e})'
+    else:
+        for k, gref in fx['grads'].items():
+            torch.testing.assert_close(grads[k].detach().float().cpu(), gref, atol=1e-4, rtol=rtol, msg=lambda m: f'{tag}{k}: {m}')
+    for k, n in fx.get('grad_norms', {}).items():
+        got = grads[k].detach().float().norm().item()
+        assert abs(got - n) <= norm_rtol * n + 1e-6, (tag, k, got, n)
+    return worst
+
+
 def oracle_slab_forward(img_all, txt_all, scale, B, row0):
     """CPU restatement of lvl_clip_loss_fwd (stats [2,B,4], argmax [2,B]) from oracle.clip_logits."""
     li = O.clip_logits(img_all.float(), txt_all.float(), scale.float())          # [G,G] logits_per_image

@@ -13,37 +13,13 @@ import pytest
 import torch
 
 from conftest import load_golden
-from helpers import build_model
+from helpers import build_model, check_fixture_gradients, fixture_weights
+from lavila_amd.guards import forbid_library_gemm
 from oracle import oracle as O
 from oracle.gen_golden import synthetic_inputs
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
-
-
-@contextlib.contextmanager
-def forbid_library_gemm():
-    """Any GEMM-shaped torch entry point raises: what runs inside the block runs on lavila_amd's own kernels."""
-    import torch.nn.functional as F
-    names = [(F, 'linear'), (F, 'bilinear'), (F, 'scaled_dot_product_attention'), (F, 'multi_head_attention_forward'),
-             (F, 'conv2d'), (F, 'conv3d'),
-             (torch, 'matmul'), (torch, 'mm'), (torch, 'bmm'), (torch, 'addmm'), (torch, 'baddbmm'), (torch, 'einsum'),
-             (torch, 'mv'), (torch, 'addmv'), (torch, 'tensordot'), (torch, 'inner'), (torch, 'conv2d'),
-             (torch.Tensor, 'matmul'), (torch.Tensor, '__matmul__'), (torch.Tensor, '__rmatmul__'), (torch.Tensor, 'mm'),
-             (torch.Tensor, 'bmm'), (torch.Tensor, 'addmm'), (torch.Tensor, 'mv')]
-    saved = [(o, n, getattr(o, n)) for o, n in names]
-
-    def make(n):
-        def boom(*a, **k):
-            raise AssertionError(f'library GEMM entry point torch...{n} called on the lavila_amd path')
-        return boom
-    for o, n, _ in saved:
-        setattr(o, n, make(n))
-    try:
-        yield
-    finally:
-        for o, n, f in saved:
-            setattr(o, n, f)
 
 
 def _bf(x):
@@ -174,7 +150,11 @@ def test_linear_and_mlp_autograd_float32_no_library_gemm():
         assert rel < 3e-5, (name, rel)
 
 
-@pytest.mark.parametrize('name', ['config1_tsfb_112', 'config2_tsfb_224_b8', 'tsfl14_224_b2', 'tsfl14_336_b2'])
+FULL_SIZE = ['config1_tsfb_112', 'config2_tsfb_224_b8_spread', 'tsfl14_224_b2_spread', 'tsfl14_336_b2_spread',
+             'tsfb_224_f16_b2_spread', 'tsfl14_336_f16_b2_spread']
+
+
+@pytest.mark.parametrize('name', FULL_SIZE)
 def test_full_size_models_run_on_own_kernels_within_1e3(name):
     """The reference's committed outputs at north_star's 1e-3 -- forward, loss, backward of every parameter tensor -- for
     BASELINE configs[0] (CLIP_OPENAI_TIMESFORMER_BASE shape, 2 x 112^2, batch 4), configs[1]'s clip shape (TSF-B/16,
@@ -182,14 +162,21 @@ def test_full_size_models_run_on_own_kernels_within_1e3(name):
     CLIP_OPENAI_TIMESFORMER_LARGE / _LARGE_336PX shapes (forward AND backward) -- with every library GEMM
     entry point of torch forbidden: the Linear layers, the patch-embedding contraction and the two projections run on
     lvl_linear_tn / lvl_linear_wgrad in f32-class mode, and no attention call may land on the shape-generic kernels:
-    space / causal attention run on the split-operand MFMA kernels, time attention on the float32 register-tiled ones."""
+    space / causal attention run on the split-operand MFMA kernels, time attention on the float32 register-tiled ones.
+
+    Round 5: all but config 1 are format-2 "spread" fixtures (oracle.synthetic_batch / procedural_weights spread=True:
+    samples that do not collapse onto one embedding -- mean cosine between samples 0.2-0.45 instead of 0.99 --, ragged
+    captions, attention scores of a few units) with 69 full gradients + 35 weight-gradient row slices, each compared on
+    its own scale (helpers.check_fixture_gradients), and the TRUE 16-frame shapes are in: BASELINE configs[2]'s clip
+    (TSF-B/16, 16 x 224^2: 3137 tokens, MFMA time attention at F = 16 with 196 locations) and configs[3]'s
+    (TSF-L/14 at 336, 16 frames: 9217 tokens, 577-key streaming space kernels + F = 16 time attention at 576 locations)."""
     from lavila.models.loss import CLIPLoss
     from lavila_amd import ops
     assert ops.F32_MFMA
     fx = load_golden(f'model_{name}.pt')
     c = fx['config']
     model = build_model(c)
-    model.load_state_dict(O.procedural_weights(fx['shapes'], seed=fx['weight_seed']), strict=True)
+    model.load_state_dict(fixture_weights(fx), strict=True)
     model.to(DEV).train()
     video, tokens = synthetic_inputs(c, seed=fx['input_seed'])
     video, tokens = video.to(DEV), tokens.to(DEV)
@@ -213,16 +200,12 @@ def test_full_size_models_run_on_own_kernels_within_1e3(name):
     assert torch.equal(dbg['labels'].cpu(), fx['labels']) and torch.equal(dbg['pred'][0].cpu(), fx['pred'])
     torch.testing.assert_close(ld['loss'].detach().cpu(), fx['loss'], **tol)
     grads = {k: p.grad for k, p in model.named_parameters()}
-    for k, gref in fx['grads'].items():
-        torch.testing.assert_close(grads[k].cpu(), gref, atol=1e-4, rtol=5e-3, msg=lambda m: f'{k}: {m}')
-    for k, n in fx.get('grad_norms', {}).items():
-        got = grads[k].norm().item()
-        assert abs(got - n) <= 5e-3 * n + 1e-6, (k, got, n)
+    worst = check_fixture_gradients(fx, grads, rtol=2e-3 if fx.get('format', 1) == 2 else 5e-3, norm_rtol=5e-3, tag=name + ' ')
     # how far inside the bar: report the measured distances (shown with -s / in the failure message)
     d_logit = (dbg['logits'][0].cpu() - fx['logits_per_image']).abs().max().item()
     d_embed = (out['image_embed'].cpu() - fx['image_embed']).abs().max().item()
     print(f'[f32-class {name}] max |d logit| = {d_logit:.2e}, max |d image_embed| = {d_embed:.2e}, '
-          f'|d loss| = {abs(ld["loss"].item() - fx["loss"].item()):.2e}')
+          f'|d loss| = {abs(ld["loss"].item() - fx["loss"].item()):.2e}, worst gradient tensor (own scale) = {worst:.2e}')
     assert d_logit < 1e-3
 
 

@@ -128,3 +128,43 @@ def test_replay_is_host_light_and_refuses_what_it_cannot_replay():
     step(video.to(DEV), tokens.to(DEV), text_len=21)
     assert step.buckets == [24, 77]
 
+
+
+def test_evaluation_between_replays_sees_the_updated_weights():
+    """a replay moves the parameters on the device without touching a version counter; ops.weight_copies
+    caches the GEMMs' bf16 weight copies across no-grad forwards. replay -> eval -> replay -> eval: every eval must run
+    on the CURRENT weights -- compared against the same forward with the cache bypassed (lvl_cast_transpose on the live
+    parameters) -- and the two evals must differ (the step in between really moved the weights)."""
+    from lavila.models.loss import CLIPLoss
+    from lavila_amd import ops
+    from lavila_amd.graph_step import GraphedTrainStep
+    torch.manual_seed(6)
+    model = build_model(CFG).to(DEV).train()
+    crit = CLIPLoss(use_vissl=True, cache_labels=True, rank=0, world_size=1)
+    opt = torch.optim.AdamW(model.parameters(), lr=5e-3, fused=True, capturable=True)
+    step = GraphedTrainStep(model, crit, opt, (CFG['batch'], 3, CFG['frames'], CFG['img'], CFG['img']), (CFG['batch'], 77), DEV)
+    with pytest.raises(NotImplementedError, match='use_checkpoint'):
+        GraphedTrainStep(model, crit, opt, (1,), (1, 77), DEV, forward_kwargs=dict(use_checkpoint=True))
+    video, tokens = _batches()[0]
+    v, t = video.to(DEV), tokens.to(DEV)
+
+    def evaluate():
+        model.eval()
+        with torch.no_grad(), torch.autocast('cuda', dtype=torch.bfloat16):
+            cached = model(v, t, norm_embed=True)['image_embed'].float().clone()
+            ops.invalidate_weight_cache()                      # ground truth: copies re-cast from the live parameters
+            fresh = model(v, t, norm_embed=True)['image_embed'].float().clone()
+        model.train()
+        return cached, fresh
+
+    step(video, tokens)                      # eager first call
+    step(video, tokens)                      # capture + first replay
+    evals = []
+    for _ in range(3):
+        step(video, tokens)                  # replay: parameters move on the device
+        torch.cuda.synchronize()
+        cached, fresh = evaluate()
+        assert torch.equal(cached, fresh), 'an eval between replays ran on stale bf16 weight copies'
+        evals.append(fresh)
+    assert step.replays >= 3
+    assert not torch.equal(evals[0], evals[1]) and not torch.equal(evals[1], evals[2])

@@ -11,6 +11,7 @@ import torch.nn.functional as F
 
 from conftest import load_golden
 from oracle import oracle as O
+from lavila_amd.guards import forbid_library_gemm
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
@@ -348,7 +349,7 @@ def test_narrator_forward_matches_reference_f32(variant):
     """VCLM_HF.forward (narrator.py:89-104): teacher-forced logits [B, V, L-1] and labels, float32 within 1e-3 of the
     reference's CPU output (logits of a few units)."""
     m, c, d, v, video, tok = _golden_model(variant)
-    with torch.no_grad():
+    with torch.no_grad(), forbid_library_gemm():        # round 5: the float32 decoder runs on the own f32-class kernels
         out = m(video, v['text'].to(DEV))
     assert out['text_tokens_logits'].dtype == torch.float32
     assert torch.equal(out['labels'].cpu(), v['labels'])
@@ -364,7 +365,7 @@ def test_narrator_generate_matches_reference_f32(variant, graph):
     m, c, d, v, video, tok = _golden_model(variant)
     no_eos = types.SimpleNamespace(bos_token_id=v['bos'], eos_token_id=-1, pad_token_id=v['pad'])
     text = v['text'].to(DEV)
-    with torch.no_grad():
+    with torch.no_grad(), forbid_library_gemm():
         img = m.encode_image(video)
         torch.testing.assert_close(img.cpu(), v['image_tokens'], atol=1e-3, rtol=1e-3)
         runs = [
@@ -392,7 +393,7 @@ def test_narrator_beam_search_matches_reference_f32(variant, graph):
     re-gathered with the beams after every step (eagerly and under hipGraph replay) and on the recompute schedule."""
     m, c, d, v, video, tok = _golden_model(variant)
     bx = load_golden('narrator_beam.pt')['variants'][variant]
-    with torch.no_grad():
+    with torch.no_grad(), forbid_library_gemm():
         img = m.encode_image(video)
         for name, run in bx['runs'].items():
             tk = types.SimpleNamespace(bos_token_id=bx['bos'], eos_token_id=run['eos'], pad_token_id=bx['pad'])

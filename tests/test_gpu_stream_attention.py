@@ -194,3 +194,64 @@ def test_fp8_qk_path_matches_its_emulation(B, Fr, N, H):
     rel_g = ((grad.double() - qo.grad).norm() / qo.grad.norm()).item()
     assert rel_o < 0.15 and rel_g < 0.25, (rel_o, rel_g)
     assert torch.isfinite(grad).all()
+
+
+def test_fp8_qk_end_to_end_bound_on_tsfl14_336():
+    """BASELINE configs[3] end to end: CLIP_OPENAI_TIMESFORMER_LARGE_336PX's shape (24 blocks of width 1024, 577-key space
+    groups) under bf16 autocast, forward + CLIPLoss + backward, once on the bf16 streaming kernels and once with the fp8
+    QK^T policy on, both against the REFERENCE's float32 outputs (tests/golden/model_tsfl14_336_b2_spread.pt: samples
+    spread, attention scores of a few units -- the regime where e4m3 scores matter).
+
+    Expected size. bf16 alone: eps * sqrt(r L) = 1.1e-3 * sqrt(10 * 24) = 1.7e-2 on the embeddings, x (1..2) (derivation in
+    test_gpu_parity_bf16.py). e4m3 keeps 3 mantissa bits (RMS relative error 2^-4 / sqrt(3) = 3.6e-2 per element of q and
+    k): a score sum_64 q_i k_i moves by 3.6e-2 * sqrt(2 / 64) |q||k| = 6.4e-3 |q||k|, i.e. ~0.1 in the softmax argument
+    where |q||k| / 8 ~ 2-3 -- a ~10 % relative perturbation of every attention weight, averaged over 577 keys and over
+    16 heads per block: a few 1e-2 per block on the branch, sqrt(24) blocks. So: the fp8 path is expected at 2-4x the
+    bf16 path's distance; the bars below are what a training run can absorb (embeddings within 0.15 relative L2 of the
+    float32 reference, loss within 5e-2, gradient norms within 25 %), and the fp8 path may not be more than 6x further from
+    the reference than bf16 is. The measured distances are printed (pytest -s)."""
+    from conftest import load_golden
+    from helpers import build_model, fixture_weights
+    from oracle.gen_golden import synthetic_inputs
+    from lavila.models.loss import CLIPLoss
+    fx = load_golden('model_tsfl14_336_b2_spread.pt')
+    c = fx['config']
+    video, tokens = synthetic_inputs(c, seed=fx['input_seed'])
+    video, tokens = video.to(DEV), tokens.to(DEV)
+
+    def run(fp8):
+        model = build_model(c)
+        model.load_state_dict(fixture_weights(fx), strict=True)
+        model.to(DEV).train()
+        crit = CLIPLoss(use_vissl=False, cache_labels=True, rank=0, world_size=1)
+        with (fp8_qk() if fp8 else contextlib.nullcontext()):
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                out = model(video, tokens, norm_embed=True)
+                ld = crit(out)
+            ld['loss'].backward()
+            torch.cuda.synchronize()
+        e_i = ((out['image_embed'].float().cpu() - fx['image_embed']).norm() / fx['image_embed'].norm()).item()
+        d_loss = abs(ld['loss'].item() - fx['loss'].item())
+        ratios = []
+        for k, p in model.named_parameters():
+            n = fx['grad_norms'][k]
+            if n > 1e-7 * max(fx['grad_norms'].values()):
+                ratios.append(p.grad.float().norm().item() / n)
+        ratios = torch.tensor(ratios)
+        dirs = []
+        for k, gref in fx['grads'].items():
+            if gref.norm() > 0:
+                g = dict(model.named_parameters())[k].grad.float().cpu()
+                dirs.append(((g - gref).norm() / gref.norm()).item())
+        assert all(torch.isfinite(p.grad).all() for p in model.parameters())
+        return dict(embed=e_i, loss=d_loss, norm_dev=(ratios - 1).abs().median().item(),
+                    norm_worst=(ratios - 1).abs().max().item(), grad_rel_median=float(torch.tensor(dirs).median()),
+                    pred=crit.debug_slabs(out)['pred'][0].cpu())
+
+    bf16, fp8 = run(False), run(True)
+    print(f'[fp8 end to end, TSF-L/14@336] vs the float32 reference -- bf16: {bf16}; fp8 QK^T: {fp8}')
+    assert fp8['embed'] != bf16['embed'], 'the fp8 switch had no effect on the model'
+    for r in (bf16, fp8):
+        assert r['embed'] < 0.15 and r['loss'] < 5e-2 and r['norm_dev'] < 0.25, r
+    assert bf16['embed'] < 5e-2 and bf16['grad_rel_median'] < 0.1, bf16
+    assert fp8['embed'] <= 6 * bf16['embed'] + 1e-2 and fp8['grad_rel_median'] <= 6 * bf16['grad_rel_median'] + 2e-2, (bf16, fp8)

@@ -6,14 +6,17 @@ import torch
 from oracle import oracle as O
 from oracle.gen_golden import synthetic_inputs
 from conftest import load_golden
+from helpers import check_fixture_gradients, fixture_weights
 
 import os
 
-MODELS = ['tiny_p16', 'tiny_p14_gated', 'tiny_f16', 'config1_tsfb_112', 'config2_tsfb_224_b8']
-# the TSF-L/14 fixtures (24 blocks of width 1024) take a few minutes of CPU each: checked on request
-# (LAVILA_SLOW_ORACLE=1; done once when the fixtures were generated)
+MODELS = ['tiny_p16', 'tiny_p14_gated', 'tiny_f16', 'config1_tsfb_112', 'config2_tsfb_224_b8_spread']
+# the TSF-L/14 and 16-frame fixtures (24 blocks of width 1024; 3137 / 9217 tokens per clip) take minutes of CPU and tens
+# of GB each: checked on request (LAVILA_SLOW_ORACLE=1; done when the fixtures were generated)
 if os.environ.get('LAVILA_SLOW_ORACLE') == '1':
-    MODELS += ['tsfl14_224_b2', 'tsfl14_336_b2']
+    MODELS += ['tsfl14_224_b2_spread', 'tsfl14_336_b2_spread', 'tsfb_224_f16_b2_spread']
+if os.environ.get('LAVILA_SLOW_ORACLE') == '2':
+    MODELS += ['tsfl14_336_f16_b2_spread']
 
 
 @pytest.mark.parametrize('case', range(4))
@@ -35,19 +38,30 @@ def test_var_attention_matches_reference(case, mode):
 def test_full_model_matches_reference(name):
     fx = load_golden(f'model_{name}.pt')
     c = fx['config']
-    w = {k: v.requires_grad_(v.is_floating_point())
-         for k, v in O.procedural_weights(fx['shapes'], seed=fx['weight_seed']).items()}
+    # 9217 tokens per clip x 24 blocks: the oracle's plain backward would keep ~80 GB -- forward pins only (the backward
+    # of that shape is pinned on the GPU against the reference's gradients, tests/test_gpu_f32_class.py)
+    fwd_only = bool(c.get('checkpoint'))
+    w = {k: v.requires_grad_(v.is_floating_point() and not fwd_only) for k, v in fixture_weights(fx).items()}
     video, tokens = synthetic_inputs(c, seed=fx['input_seed'])
-    out = O.clip_forward(video, tokens, w, c['heads'], c['t_heads'], norm_embed=True)
-    torch.testing.assert_close(out['image_embed'], fx['image_embed'], atol=1e-5, rtol=1e-4)
-    torch.testing.assert_close(out['text_embed'], fx['text_embed'], atol=1e-5, rtol=1e-4)
+    with torch.set_grad_enabled(not fwd_only):
+        out = O.clip_forward(video, tokens, w, c['heads'], c['t_heads'], norm_embed=True)
+    # format-2 ("spread") fixtures: attention scores of a few units amplify float32 round-off ~3x (two float32
+    # evaluation orders of the same network: 1.1e-5 on a text embedding entry)
+    ea = 3e-5 if fx.get('format', 1) == 2 else 1e-5
+    torch.testing.assert_close(out['image_embed'], fx['image_embed'], atol=ea, rtol=1e-4)
+    torch.testing.assert_close(out['text_embed'], fx['text_embed'], atol=ea, rtol=1e-4)
     ld = O.clip_loss(out['image_embed'], out['text_embed'], out['logit_scale'])
-    torch.testing.assert_close(ld['logits_per_image'], fx['logits_per_image'], atol=1e-4, rtol=1e-4)
+    torch.testing.assert_close(ld['logits_per_image'], fx['logits_per_image'], atol=1e-4 * ea / 1e-5, rtol=1e-4)
     torch.testing.assert_close(ld['loss'], fx['loss'], atol=1e-5, rtol=1e-5)
     assert torch.equal(ld['labels'], fx['labels'])          # int64, bit-exact
     assert torch.equal(ld['pred'], fx['pred'])
     torch.testing.assert_close(ld['clip_acc'], fx['clip_acc'])
+    if fwd_only:
+        return
     ld['loss'].backward()
+    if fx.get('format', 1) == 2:
+        check_fixture_gradients(fx, {k: v.grad for k, v in w.items() if v.grad is not None}, rtol=1e-3, norm_rtol=2e-3)
+        return
     for k, g in fx['grads'].items():
         torch.testing.assert_close(w[k].grad, g, atol=2e-5, rtol=2e-3, msg=lambda m: f'{k}: {m}')
     if 'grad_norms' in fx:

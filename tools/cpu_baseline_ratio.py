@@ -18,7 +18,7 @@ from oracle.ref_import import load_reference  # noqa: E402
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 threads = int(sys.argv[2]) if len(sys.argv) > 2 else min(32, os.cpu_count() or 1)
 torch.set_num_threads(threads)
-c = dict(CONFIGS['config2_tsfb_224_b8'], batch=batch)
+c = dict(CONFIGS['config2_tsfb_224_b8_spread'], batch=batch)
 ref = load_reference()
 torch.manual_seed(0)
 model = build_reference_model(ref, c)
