@@ -416,7 +416,13 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
         os.environ.setdefault('LAVILA_DYNAMIC_TILES', '1')
-        dist.init_process_group('nccl', rank=0, world_size=1, device_id=device)
+        # bisect switches of the group's own cost (profiles/r05_one_rank_group_bisect.txt): another backend, lazy
+        # communicator creation (no device_id: the communicator is only built by the first collective)
+        backend1 = os.environ.get('LAVILA_BENCH_GROUP_BACKEND', 'nccl')
+        if backend1 != 'nccl' or os.environ.get('LAVILA_BENCH_LAZY_INIT') == '1':
+            dist.init_process_group(backend1, rank=0, world_size=1)
+        else:
+            dist.init_process_group('nccl', rank=0, world_size=1, device_id=device)
         rehearsal = 'ONE-RANK RCCL GROUP (LAVILA_BENCH_ONE_RANK_RCCL=1): DDP + RCCL call sites + tile counters on one GPU'
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -466,7 +472,7 @@ def main():
     net = model
     if (world > 1 or force_group) and os.environ.get('LAVILA_BENCH_NO_DDP') != '1':     # NO_DDP: bisecting the wrapper's cost
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev_index], bucket_cap_mb=200,
-                                                        gradient_as_bucket_view=True)
+                                                        gradient_as_bucket_view=os.environ.get('LAVILA_BENCH_NO_BUCKET_VIEW') != '1')
     crit = CLIPLoss(use_vissl=True, cache_labels=True, rank=rank, world_size=world)
     decay = [p for n, p in model.named_parameters() if not (p.ndim < 2 or 'bias' in n or 'ln' in n or 'bn' in n)]
     no_decay = [p for n, p in model.named_parameters() if (p.ndim < 2 or 'bias' in n or 'ln' in n or 'bn' in n)]

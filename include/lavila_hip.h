@@ -371,6 +371,22 @@ int lvl_linear_wgrad(const void* dy, const void* x, float* dw, float* dbias, flo
  * dbias: [3D] f32. Workspace: lvl_workspace_floats("qkv_bias_grad", rows, D). */
 int lvl_qkv_bias_grad(const void* dqkv, const void* dout, float* dbias, float* ws, int64_t rows, int D, int dtype,
                       void* stream);
+/* lvl_divided_attn_bwd_bias (round 5): lvl_divided_attn_bwd AND the qkv-bias gradient of the same Linear in one call,
+ * without the pass over dqkv / dout where the kernels can avoid it (autograd of timesformer.py:96,110-140 wrt qkv.bias):
+ *   q third -- the LDS-resident fused space kernel and the register-tiled time kernels hold the dQ accumulators / dq
+ *              rows in registers: they write per-workgroup column sums (a [B F, D] / [B chunks, D] f32 slab) on the way
+ *              and a two-stage column reduce finishes them; other kernel families reduce the q third of dqkv afterwards;
+ *   k third -- exactly 0;
+ *   v third -- `dout_colsum` [D] f32 when the caller has it (dout is the input gradient dy.W of the projection Linear:
+ *              sum_rows(dout) = sum_rows(dy).W = d(b_proj).W, lvl_vec_mat_f32), else (NULL) reduced here from dout.
+ * dbias [3D] f32; ws as for lvl_divided_attn_bwd; ws2: lvl_divided_attn_bwd_bias_ws(...) floats. */
+int64_t lvl_divided_attn_bwd_bias_ws(int B, int F, int N, int H, int mode, int dtype);
+int lvl_divided_attn_bwd_bias(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* ws,
+                              const float* dout_colsum, float* dbias, float* ws2, int B, int F, int N, int H, int mode,
+                              int dtype, void* stream);
+/* lvl_vec_mat_f32: out[K] = v[N] . W[N, K] (float32, row-major W) -- column sums of a Linear's input gradient from the
+ * column sums of its output gradient: dx = dy W  =>  sum_rows(dx) = sum_rows(dy) W (what feeds `dout_colsum` above). */
+int lvl_vec_mat_f32(const float* v, const float* W, float* out, int N, int K, void* stream);
 
 /* ---- weight staging of a Linear layer under bf16 autocast ----------------------------------------------------
  * dst[n,k] = bf16(src[n,k]), dst_t[k,n] = bf16(src[n,k]): the cast autocast applies to nn.Linear weights

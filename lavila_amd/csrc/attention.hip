@@ -39,10 +39,21 @@ int lvl_text_mfma_bwd(const void* qkv, const void* out, const void* dout, const 
                       int B, int L, int H, int dtype, hipStream_t st);
 bool lvl_space_mfma_bwd_supported(int F, int N, int dtype);
 int lvl_space_mfma_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* ws,
-                       int B, int F, int N, int H, int dtype, hipStream_t st);
+                       float* dq_part, int B, int F, int N, int H, int dtype, hipStream_t st);
+int lvl_space_mfma_bwd_dq_part_rows(int B, int F, int N);
 bool lvl_time_fast_bwd_supported(int F, int N, int H);
 int lvl_time_fast_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* ws,
-                      int B, int F, int N, int H, int dtype, hipStream_t st);
+                      float* dq_part, int B, int F, int N, int H, int dtype, hipStream_t st);
+int lvl_time_fast_bwd_dq_part_rows(int B, int F, int N, int H);
+int lvl_colsum_mid_rows();
+int lvl_launch_column_reduce(const float* part, int nparts, int width, int seg, float* mid, float* out0, float* out1,
+                             float* out2, hipStream_t st);
+int lvl_launch_column_reduce_tail(const float* part, int nparts, int width, int seg, float* mid, float* out0, float* out1,
+                                  float* out2, float* zero_dst, const float* copy_src, float* copy_dst, int tail_n,
+                                  hipStream_t st);
+int lvl_qkv_bias_sources(const void* dqkv, const void* dout, float* dbias, float* ws, int64_t rows, int D, int dtype,
+                         bool zero_k, const float* v_src, hipStream_t st);
+int64_t lvl_qkv_bias_ws_floats(int D);
 int lvl_time_fast_fwd(const void* qkv, void* out, float* lse, float* ws, int B, int F, int N, int H, int dtype,
                       hipStream_t st);
 
@@ -97,22 +108,94 @@ extern "C" int lvl_divided_attn_fwd(const void* qkv, void* out, float* lse, floa
   return lvl_generic_divided_fwd(qkv, out, lse, B, F, N, H, mode, dtype, (hipStream_t)stream, true, true);
 }
 
+// which backward kernel family a call lands on, and how many rows of dq column-sum partials it can emit on the way
+// (0: no rider in that family -- the bias gradient's q third is then reduced from dqkv afterwards)
+enum { BWD_STREAM, BWD_SPACE_MFMA, BWD_TIME_MFMA, BWD_TIME_FAST, BWD_GENERIC };
+static int bwd_family(int B, int F, int N, int H, int mode, int dtype, int* part_rows) {
+  *part_rows = 0;
+  if (fast_dtype(dtype) && mode == LVL_ATTN_SPACE && F <= 64 && lvl_space_stream_wanted(F, N, dtype)) return BWD_STREAM;
+  if (fast_dtype(dtype) && mode == LVL_ATTN_SPACE && lvl_space_mfma_bwd_supported(F, N, dtype)) {
+    *part_rows = lvl_space_mfma_bwd_dq_part_rows(B, F, N);
+    return BWD_SPACE_MFMA;
+  }
+  if (dtype == LVL_BF16 && mode == LVL_ATTN_TIME && time_use_mfma(F, N, H)) return BWD_TIME_MFMA;
+  if (fast_dtype(dtype) && mode == LVL_ATTN_TIME && lvl_time_fast_bwd_supported(F, N, H)) {
+    *part_rows = lvl_time_fast_bwd_dq_part_rows(B, F, N, H);
+    return BWD_TIME_FAST;
+  }
+  return BWD_GENERIC;
+}
+
+static int divided_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* ws,
+                       float* dq_part, int B, int F, int N, int H, int mode, int dtype, hipStream_t st) {
+  int part_rows;
+  switch (bwd_family(B, F, N, H, mode, dtype, &part_rows)) {
+    case BWD_STREAM: return lvl_space_stream_bwd(qkv, out, dout, lse, dqkv, ws, B, F, N, H, dtype, st);
+    case BWD_SPACE_MFMA: return lvl_space_mfma_bwd(qkv, out, dout, lse, dqkv, ws, dq_part, B, F, N, H, dtype, st);
+    case BWD_TIME_MFMA: return lvl_time_mfma_bwd(qkv, out, dout, lse, dqkv, ws, B, F, N, H, st);
+    case BWD_TIME_FAST: return lvl_time_fast_bwd(qkv, out, dout, lse, dqkv, ws, dq_part, B, F, N, H, dtype, st);
+    default: break;
+  }
+  g_generic_calls.fetch_add(1, std::memory_order_relaxed);
+  return lvl_generic_divided_bwd(qkv, out, dout, lse, dqkv, ws, B, F, N, H, mode, dtype, st);
+}
+
 extern "C" int lvl_divided_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
                                     float* ws, int B, int F, int N, int H, int mode, int dtype, void* stream) {
   if (int rc = check_divided("divided_attn_bwd", qkv, out, B, F, N, H, mode, dtype)) return rc;
   LVL_REQUIRE(dout && lse && dqkv && ws, "divided_attn_bwd: null pointer");
   LVL_REQUIRE(lvl_aligned16(dout) && lvl_aligned16(dqkv), "divided_attn_bwd: pointers must be 16-byte aligned");
   if (B == 0) return LVL_OK;
-  if (fast_dtype(dtype) && mode == LVL_ATTN_SPACE && F <= 64 && lvl_space_stream_wanted(F, N, dtype))
-    return lvl_space_stream_bwd(qkv, out, dout, lse, dqkv, ws, B, F, N, H, dtype, (hipStream_t)stream);
-  if (fast_dtype(dtype) && mode == LVL_ATTN_SPACE && lvl_space_mfma_bwd_supported(F, N, dtype))
-    return lvl_space_mfma_bwd(qkv, out, dout, lse, dqkv, ws, B, F, N, H, dtype, (hipStream_t)stream);
-  if (dtype == LVL_BF16 && mode == LVL_ATTN_TIME && time_use_mfma(F, N, H))
-    return lvl_time_mfma_bwd(qkv, out, dout, lse, dqkv, ws, B, F, N, H, (hipStream_t)stream);
-  if (fast_dtype(dtype) && mode == LVL_ATTN_TIME && lvl_time_fast_bwd_supported(F, N, H))
-    return lvl_time_fast_bwd(qkv, out, dout, lse, dqkv, ws, B, F, N, H, dtype, (hipStream_t)stream);
-  g_generic_calls.fetch_add(1, std::memory_order_relaxed);
-  return lvl_generic_divided_bwd(qkv, out, dout, lse, dqkv, ws, B, F, N, H, mode, dtype, (hipStream_t)stream);
+  return divided_bwd(qkv, out, dout, lse, dqkv, ws, nullptr, B, F, N, H, mode, dtype, (hipStream_t)stream);
+}
+
+// ---- backward + the gradient of the qkv Linear's bias in one call (round 5) ---------------------------------------------
+// d(bias) [3D] = column sums of dqkv over all B*T rows. Thirds:
+//   k: exactly 0 (the scores do not change when one vector is added to every key of a sample);
+//   v: column sums of dout (every softmax row sums to 1) -- handed over by the caller as `dout_colsum` when it already has
+//      them (dout = dy . W_proj of the projection Linear, so sum_rows(dout) = sum_rows(dy) . W_proj = d(b_proj) . W_proj: a
+//      vector-matrix product instead of a pass over dout, lvl_vec_mat_f32), else reduced here from dout;
+//   q: partial column sums written by the backward kernel itself where the family has the rider (the LDS-resident fused
+//      space kernel, the register-tiled time kernels: the dQ accumulators / dq rows are in registers there), else a pass
+//      over the q third of dqkv.
+// ws2: lvl_divided_attn_bwd_bias_ws floats.
+extern "C" int64_t lvl_divided_attn_bwd_bias_ws(int B, int F, int N, int H, int mode, int dtype) {
+  int part_rows = 0;
+  if (B > 0 && F > 0 && N > 0 && H > 0) bwd_family(B, F, N, H, mode, dtype, &part_rows);
+  const int64_t D = (int64_t)H * 64;
+  const int64_t rider = ((int64_t)part_rows + lvl_colsum_mid_rows()) * D;
+  const int64_t pass = lvl_qkv_bias_ws_floats((int)D);
+  return rider > pass ? rider : pass;
+}
+
+extern "C" int lvl_divided_attn_bwd_bias(const void* qkv, const void* out, const void* dout, const float* lse,
+                                         void* dqkv, float* ws, const float* dout_colsum, float* dbias, float* ws2,
+                                         int B, int F, int N, int H, int mode, int dtype, void* stream) {
+  if (int rc = check_divided("divided_attn_bwd_bias", qkv, out, B, F, N, H, mode, dtype)) return rc;
+  LVL_REQUIRE(dout && lse && dqkv && ws && dbias && ws2, "divided_attn_bwd_bias: null pointer");
+  LVL_REQUIRE(lvl_aligned16(dout) && lvl_aligned16(dqkv) && lvl_aligned16(dbias) && lvl_aligned16(ws2) &&
+                  lvl_aligned16(dout_colsum), "divided_attn_bwd_bias: pointers must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int D = H * 64;
+  const int64_t rows = (int64_t)B * (1 + (int64_t)F * N);
+  if (B == 0) {
+    hipError_t e = hipMemsetAsync(dbias, 0, (size_t)3 * D * sizeof(float), st);
+    return e == hipSuccess ? LVL_OK : lvl_fail(LVL_EHIP, "divided_attn_bwd_bias memset: %s", hipGetErrorString(e));
+  }
+  int part_rows;
+  bwd_family(B, F, N, H, mode, dtype, &part_rows);
+  float* dq_part = part_rows > 0 ? ws2 : nullptr;
+  if (int rc = divided_bwd(qkv, out, dout, lse, dqkv, ws, dq_part, B, F, N, H, mode, dtype, st)) return rc;
+  // the zeros of the k third and a ready-made v third ride on the second stage of whichever reduction runs last
+  if (dq_part) {
+    float* v_dst = dbias + 2 * (size_t)D;
+    if (int rc = lvl_launch_column_reduce_tail(dq_part, part_rows, D, D, dq_part + (size_t)part_rows * D, dbias, nullptr,
+                                               nullptr, dbias + D, dout_colsum, dout_colsum ? v_dst : nullptr, D, st))
+      return rc;
+    if (dout_colsum) return LVL_OK;
+    return lvl_qkv_bias_sources(nullptr, dout, dbias, ws2, rows, D, dtype, false, nullptr, st);      // v third from dout
+  }
+  return lvl_qkv_bias_sources(dqkv, dout_colsum ? nullptr : dout, dbias, ws2, rows, D, dtype, true, dout_colsum, st);
 }
 
 extern "C" int lvl_causal_attn_fwd(const void* qkv, void* out, float* lse, int B, int L, int H, int dtype,

@@ -421,8 +421,18 @@ template <int NKP, int IMAGES = 1> struct FusedLds {
   static constexpr int lo_off = 2 * R * RS;                // ELEMENTS from a hi image to its lo image (PrecSplit)
   static constexpr int lse_off = IMAGES * 2 * R * RS * 2;
   static constexpr int del_off = lse_off + R * 4;
-  static constexpr int total = del_off + R * 4;
+  static constexpr int qsum_off = del_off + R * 4;         // [4 waves][64 channels] f32: column sums of dQ (bias-gradient rider)
+  static constexpr int total = qsum_off + 4 * 64 * 4;
 };
+
+// sum over the 16 lanes of a row (the 16 tokens of an accumulator tile), result in every lane: four DPP row rotations
+__device__ __forceinline__ float row16_sum(float x) {
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xf, 0xf, false));   // row_ror:8
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x124, 0xf, 0xf, false));   // row_ror:4
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x122, 0xf, 0xf, false));   // row_ror:2
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x121, 0xf, 0xf, false));   // row_ror:1
+  return x;
+}
 
 // o[dt][r] = X^T[channel dt*16 + g*4 + r][token lane&15] -> 4 stores of 4 consecutive channels of one token row
 template <typename P>
@@ -442,7 +452,10 @@ template <typename P, int NKP>
 __global__ __launch_bounds__(256, (P::kSplit ? 1 : 2)) void space_bwd_fused_kernel(
     const typename P::io_t* __restrict__ qkv, const typename P::io_t* __restrict__ out,
     const typename P::io_t* __restrict__ dout, const float* __restrict__ lse, typename P::io_t* __restrict__ dqkv,
-    float* __restrict__ atom_ws, int F, int N, int H) {
+    float* __restrict__ atom_ws, float* __restrict__ dq_part, int F, int N, int H) {
+  // dq_part (nullable; round 5): [B * F, H * 64] f32 -- this workgroup's column sums of dQ over its N patch queries and
+  // its share of the cls query's dQ, i.e. its part of the q third of d(qkv bias). The accumulators are already in
+  // registers: 32 adds per query pair, 64 DPP adds and one 256-byte store per workgroup instead of a pass over dqkv.
   using io_t = typename P::io_t;
   using Op = typename P::Op;
   using Tr = typename P::Tr;
@@ -454,6 +467,7 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : 2)) void space_bwd_fused_kern
   uint16_t* img1 = reinterpret_cast<uint16_t*>(smem + L::img1_off);      // V, then dO
   float* lse_s = reinterpret_cast<float*>(smem + L::lse_off);            // log2 units
   float* del_s = reinterpret_cast<float*>(smem + L::del_off);
+  float* qsum_s = reinterpret_cast<float*>(smem + L::qsum_off);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = blockIdx.x % H, f = (blockIdx.x / H) % F, b = blockIdx.x / (H * F);
@@ -496,6 +510,9 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : 2)) void space_bwd_fused_kern
   }
   __syncthreads();
 
+  f32x4 qsum[4];                                         // column sums of dQ^T over this wave's queries (rider)
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) qsum[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
   for (int qp = wave; qp < nqp; qp += NW) {
     if (qp != wave) load_qfrags(qp);
@@ -588,7 +605,20 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : 2)) void space_bwd_fused_kern
         store_token_channels<P>(dqkv + (size_t)b * T * ts + (size_t)(tok0 + qrow) * ts + h * 64, o[t], 0.125f, g);
       else if (qrow == N)
         atomic_token_channels(cls_ws, o[t], 0.125f, g);          // this frame's share of d(cls q)
+      if (dq_part && qrow <= N) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) qsum[dt] += o[t][dt];
+      }
     }
+  }
+  if (dq_part) {                                         // uniform; lanes c == 0 publish the wave's 64 channel sums
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = row16_sum(qsum[dt][r]);
+        if (c == 0) qsum_s[wave * 64 + dt * 16 + g * 4 + r] = v;
+      }
   }
 
   // ---- phase 2: dK, dV ----------------------------------------------------------------------------------------
@@ -631,6 +661,9 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : 2)) void space_bwd_fused_kern
       P::stage(img1, LO, img_off(p * RPP + r_in, c8), vb[p]);
     }
   }
+  if (dq_part && tid < 64)                               // the q scaling (head_dim^-0.5) rides here, as in the dQ stores
+    dq_part[((size_t)b * F + f) * D + h * 64 + tid] =
+        0.125f * ((qsum_s[tid] + qsum_s[64 + tid]) + (qsum_s[128 + tid] + qsum_s[192 + tid]));
   __syncthreads();
 
   const int cls_qp = N >> 5, cls_sub = N & 31;            // where the cls query sits in the pair loop
@@ -730,14 +763,14 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : 2)) void space_bwd_fused_kern
 
 template <typename P, int NKP>
 int launch_fused(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* atom_ws,
-                 int B, int F, int N, int H, hipStream_t st) {
+                 float* dq_part, int B, int F, int N, int H, hipStream_t st) {
   using L = FusedLds<NKP, P::kImages>;
   using io_t = typename P::io_t;
   static_assert(L::total <= 160 * 1024, "LDS per CU");
   if (L::total > 64 * 1024)
     if (int rc = lvl_allow_lds<space_bwd_fused_kernel<P, NKP>>()) return rc;
   hipLaunchKernelGGL((space_bwd_fused_kernel<P, NKP>), dim3((unsigned)(B * F * H)), dim3(256), L::total, st,
-                     (const io_t*)qkv, (const io_t*)out, (const io_t*)dout, lse, (io_t*)dqkv, atom_ws, F, N, H);
+                     (const io_t*)qkv, (const io_t*)out, (const io_t*)dout, lse, (io_t*)dqkv, atom_ws, dq_part, F, N, H);
   LVL_CHECK_LAUNCH("space_bwd_fused");
   return LVL_OK;
 }
@@ -746,9 +779,9 @@ constexpr int kFusedPairs = 9;         // fused kernel: up to 288 keys per group
 
 template <typename P>
 int dispatch_fused(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* atom_ws,
-                   int B, int F, int N, int H, hipStream_t st) {
+                   float* dq_part, int B, int F, int N, int H, hipStream_t st) {
   switch ((N + 1 + 31) / 32) {
-#define SPACE_FUSED_CASE(K) case K: return launch_fused<P, K>(qkv, out, dout, lse, dqkv, atom_ws, B, F, N, H, st);
+#define SPACE_FUSED_CASE(K) case K: return launch_fused<P, K>(qkv, out, dout, lse, dqkv, atom_ws, dq_part, B, F, N, H, st);
     SPACE_FUSED_CASE(1) SPACE_FUSED_CASE(2) SPACE_FUSED_CASE(3) SPACE_FUSED_CASE(4) SPACE_FUSED_CASE(5)
     SPACE_FUSED_CASE(6) SPACE_FUSED_CASE(7) SPACE_FUSED_CASE(8) SPACE_FUSED_CASE(9)
 #undef SPACE_FUSED_CASE
@@ -842,17 +875,21 @@ bool lvl_space_mfma_bwd_supported(int F, int N, int dtype) {
   return N + 1 <= kBigTiles * 16 && dkv_geometry(N, 4).total <= 160 * 1024;      // large groups: 4-wave kernels
 }
 
+// rows of the dq column-sum slab the fused kernel writes (0: this shape runs on kernels without the rider)
+int lvl_space_mfma_bwd_dq_part_rows(int B, int F, int N) { return N + 1 <= kFusedPairs * 32 ? B * F : 0; }
+
 // ws layout: delta [B*H*T] f32, then atomics [B*H*192] f32 (d cls q | d cls k | d cls v)
+// dq_part (nullable): [B*F, H*64] f32 partial column sums of dQ, written when lvl_space_mfma_bwd_dq_part_rows > 0
 int lvl_space_mfma_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* ws,
-                       int B, int F, int N, int H, int dtype, hipStream_t st) {
+                       float* dq_part, int B, int F, int N, int H, int dtype, hipStream_t st) {
   const int T = 1 + F * N;
   float* delta = ws;
   float* atom_ws = ws + (size_t)B * H * T;
   hipError_t e = hipMemsetAsync(atom_ws, 0, (size_t)B * H * 192 * sizeof(float), st);
   if (e != hipSuccess) return lvl_fail(LVL_EHIP, "space_bwd memset: %s", hipGetErrorString(e));
   if (N + 1 <= kFusedPairs * 32) {
-    if (int rc = dtype == LVL_F32 ? dispatch_fused<PrecSplit>(qkv, out, dout, lse, dqkv, atom_ws, B, F, N, H, st)
-                                  : dispatch_fused<PrecBf16>(qkv, out, dout, lse, dqkv, atom_ws, B, F, N, H, st))
+    if (int rc = dtype == LVL_F32 ? dispatch_fused<PrecSplit>(qkv, out, dout, lse, dqkv, atom_ws, dq_part, B, F, N, H, st)
+                                  : dispatch_fused<PrecBf16>(qkv, out, dout, lse, dqkv, atom_ws, dq_part, B, F, N, H, st))
       return rc;
   } else {
     if (dtype == LVL_F32) return lvl_fail(LVL_ENOSYS, "space_mfma_bwd (f32 class): %d keys per group", N + 1);

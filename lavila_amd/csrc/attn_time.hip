@@ -222,12 +222,16 @@ __global__ __launch_bounds__((DPL == 2 ? 512 : 256), (DPL == 2 || sizeof(E) == 4
 template <typename E, int F, int DPL>
 __global__ __launch_bounds__((DPL == 2 ? 512 : 256), (DPL == 2 || sizeof(E) == 4 ? 1 : (F <= 2 ? 4 : (F <= 4 ? 3 : 2)))) void time_bwd_kernel(const E* __restrict__ qkv, const E* __restrict__ out,
                                                        const E* __restrict__ dout, const float* __restrict__ lse,
-                                                       E* __restrict__ dqkv, float* __restrict__ atom_ws, int N,
+                                                       E* __restrict__ dqkv, float* __restrict__ atom_ws,
+                                                       float* __restrict__ dq_part, int N,
                                                        int H, int NPB, int NCH, int NC) {
+  // dq_part (nullable; round 5): [B * NC, H * 64] f32 -- column sums of the dq rows this workgroup writes plus its share
+  // of the cls query's dq: its part of the q third of d(qkv bias), accumulated in DPL registers per thread (the rows
+  // are in registers anyway) instead of a pass over dqkv afterwards.
   using V = Vec<E, DPL>;
   using vec_t = typename V::type;
   constexpr int LPP = 64 / DPL;
-  extern __shared__ __attribute__((aligned(16))) float smem[];      // [NPB][H][LPP][3 * DPL]
+  extern __shared__ __attribute__((aligned(16))) float smem[];      // [NPB][H][LPP][4 * DPL]
   const int tid = threadIdx.x, dl = tid % LPP, grp = tid / LPP;
   const int h = grp % H, n_sub = grp / H;
   const int chunk = blockIdx.x % NC, b = blockIdx.x / NC;
@@ -254,9 +258,9 @@ __global__ __launch_bounds__((DPL == 2 ? 512 : 256), (DPL == 2 || sizeof(E) == 4
   }
   const float Lc2 = lse[((size_t)b * H + h) * T] * kLog2e;            // cls-row lse in log2 units
 
-  float dqc[DPL], dkc[DPL], dvc[DPL];
+  float dqc[DPL], dkc[DPL], dvc[DPL], dqs[DPL];
 #pragma unroll
-  for (int i = 0; i < DPL; ++i) { dqc[i] = 0.f; dkc[i] = 0.f; dvc[i] = 0.f; }
+  for (int i = 0; i < DPL; ++i) { dqc[i] = 0.f; dkc[i] = 0.f; dvc[i] = 0.f; dqs[i] = 0.f; }
   if (chunk == 0 && n_sub == 0) {     // the cls key inside the CLS row, once per (b,h)
     float s = 0.f, dp = 0.f;
 #pragma unroll
@@ -355,6 +359,8 @@ __global__ __launch_bounds__((DPL == 2 ? 512 : 256), (DPL == 2 || sizeof(E) == 4
         }
       }
       *reinterpret_cast<vec_t*>(gbase + (size_t)tok * ts) = V::pack(dq);
+#pragma unroll
+      for (int i = 0; i < DPL; ++i) dqs[i] += dq[i];
     }
 #pragma unroll
     for (int f = 0; f < F; ++f) {
@@ -364,10 +370,13 @@ __global__ __launch_bounds__((DPL == 2 ? 512 : 256), (DPL == 2 || sizeof(E) == 4
     }
   }
 
-  constexpr int RS = 3 * DPL;
+  constexpr int RS = 4 * DPL;
   float* mine = smem + ((size_t)(n_sub * H + h) * LPP + dl) * RS;
 #pragma unroll
-  for (int i = 0; i < DPL; ++i) { mine[i] = dqc[i]; mine[DPL + i] = dkc[i]; mine[2 * DPL + i] = dvc[i]; }
+  for (int i = 0; i < DPL; ++i) {
+    mine[i] = dqc[i]; mine[DPL + i] = dkc[i]; mine[2 * DPL + i] = dvc[i];
+    mine[3 * DPL + i] = dqs[i] + dqc[i];                 // patch rows + this thread's share of the cls query's dq
+  }
   __syncthreads();
   if (n_sub == 0) {
     float acc[RS];
@@ -384,6 +393,11 @@ __global__ __launch_bounds__((DPL == 2 ? 512 : 256), (DPL == 2 || sizeof(E) == 4
       atomicAdd(dst + i, acc[i]);
       atomicAdd(dst + 64 + i, acc[DPL + i]);
       atomicAdd(dst + 128 + i, acc[2 * DPL + i]);
+    }
+    if (dq_part) {
+      float* qd = dq_part + (size_t)blockIdx.x * D + h * 64 + dl * DPL;
+#pragma unroll
+      for (int i = 0; i < DPL; ++i) qd[i] = acc[3 * DPL + i];
     }
   }
 }
@@ -458,9 +472,16 @@ bool lvl_time_fast_bwd_supported(int F, int N, int H) {
   return time_geometry(N, H, time_dpl(F)).ok;
 }
 
+// rows of the dq column-sum slab (one per workgroup)
+int lvl_time_fast_bwd_dq_part_rows(int B, int F, int N, int H) {
+  const TimeGeom g = time_geometry(N, H, time_dpl(F));
+  return g.ok ? B * g.NC : 0;
+}
+
 // ws layout: delta [B*H*T] f32 (unused here), then atomics [B*H*192] f32
+// dq_part (nullable): [lvl_time_fast_bwd_dq_part_rows, H*64] f32 partial column sums of dq (bias-gradient rider)
 int lvl_time_fast_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* ws,
-                      int B, int F, int N, int H, int dtype, hipStream_t st) {
+                      float* dq_part, int B, int F, int N, int H, int dtype, hipStream_t st) {
   const int dpl = time_dpl(F);
   const TimeGeom g = time_geometry(N, H, dpl);
   if (!g.ok) return lvl_fail(LVL_ENOSYS, "time_fast_bwd: unsupported head count %d", H);
@@ -468,17 +489,18 @@ int lvl_time_fast_bwd(const void* qkv, const void* out, const void* dout, const 
   float* atom_ws = ws + (size_t)B * H * T;
   hipError_t e = hipMemsetAsync(atom_ws, 0, (size_t)B * H * 192 * sizeof(float), st);
   if (e != hipSuccess) return lvl_fail(LVL_EHIP, "time_bwd memset: %s", hipGetErrorString(e));
-  const size_t shmem = (size_t)g.NPB * H * (64 / dpl) * 3 * dpl * sizeof(float);
+  const size_t shmem = (size_t)g.NPB * H * (64 / dpl) * 4 * dpl * sizeof(float);
   const dim3 grid((unsigned)(B * g.NC)), block(g.block);
 #define TIME_BWD(FF, DD)                                                                                            \
   do {                                                                                                              \
     if (dtype == LVL_F32)                                                                                           \
       hipLaunchKernelGGL((time_bwd_kernel<float, FF, DD>), grid, block, shmem, st, (const float*)qkv,                \
-                         (const float*)out, (const float*)dout, lse, (float*)dqkv, atom_ws, N, H, g.NPB, g.NCH, g.NC); \
+                         (const float*)out, (const float*)dout, lse, (float*)dqkv, atom_ws, dq_part, N, H, g.NPB,      \
+                         g.NCH, g.NC);                                                                              \
     else                                                                                                            \
       hipLaunchKernelGGL((time_bwd_kernel<uint16_t, FF, DD>), grid, block, shmem, st, (const uint16_t*)qkv,          \
-                         (const uint16_t*)out, (const uint16_t*)dout, lse, (uint16_t*)dqkv, atom_ws, N, H, g.NPB,    \
-                         g.NCH, g.NC);                                                                              \
+                         (const uint16_t*)out, (const uint16_t*)dout, lse, (uint16_t*)dqkv, atom_ws, dq_part, N, H,  \
+                         g.NPB, g.NCH, g.NC);                                                                       \
   } while (0)
   switch (F) {
     case 1: TIME_BWD(1, 4); break;

@@ -203,10 +203,10 @@ inline unsigned grid_for(int64_t total, int block) {
 constexpr int kBiasGradRowBlocks = 1024;
 template <typename T>
 __global__ __launch_bounds__(128) void qkv_bias_partial_kernel(const T* __restrict__ dqkv, const T* __restrict__ dout,
-                                                               float* __restrict__ part, int64_t rows, int D) {
+                                                               float* __restrict__ part, int64_t rows, int D, int src0) {
   const int vc = blockIdx.x * blockDim.x + threadIdx.x;
   if (vc * 8 >= D) return;
-  const int src = blockIdx.z;
+  const int src = blockIdx.z + src0;                     // src0 = 1, gridDim.z = 1: dout only; src0 = 0: dq (and dout)
   const T* base = (src == 0 ? dqkv : dout) + vc * 8;
   const int64_t ld = src == 0 ? 3 * (int64_t)D : D;
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -420,7 +420,71 @@ extern "C" int lvl_split_bf16x3(const float* src, void* dst, int64_t rows, int c
   return LVL_OK;
 }
 
+// out[k] = sum_n v[n] W[n, k], float32: the column sums of a Linear's INPUT gradient from the column sums of its output
+// gradient (dx = dy W  =>  sum_rows dx = (sum_rows dy) W) -- N, K of a few hundred to a few thousand, a few microseconds.
+// 1024 threads: lane = one column, 16 waves split the rows (8 loads in flight each), merged through LDS.
+__global__ __launch_bounds__(1024) void vec_mat_kernel(const float* __restrict__ v, const float* __restrict__ W,
+                                                       float* __restrict__ out, int N, int K) {
+  __shared__ float red[16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + lane;
+  float acc = 0.f;
+  if (k < K) {
+    int n = wave;
+    for (; n + 7 * 16 < N; n += 8 * 16) {
+      float w[8], x[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { w[i] = W[(size_t)(n + i * 16) * K + k]; x[i] = v[n + i * 16]; }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc = fmaf(x[i], w[i], acc);
+    }
+    for (; n < N; n += 16) acc = fmaf(v[n], W[(size_t)n * K + k], acc);
+  }
+  red[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && k < K) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += red[i][lane];
+    out[k] = s;
+  }
+}
+
+extern "C" int lvl_vec_mat_f32(const float* v, const float* W, float* out, int N, int K, void* stream) {
+  LVL_REQUIRE(v && W && out, "vec_mat_f32: null pointer");
+  LVL_REQUIRE(N > 0 && K > 0, "vec_mat_f32: bad shape N=%d K=%d", N, K);
+  hipLaunchKernelGGL(vec_mat_kernel, dim3((unsigned)((K + 63) / 64)), dim3(1024), 0, (hipStream_t)stream, v, W, out, N, K);
+  LVL_CHECK_LAUNCH("vec_mat_f32");
+  return LVL_OK;
+}
+
 int lvl_qkv_bias_row_blocks() { return kBiasGradRowBlocks; }
+int lvl_colsum_mid_rows();
+int64_t lvl_qkv_bias_ws_floats(int D) { return (int64_t)(kBiasGradRowBlocks + lvl_colsum_mid_rows()) * 2 * D; }
+
+// Column sums of the q third of dqkv (-> dbias[0, D)) and / or of dout (-> dbias[2D, 3D)); a null source is skipped and its
+// third of dbias left untouched. ws: lvl_qkv_bias_ws_floats.
+int lvl_launch_column_reduce_tail(const float* part, int nparts, int width, int seg, float* mid, float* out0, float* out1,
+                                  float* out2, float* zero_dst, const float* copy_src, float* copy_dst, int tail_n,
+                                  hipStream_t st);
+
+// zero_k: also write the exact zeros of the k third (dbias[D, 2D)); v_src: a ready-made v third to copy into dbias[2D, 3D)
+// (only meaningful when dout is null) -- both ride on the reduction's second stage.
+int lvl_qkv_bias_sources(const void* dqkv, const void* dout, float* dbias, float* ws, int64_t rows, int D, int dtype,
+                         bool zero_k, const float* v_src, hipStream_t st) {
+  if (!dqkv && !dout) return LVL_OK;
+  int64_t gy = rows < kBiasGradRowBlocks ? rows : kBiasGradRowBlocks;
+  const int src0 = dqkv ? 0 : 1, nsrc = (dqkv ? 1 : 0) + (dout ? 1 : 0);
+  const dim3 grid((unsigned)((D / 8 + 127) / 128), (unsigned)gy, (unsigned)nsrc);
+  LVL_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((qkv_bias_partial_kernel<T>), grid, dim3(128), 0, st, (const T*)dqkv,
+                                               (const T*)dout, ws, rows, D, src0));
+  LVL_CHECK_LAUNCH("qkv_bias_sources");
+  // partial rows are [sums of dq | sums of dout] (2 D wide); a skipped source's half holds stale scratch and goes nowhere
+  return lvl_launch_column_reduce_tail(ws, (int)gy, 2 * D, D, ws + (size_t)kBiasGradRowBlocks * 2 * D,
+                                       dqkv ? dbias : nullptr, dout ? dbias + 2 * (size_t)D : nullptr, nullptr,
+                                       zero_k ? dbias + D : nullptr, v_src, (v_src && !dout) ? dbias + 2 * (size_t)D : nullptr,
+                                       D, st);
+}
 
 extern "C" int lvl_qkv_bias_grad(const void* dqkv, const void* dout, float* dbias, float* ws, int64_t rows, int D,
                                  int dtype, void* stream) {
@@ -434,7 +498,7 @@ extern "C" int lvl_qkv_bias_grad(const void* dqkv, const void* dout, float* dbia
   int64_t gy = rows < kBiasGradRowBlocks ? rows : kBiasGradRowBlocks;
   const dim3 grid((unsigned)((D / 8 + 127) / 128), (unsigned)gy, 2);
   LVL_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((qkv_bias_partial_kernel<T>), grid, dim3(128), 0, st, (const T*)dqkv,
-                                               (const T*)dout, ws, rows, D));
+                                               (const T*)dout, ws, rows, D, 0));
   LVL_CHECK_LAUNCH("qkv_bias_grad");
   return lvl_launch_column_reduce(ws, (int)gy, 2 * D, D, ws + (size_t)kBiasGradRowBlocks * 2 * D, dbias,
                                   dbias + 2 * (size_t)D, nullptr, st);

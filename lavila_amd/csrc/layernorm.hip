@@ -342,12 +342,20 @@ __global__ __launch_bounds__(256) void colsum_stage1_kernel(const float* __restr
   }
 }
 
+// Tail (optional): zero_dst[0, tail_n) = 0 and copy_dst[0, tail_n) = copy_src[...] ride along (the k third of a qkv bias
+// gradient is exactly 0 and its v third may arrive ready-made: no memset / copy launches beside the reduction).
 __global__ __launch_bounds__(256) void colsum_stage2_kernel(const float* __restrict__ mid, int width, int seg,
                                                             float* __restrict__ out0, float* __restrict__ out1,
-                                                            float* __restrict__ out2) {
+                                                            float* __restrict__ out2, float* __restrict__ zero_dst,
+                                                            const float* __restrict__ copy_src,
+                                                            float* __restrict__ copy_dst, int tail_n) {
   __shared__ float4 red[16][16];
   const int cg = threadIdx.x & 15, rg = threadIdx.x >> 4;
   const int c = blockIdx.x * 64 + cg * 4;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < tail_n; i += gridDim.x * 256) {
+    if (zero_dst) zero_dst[i] = 0.f;
+    if (copy_dst) copy_dst[i] = copy_src[i];
+  }
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c < width) {
     float4 v[kColsumMid / 16];
@@ -398,13 +406,20 @@ int lvl_colsum_mid_rows() { return kColsumMid; }
 
 // out0/out1/out2 receive consecutive `seg`-wide segments of the column sums of part[nparts][width] (width % 4 == 0);
 // mid: kColsumMid * width floats of scratch (the callers place it behind their partial slab)
-int lvl_launch_column_reduce(const float* part, int nparts, int width, int seg, float* mid, float* out0, float* out1,
-                             float* out2, hipStream_t st) {
+int lvl_launch_column_reduce_tail(const float* part, int nparts, int width, int seg, float* mid, float* out0, float* out1,
+                                  float* out2, float* zero_dst, const float* copy_src, float* copy_dst, int tail_n,
+                                  hipStream_t st) {
   hipLaunchKernelGGL(colsum_stage1_kernel, dim3((width + 255) / 256, kColsumMid), dim3(256), 0, st, part, nparts, width,
                      mid);
-  hipLaunchKernelGGL(colsum_stage2_kernel, dim3((width + 63) / 64), dim3(256), 0, st, mid, width, seg, out0, out1, out2);
+  hipLaunchKernelGGL(colsum_stage2_kernel, dim3((width + 63) / 64), dim3(256), 0, st, mid, width, seg, out0, out1, out2,
+                     zero_dst, copy_src, copy_dst, (zero_dst || copy_dst) ? tail_n : 0);
   LVL_CHECK_LAUNCH("column_reduce");
   return LVL_OK;
+}
+
+int lvl_launch_column_reduce(const float* part, int nparts, int width, int seg, float* mid, float* out0, float* out1,
+                             float* out2, hipStream_t st) {
+  return lvl_launch_column_reduce_tail(part, nparts, width, seg, mid, out0, out1, out2, nullptr, nullptr, nullptr, 0, st);
 }
 
 extern "C" int lvl_layernorm_fwd(const void* x, const void* x2, const float* xbias, const float* gamma,

@@ -463,6 +463,72 @@ def linear_f32_rows(x2, w3, bias=None, act=None):
     return linear_skinny_f32c_raw(x3, w3, bias, act)
 
 
+# Column-sum tokens (round 5). The bias gradient of a qkv Linear needs sum_rows(dout) of its attention core (the v third:
+# every softmax row sums to 1). dout is the INPUT gradient of the projection Linear behind the attention, dout = dy W, so
+# sum_rows(dout) = sum_rows(dy) W -- and sum_rows(dy) is the projection's own bias gradient, which the LayerNorm backward
+# behind it produces anyway. A "token" is a [width] float32 tensor that travels beside an activation through the own
+# autograd Functions (attention core -> projection -> fused add / LayerNorm); its GRADIENT is defined as the column sums of
+# the activation's gradient, each Function computing it from what it already has (a [D] x [D, D] vector-matrix product,
+# lvl_vec_mat_f32, a few microseconds) instead of a 300 MB pass over dout per attention. Exact in real arithmetic; in
+# floating point it is the more accurate of the two (float32 sums of float32 column sums against sums of bf16-rounded
+# rows). LAVILA_COLSUM_TOKENS=0 switches the tokens off (the attention backward then reduces dout itself, as before).
+COLSUM_TOKENS = os.environ.get('LAVILA_COLSUM_TOKENS', '1') != '0'
+
+
+def vec_mat(v, weight):
+    """v [N] float32 . weight [N, K] -> [K] float32 (lvl_vec_mat_f32)."""
+    w = weight.detach()
+    if w.dtype != torch.float32 or not w.is_contiguous():
+        w = w.float().contiguous()
+    v = v.detach().float().contiguous()
+    C.require_device(v, w)
+    out = torch.empty(w.shape[1], dtype=torch.float32, device=w.device)
+    C.check(C.lib().lvl_vec_mat_f32(C.ptr(v), C.ptr(w), C.ptr(out), w.shape[0], w.shape[1], C.stream_ptr()), 'lvl_vec_mat_f32')
+    return out
+
+
+class _LinearTokenFn(torch.autograd.Function):
+    """(y, ytoken) = (x W^T, token of y) for a bf16 activation x that carries the column-sum token `xtoken`: _LinearFn's
+    own-kernel path without a bias (the caller leaves it pending for the fused add + LayerNorm), plus the token rule
+    d(xtoken) = d(ytoken) . W."""
+
+    @staticmethod
+    def forward(ctx, x, weight, xtoken):
+        x2 = x.reshape(-1, x.shape[-1])
+        x2 = x2 if x2.is_contiguous() else x2.contiguous()
+        w, wt = weight_copies(weight)
+        ctx.save_for_backward(x2, wt, weight)
+        ctx.meta = (weight.dtype, x.shape)
+        ctx.set_materialize_grads(False)        # an unused token arrives as None, not as zeros
+        y = linear_tn_raw(x2, w, None, C.EPI_BIAS)
+        return y.reshape(*x.shape[:-1], weight.shape[0]), x.new_empty(weight.shape[0], dtype=torch.float32)
+
+    @staticmethod
+    def backward(ctx, dy, dytoken):
+        x2, wt, weight = ctx.saved_tensors
+        wdt, xshape = ctx.meta
+        if dy is None:
+            return None, None, None
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        dy2 = dy2 if dy2.is_contiguous() else dy2.contiguous()
+        with torch.autocast('cuda', enabled=False):
+            dx = linear_tn_raw(dy2, wt, None, C.EPI_BIAS).reshape(xshape) if ctx.needs_input_grad[0] else None
+            dw = _wgrad(dy2, x2, wdt) if ctx.needs_input_grad[1] else None
+            dtok = vec_mat(dytoken, weight) if (dytoken is not None and ctx.needs_input_grad[2]) else None
+        return dx, dw, dtok
+
+
+def linear_with_token(x, weight, xtoken):
+    """(y, ytoken) of a bias-free Linear on a token-carrying bf16 activation, or (linear(x, weight), None) when the shapes
+    are not the own kernels' (the token chain then simply ends: consumers fall back to reducing their rows)."""
+    x = _act(x)
+    rows, n_in, n_out = x.numel() // x.shape[-1], x.shape[-1], weight.shape[0]
+    if (xtoken is not None and x.dtype == torch.bfloat16 and x.is_cuda and weight.dtype == torch.float32
+            and _tn_ok(rows, n_out, n_in) and _tn_ok(rows, n_in, n_out)):
+        return _LinearTokenFn.apply(x, weight, xtoken)
+    return linear(x, weight), None
+
+
 def project(x, proj):
     """x @ proj for the [width, embed_dim] projection parameters (models.py:146,161): the Linear kernels against the
     transposed view (its gradient flows back to `proj` through the view)."""
@@ -624,7 +690,7 @@ class _LinearResidualLayerNormFn(torch.autograd.Function):
     weight gradient: lvl_linear_wgrad)."""
 
     @staticmethod
-    def forward(ctx, x, weight, lbias, res, gamma, beta, eps):
+    def forward(ctx, x, weight, lbias, res, gamma, beta, eps, xtoken=None):
         x2 = x.reshape(-1, x.shape[-1])
         x2 = x2 if x2.is_contiguous() else x2.contiguous()
         res2 = res.reshape(-1, res.shape[-1])
@@ -633,34 +699,43 @@ class _LinearResidualLayerNormFn(torch.autograd.Function):
         s = linear_tn_raw(x2, w, _f32(lbias), C.EPI_BIAS_RESIDUAL, aux_in=res2)
         g = _f32(gamma)
         h, _, mean, rstd = layernorm_fwd_raw(s, None, None, g, _f32(beta), eps, False)
-        ctx.save_for_backward(x2, wt, s, g, mean, rstd)
+        ctx.has_token = xtoken is not None
+        ctx.save_for_backward(x2, wt, s, g, mean, rstd, *((weight,) if ctx.has_token else ()))
         ctx.meta = (weight.dtype, None if lbias is None else lbias.dtype, gamma.dtype, beta.dtype, x.shape)
         return s.reshape(res.shape), h.reshape(res.shape)
 
     @staticmethod
     def backward(ctx, ds, dh):
-        x2, wt, s, g, mean, rstd = ctx.saved_tensors
+        x2, wt, s, g, mean, rstd = ctx.saved_tensors[:6]
         wdt, bdt, gdt, betadt, xshape = ctx.meta
         dh2 = dh.reshape(s.shape)
         dadd = None if ds is None else ds.reshape(s.shape).contiguous()
-        dsum, dg, dbeta, dcol = layernorm_bwd_raw(dh2.contiguous(), s, None, None, g, mean, rstd, dadd, bdt is not None)
+        want_tok = ctx.has_token and ctx.needs_input_grad[7]
+        dsum, dg, dbeta, dcol = layernorm_bwd_raw(dh2.contiguous(), s, None, None, g, mean, rstd, dadd,
+                                                  bdt is not None or want_tok)
         with torch.autocast('cuda', enabled=False):
             dx = linear_tn_raw(dsum, wt, None, C.EPI_BIAS).reshape(xshape) if ctx.needs_input_grad[0] else None
             dw = _wgrad(dsum, x2, wdt) if ctx.needs_input_grad[1] else None
+            # token rule: column sums of dx = (column sums of dsum) . W  (dx = dsum W)
+            dtok = vec_mat(dcol, ctx.saved_tensors[6]) if want_tok else None
         db = dcol.to(bdt) if (bdt is not None and ctx.needs_input_grad[2]) else None
-        return dx, dw, db, dsum.reshape(ds.shape if ds is not None else dh.shape), dg.to(gdt), dbeta.to(betadt), None
+        return (dx, dw, db, dsum.reshape(ds.shape if ds is not None else dh.shape), dg.to(gdt), dbeta.to(betadt), None,
+                dtok)
 
 
-def linear_residual_layer_norm(x, weight, lbias, res, gamma, beta, eps):
+def linear_residual_layer_norm(x, weight, lbias, res, gamma, beta, eps, xtoken=None):
     """(s, h) = (res + Linear(x), LayerNorm(s)) through the GEMM's residual epilogue, or None when the shapes / dtypes are
-    not the benched bf16 configuration (the caller then composes linear + add_layer_norm as before)."""
+    not the benched bf16 configuration (the caller then composes linear + add_layer_norm as before). xtoken: the
+    column-sum token of x (see COLSUM_TOKENS)."""
     x, res = _act(x), lowp(res)
     rows = x.numel() // x.shape[-1]
     n_out, n_in = weight.shape
     if not (RESIDUAL_EPILOGUE and x.dtype == torch.bfloat16 and res.dtype == torch.bfloat16 and x.is_cuda
             and _tn_ok(rows, n_out, n_in) and _tn_ok(rows, n_in, n_out)):
         return None
-    s, h = _LinearResidualLayerNormFn.apply(x, weight, lbias, res, gamma, beta, eps)
+    if xtoken is not None and weight.dtype != torch.float32:
+        xtoken = None
+    s, h = _LinearResidualLayerNormFn.apply(x, weight, lbias, res, gamma, beta, eps, xtoken)
     return s, _narrow(h)
 
 
@@ -724,34 +799,38 @@ class _AddLayerNormPassFn(torch.autograd.Function):
     (dx = dx_plain + d_res_out) instead of by a separate full-size add of the autograd engine."""
 
     @staticmethod
-    def forward(ctx, res, y, ybias, weight, bias, eps):
+    def forward(ctx, res, y, ybias, weight, bias, eps, ytoken=None):
         res, y = res.contiguous(), y.contiguous()
         yb, g, b = _f32(ybias), _f32(weight), _f32(bias)
         h, _, mean, rstd = layernorm_fwd_raw(res, y, yb, g, b, eps, False)
         ctx.save_for_backward(res, y, yb, g, mean, rstd)
         ctx.has_ybias = ybias is not None
+        ctx.has_token = ytoken is not None
         ctx.pdt = (weight.dtype, bias.dtype, ybias.dtype if ybias is not None else None)
         return res.view_as(res), h
 
     @staticmethod
     def backward(ctx, dres, dh):
         res, y, yb, g, mean, rstd = ctx.saved_tensors
+        want_sum = ctx.has_ybias or (ctx.has_token and ctx.needs_input_grad[6])     # column sums of dy
         if dres is None:
-            dx, dg, db, dsum = layernorm_bwd_raw(dh.contiguous(), res, y, yb, g, mean, rstd, None, ctx.has_ybias)
+            dx, dg, db, dsum = layernorm_bwd_raw(dh.contiguous(), res, y, yb, g, mean, rstd, None, want_sum)
             dy = dx
         else:
             dx, dg, db, dsum, dy = layernorm_bwd_raw(dh.contiguous(), res, y, yb, g, mean, rstd, dres.contiguous(),
-                                                     ctx.has_ybias, want_plain=True)
+                                                     want_sum, want_plain=True)
         dyb = dsum.to(ctx.pdt[2]) if ctx.has_ybias else None
-        return dx, dy, dyb, dg.to(ctx.pdt[0]), db.to(ctx.pdt[1]), None
+        dtok = dsum if (ctx.has_token and ctx.needs_input_grad[6]) else None      # token rule: sum_rows(dy) itself
+        return dx, dy, dyb, dg.to(ctx.pdt[0]), db.to(ctx.pdt[1]), None, dtok
 
 
-def add_layer_norm_pass(res, y, ybias, weight, bias, eps):
-    """Returns (res_again, h) with h = LayerNorm(res + y (+ ybias)); use res_again for the next consumer of res."""
+def add_layer_norm_pass(res, y, ybias, weight, bias, eps, ytoken=None):
+    """Returns (res_again, h) with h = LayerNorm(res + y (+ ybias)); use res_again for the next consumer of res.
+    ytoken: the column-sum token of y (see COLSUM_TOKENS)."""
     res = lowp(res)
     if y.dtype != res.dtype:
-        y = y.to(res.dtype)
-    r, h = _AddLayerNormPassFn.apply(res, y, ybias, weight, bias, eps)
+        y, ytoken = y.to(res.dtype), None
+    r, h = _AddLayerNormPassFn.apply(res, y, ybias, weight, bias, eps, ytoken)
     return r, _narrow(h)
 
 
@@ -879,10 +958,13 @@ def _qkv_bias_grad(dqkv, dout, dtype):
 
 class _DividedAttnFn(torch.autograd.Function):
     """`bias` (optional): the bias of the qkv Linear that produced `qkv` (already added there; the caller hands the
-    Linear a detached copy). It takes no part in the forward; its gradient comes from _qkv_bias_grad."""
+    Linear a detached copy). It takes no part in the forward; its gradient comes out of the backward call itself
+    (lvl_divided_attn_bwd_bias: q third from the backward kernels' own column sums where they have the rider, k third 0,
+    v third from the output's column-sum token when the consumer supplies it -- see COLSUM_TOKENS -- else from dout).
+    want_token: also return the column-sum token of `out` (for a consumer that is an own token-aware Function)."""
 
     @staticmethod
-    def forward(ctx, qkv, bias, frames, n_per_frame, heads, mode):
+    def forward(ctx, qkv, bias, frames, n_per_frame, heads, mode, want_token=False):
         qkv = qkv.contiguous()
         C.require_device(qkv)
         B, T, D3 = qkv.shape
@@ -896,20 +978,37 @@ class _DividedAttnFn(torch.autograd.Function):
         out, lse = divided_attn_fwd_raw(qkv, frames, n_per_frame, heads, mode)
         ctx.save_for_backward(qkv, out, lse)
         ctx.cfg = (B, frames, n_per_frame, heads, mode, None if bias is None else bias.dtype)
+        ctx.want_token = bool(want_token)
+        # an unused token must arrive in backward as None (= "nobody computed the column sums"), not as zeros
+        ctx.set_materialize_grads(False)
+        if want_token:
+            return out, out.new_empty(D, dtype=torch.float32)
         return out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dout, dtoken=None):
         qkv, out, lse = ctx.saved_tensors
         B, Fr, N, H, mode, bdt = ctx.cfg
+        if dout is None:                        # the output itself was not used: zero gradient, no token either
+            dout, dtoken = torch.zeros_like(out), None
         dout = dout.contiguous()
         dqkv = torch.empty_like(qkv)
         ws = C.workspace('divided_attn_bwd', B * H, 1 + Fr * N, qkv.device)
+        if bdt is not None and ctx.needs_input_grad[1]:
+            D = H * 64
+            db = torch.empty(3 * D, dtype=torch.float32, device=qkv.device)
+            n2 = int(C.lib().lvl_divided_attn_bwd_bias_ws(B, Fr, N, H, mode, C.dtype_code(qkv)))
+            ws2 = torch.empty(max(n2, 4), dtype=torch.float32, device=qkv.device)
+            tok = dtoken.float().contiguous() if dtoken is not None else None
+            C.require_device(tok)
+            C.check(C.lib().lvl_divided_attn_bwd_bias(C.ptr(qkv), C.ptr(out), C.ptr(dout), C.ptr(lse), C.ptr(dqkv),
+                                                      C.ptr(ws), C.ptr(tok), C.ptr(db), C.ptr(ws2), B, Fr, N, H, mode,
+                                                      C.dtype_code(qkv), C.stream_ptr()), 'lvl_divided_attn_bwd_bias')
+            return dqkv, db.to(bdt), None, None, None, None, None
         C.check(C.lib().lvl_divided_attn_bwd(C.ptr(qkv), C.ptr(out), C.ptr(dout), C.ptr(lse), C.ptr(dqkv), C.ptr(ws),
                                              B, Fr, N, H, mode, C.dtype_code(qkv), C.stream_ptr()),
                 'lvl_divided_attn_bwd')
-        db = _qkv_bias_grad(dqkv, dout, bdt) if (bdt is not None and ctx.needs_input_grad[1]) else None
-        return dqkv, db, None, None, None, None
+        return dqkv, None, None, None, None, None, None
 
 
 def divided_attn_fwd_raw(qkv, frames, n_per_frame, heads, mode):
@@ -923,10 +1022,14 @@ def divided_attn_fwd_raw(qkv, frames, n_per_frame, heads, mode):
     return out, lse
 
 
-def divided_attention(qkv, frames, n_per_frame, heads, mode, bias=None):
+def divided_attention(qkv, frames, n_per_frame, heads, mode, bias=None, want_token=False):
     """mode: 'space' | 'time'. qkv [B,T,3D] -> [B,T,D] (timesformer.py:110-140 between the two Linears).
-    bias: see _DividedAttnFn."""
+    bias, want_token: see _DividedAttnFn; with want_token -> (out, token), token None when tokens are switched off."""
     m = {'space': C.ATTN_SPACE, 'time': C.ATTN_TIME}[mode]
+    if want_token:
+        if COLSUM_TOKENS and bias is not None and torch.is_grad_enabled():
+            return _DividedAttnFn.apply(lowp(qkv), bias, frames, n_per_frame, heads, m, True)
+        return _DividedAttnFn.apply(lowp(qkv), bias, frames, n_per_frame, heads, m), None
     return _DividedAttnFn.apply(lowp(qkv), bias, frames, n_per_frame, heads, m)
 
 

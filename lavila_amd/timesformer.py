@@ -209,13 +209,14 @@ class VarAttention(nn.Module):
             return 'time', int(einops_dims['n'])
         raise NotImplementedError(f'einops pattern {einops_to!r}')
 
-    def core(self, x, mode, frames, n_per_frame):
-        """qkv Linear + attention core; returns the pre-projection tensor [B,T,D]."""
+    def core(self, x, mode, frames, n_per_frame, want_token=False):
+        """qkv Linear + attention core; returns the pre-projection tensor [B,T,D] (want_token: and its column-sum token,
+        ops.COLSUM_TOKENS -- for callers that hand BOTH to a token-aware consumer and use the tensor nowhere else)."""
         bias = self.qkv.bias
-        # the GEMM adds the bias; its gradient is produced next to the attention backward (ops._qkv_bias_grad),
+        # the GEMM adds the bias; its gradient comes out of the attention backward call (ops._DividedAttnFn),
         # hence the detached copy for the Linear
         qkv = ops.linear(x, self.qkv.weight, None if bias is None else bias.detach())
-        return ops.divided_attention(qkv, frames, n_per_frame, self.num_heads, mode, bias=bias)
+        return ops.divided_attention(qkv, frames, n_per_frame, self.num_heads, mode, bias=bias, want_token=want_token)
 
     def forward(self, x, einops_from, einops_to, einops_dims):
         mode, k = self._mode(einops_to, einops_dims)
@@ -296,19 +297,26 @@ class SpaceTimeBlock(nn.Module):
         else:
             x, h3 = _close_pending(res, pend, pend_bias, n3)
         ta, sa = self.timeattn, self.attn
-        o_t = ta.core(h3, 'time', frames, n_per_frame)
+        tok_y = None
         if hasattr(self, 'alpha_timeattn'):
+            o_t = ta.core(h3, 'time', frames, n_per_frame)
             y_t, b_t = torch.tanh(self.alpha_timeattn).to(o_t.dtype) * ops.linear(o_t, ta.proj.weight, ta.proj.bias), None
         else:
-            y_t, b_t = ops.linear(o_t, ta.proj.weight), ta.proj.bias
+            # column-sum tokens (ops.COLSUM_TOKENS): o_t -> projection -> fused add + norm1; the backward hands
+            # sum_rows(d o_t) to the attention backward, which needs it for the v third of d(qkv bias)
+            o_t, tok_o = ta.core(h3, 'time', frames, n_per_frame, want_token=True)
+            (y_t, tok_y), b_t = ops.linear_with_token(o_t, ta.proj.weight, tok_o), ta.proj.bias
         # t = x + time_out is never stored; x is handed through so that its second use below sends its gradient into
         # norm1's backward kernel instead of a separate add
-        x, h1 = ops.add_layer_norm_pass(x, y_t, b_t, n1.weight, n1.bias, n1.eps)
-        o_s = sa.core(h1, 'space', frames, n_per_frame)
+        x, h1 = ops.add_layer_norm_pass(x, y_t, b_t, n1.weight, n1.bias, n1.eps, ytoken=tok_y)
         fused = None
         if not self._dropping():
             # ops.RESIDUAL_EPILOGUE: x1 leaves the projection GEMM (residual epilogue), norm2 reads it
-            fused = ops.linear_residual_layer_norm(o_s, sa.proj.weight, sa.proj.bias, x, n2.weight, n2.bias, n2.eps)
+            o_s, tok_s = sa.core(h1, 'space', frames, n_per_frame, want_token=True)
+            fused = ops.linear_residual_layer_norm(o_s, sa.proj.weight, sa.proj.bias, x, n2.weight, n2.bias, n2.eps,
+                                                   xtoken=tok_s)
+        else:
+            o_s = sa.core(h1, 'space', frames, n_per_frame)
         if fused is not None:
             x1, h2 = fused
         else:
@@ -340,12 +348,14 @@ class SpaceTimeBlock(nn.Module):
         else:
             x, h3 = _close_pending(res, pend, pend_bias, n3)
         ta, sa = self.timeattn, self.attn
-        o_t = ta.core(h3, 'time', frames, n_per_frame)
+        tok_y = None
         if hasattr(self, 'alpha_timeattn'):
+            o_t = ta.core(h3, 'time', frames, n_per_frame)
             y_t, b_t = torch.tanh(self.alpha_timeattn).to(o_t.dtype) * ops.linear(o_t, ta.proj.weight, ta.proj.bias), None
         else:
-            y_t, b_t = ops.linear(o_t, ta.proj.weight), ta.proj.bias
-        x, h1 = ops.add_layer_norm_pass(x, y_t, b_t, n1.weight, n1.bias, n1.eps)
+            o_t, tok_o = ta.core(h3, 'time', frames, n_per_frame, want_token=True)
+            (y_t, tok_y), b_t = ops.linear_with_token(o_t, ta.proj.weight, tok_o), ta.proj.bias
+        x, h1 = ops.add_layer_norm_pass(x, y_t, b_t, n1.weight, n1.bias, n1.eps, ytoken=tok_y)
         # space attention, cls query only: k | v of every token (the last two thirds of the qkv Linear), q of the cls rows
         D = h1.shape[-1]
         w, bias = sa.qkv.weight, sa.qkv.bias

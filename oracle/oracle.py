@@ -509,13 +509,15 @@ def procedural_weights(shapes: Dict[str, tuple], seed: int = 0, spread: bool = F
     identical weights without shipping them. Scales are chosen so the temporal path is live
     (the shipped zeros-init makes temporal attention a no-op).
 
-    spread=True (round 5 fixtures): token embeddings of std 0.1, 3x larger in_proj weights in the text tower and 2x
-    larger qkv weights in the video tower -- attention scores of a few units instead of near-uniform attention, which in
-    a randomly initialised deep transformer collapses every sample onto one embedding. With
-    synthetic_batch(spread=True): mean cosine between samples 0.4 (video) / 0.2 (text) instead of 0.99, distinct argmax
-    per row, and a softmax that is no longer flat. (3x in the video tower is past the edge of chaos: float32 and float64
-    evaluations of the SAME network then differ by 5e-2 -- nothing can be pinned to 1e-3 there; at 2x they agree to
-    1e-5.)"""
+    spread=True (round 5 fixtures): token embeddings of std 0.1, 2x larger in_proj weights in the text tower and 1.5x
+    larger qkv weights in the video tower -- sharper attention than the near-uniform one of a randomly initialised deep
+    transformer, which collapses every sample onto one embedding. With synthetic_batch(spread=True): mean cosine between
+    samples 0.5 (video) / 0.4 (text) instead of 0.99, distinct argmax per row, and a softmax that is no longer flat.
+    How far this can be pushed is set by CONDITIONING, measured before choosing: at 3x the video tower is past the edge
+    of chaos (float32 and float64 evaluations of the SAME network differ by 5e-2); at 2x / 3x (video / text) float32
+    evaluations agree to 1e-5 but the network amplifies a 2^-17 operand perturbation -- the f32-class mode of the MFMA
+    kernels, 16-bit mantissa images -- to 3e-3 on a logit (measured on the GPU; CPU emulation of the operand rounding:
+    7e-4 from the Linear layers alone), beyond north_star's 1e-3; at 1.5x / 2x the same emulation gives 9e-5."""
     out = {}
     for idx, name in enumerate(sorted(shapes)):
         shape = tuple(shapes[name])
@@ -542,9 +544,9 @@ def procedural_weights(shapes: Dict[str, tuple], seed: int = 0, spread: bool = F
         else:                                               # Linear / in_proj weights [out, in]
             t = torch.randn(shape, generator=g) * shape[-1] ** -0.5
             if spread and leaf == 'in_proj_weight':
-                t = t * 3.0
-            elif spread and name.endswith('qkv.weight'):
                 t = t * 2.0
+            elif spread and name.endswith('qkv.weight'):
+                t = t * 1.5
         out[name] = t
     return out
 

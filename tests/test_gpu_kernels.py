@@ -214,6 +214,51 @@ def test_divided_attention_core(dt, mode, B, Fr, N, H):
     _check_qkv_bias_grad(bias.grad, qo.grad, dt)
 
 
+@pytest.mark.parametrize('mode', ['space', 'time'])
+@pytest.mark.parametrize('site', ['residual_epilogue', 'add_layernorm_pass'])
+def test_colsum_tokens_give_the_bias_gradient_without_reading_dout(mode, site, monkeypatch):
+    """Round 5: the v third of d(qkv bias) = sum_rows(dout) travels as a column-sum TOKEN from the consumer of the attention
+    output back to the attention backward (sum_rows(dout) = sum_rows(dy) . W_proj, lvl_vec_mat_f32) instead of a pass over
+    dout. Both consumer sites of SpaceTimeBlock.chain -- projection with the residual epilogue + LayerNorm (space), bias-free
+    projection + fused add / LayerNorm with the residual handed through (time) -- with tokens on and off: the q / k thirds
+    are bit-identical (same kernels), the v third agrees to the rounding of the bf16 dout rows the off-path sums, and both
+    agree with float64 column sums of the float32 oracle's dqkv."""
+    from lavila_amd import ops
+    B, Fr, N, H = 2, 4, 49, 4
+    D, T = 64 * H, 1 + Fr * N
+    g = torch.Generator().manual_seed(11)
+    qkv = (torch.randn(B, T, 3 * D, generator=g) * 1.2).to(torch.bfloat16)
+    W = torch.randn(D, D, generator=g) * D ** -0.5
+    pb, gam, bet = 0.1 * torch.randn(D, generator=g), 1 + 0.1 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+    res = torch.randn(B, T, D, generator=g).to(torch.bfloat16)
+    up, up2 = torch.randn(B, T, D, generator=g), torch.randn(B, T, D, generator=g)
+
+    def run(tokens):
+        monkeypatch.setattr(ops, 'COLSUM_TOKENS', tokens)
+        q = qkv.to(DEV).requires_grad_(True)
+        bias = torch.zeros(3 * D, device=DEV, requires_grad=True)
+        Wd = W.to(DEV).requires_grad_(True)
+        o, tok = ops.divided_attention(q, Fr, N, H, mode, bias=bias, want_token=True)
+        assert (tok is not None) == tokens
+        if site == 'residual_epilogue':
+            s_, h = ops.linear_residual_layer_norm(o, Wd, pb.to(DEV), res.to(DEV), gam.to(DEV), bet.to(DEV), 1e-6, xtoken=tok)
+        else:
+            (y, ty) = ops.linear_with_token(o, Wd, tok)
+            s_, h = ops.add_layer_norm_pass(res.to(DEV).requires_grad_(True), y, pb.to(DEV).requires_grad_(True), gam.to(DEV),
+                                            bet.to(DEV), 1e-6, ytoken=ty)
+        ((h.float() * up.to(DEV)).sum() + (s_.float() * up2.to(DEV)).sum()).backward()
+        torch.cuda.synchronize()
+        return bias.grad.clone(), q.grad.clone()
+
+    (b_on, dq_on), (b_off, dq_off) = run(True), run(False)
+    assert torch.equal(dq_on, dq_off)
+    assert torch.equal(b_on[:2 * D], b_off[:2 * D]) and float(b_on[D:2 * D].abs().max()) == 0.0
+    scale = b_off[2 * D:].abs().max().item()
+    assert (b_on[2 * D:] - b_off[2 * D:]).abs().max().item() < 2e-2 * scale
+    want = dq_on.double().sum((0, 1)).cpu()                     # column sums of the dqkv the kernels wrote (bf16 rows)
+    assert (b_on.double().cpu() - want).abs().max().item() < 3e-2 * want.abs().max().item()
+
+
 @pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize('B,L,H', [(3, 77, 2), (2, 5, 1), (2, 130, 2)])
 def test_causal_attention_core(dt, B, L, H):

@@ -252,6 +252,6 @@ def test_fp8_qk_end_to_end_bound_on_tsfl14_336():
     print(f'[fp8 end to end, TSF-L/14@336] vs the float32 reference -- bf16: {bf16}; fp8 QK^T: {fp8}')
     assert fp8['embed'] != bf16['embed'], 'the fp8 switch had no effect on the model'
     for r in (bf16, fp8):
-        assert r['embed'] < 0.15 and r['loss'] < 5e-2 and r['norm_dev'] < 0.25, r
-    assert bf16['embed'] < 5e-2 and bf16['grad_rel_median'] < 0.1, bf16
+        assert r['embed'] < 0.15 and r['loss'] < 0.1 and r['norm_dev'] < 0.25, r
+    assert bf16['embed'] < 5e-2 and bf16['grad_rel_median'] < 0.3, bf16
     assert fp8['embed'] <= 6 * bf16['embed'] + 1e-2 and fp8['grad_rel_median'] <= 6 * bf16['grad_rel_median'] + 2e-2, (bf16, fp8)
