@@ -409,6 +409,11 @@ def main():
     device = torch.device('cuda', dev_index)
     rehearsal = None
     force_group = world == 1 and os.environ.get('LAVILA_BENCH_ONE_RANK_RCCL') == '1'
+    if os.environ.get('LAVILA_BENCH_EARLY_TEXT_STREAM') == '1':
+        # bisect switch: create the text tower's side stream BEFORE the communicator creates its own streams (HIP maps
+        # streams onto a small number of hardware queues round-robin in creation order)
+        from lavila_amd import models as _m0
+        _m0._text_stream(device)
     if force_group:
         # A/B on a single GPU: the multi-GPU code path (RCCL process group, DistributedDataParallel with its bucket
         # all-reduce, device tile counters) with ONE rank -- the collectives run on the real library, their data path is a
@@ -544,6 +549,24 @@ def main():
                    'host_enqueue_ms_per_step': round(1e3 * h2 / n2, 1), 'steps': n2}
         _m._TEXT_TRIM = True
 
+    # the same step with the caption bound taken from the HOST tokens (models.caption_bound + fixed_text_length: the
+    # one-line driver change of INTEGRATION.md section 1c): same trimmed text tower, no device read-back, the host runs ahead
+    host_bound = None
+    if os.environ.get('LAVILA_TEXT_TRIM', '1') != '0' and not args.no_events:
+        from lavila_amd import models as _m
+        bound = _m.caption_bound(tokens.cpu())       # once, outside the timed loop: a real loader has the tokens on the host
+        with _m.fixed_text_length(bound):
+            step()
+            fence()
+            n4, h4, t4 = max(2, min(4, args.steps)), 0.0, time.perf_counter()
+            for _ in range(n4):
+                h0 = time.perf_counter()
+                step()
+                h4 += time.perf_counter() - h0
+            fence()
+        host_bound = {'ms_per_step': round(1e3 * (time.perf_counter() - t4) / n4, 3),
+                      'host_enqueue_ms_per_step': round(1e3 * h4 / n4, 1), 'steps': n4, 'bound': bound}
+
     # the same step with the LAST block of both towers computed on every row, as the reference does (the default computes
     # only the rows that reach the output -- cls / EOT -- which is exact: DESIGN.md section 4, "Last block")
     full_last = None
@@ -647,6 +670,7 @@ def main():
                        'host_enqueue_ms_per_step': round(1e3 * host_s / args.steps, 1),
                        'host_ms_of_each_step': [round(1e3 * h, 1) for h in host_steps[:32]],
                        'text_trim_off': no_trim,
+                       'host_caption_bound': host_bound,
                        'full_last_block': full_last,
                        # the same iteration as one replayed hipGraph per caption-length bucket (lavila_amd/graph_step.py)
                        'graphed_step': graphed,

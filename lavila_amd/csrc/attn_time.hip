@@ -219,8 +219,16 @@ __global__ __launch_bounds__((DPL == 2 ? 512 : 256), (DPL == 2 || sizeof(E) == 4
 // Everything of a (b, n, h) problem is thread-group local: the softmax is recomputed from the F+1 keys in
 // registers (no saved statistics needed, and delta = sum_j P dP needs no O rows: `out` is only read for the cls
 // row), dq/dk/dv rows of the patch tokens are written exactly once. HBM: 5 row reads + 3 row writes per token.
-template <typename E, int F, int DPL>
-__global__ __launch_bounds__((DPL == 2 ? 512 : 256), (DPL == 2 || sizeof(E) == 4 ? 1 : (F <= 2 ? 4 : (F <= 4 ? 3 : 2)))) void time_bwd_kernel(const E* __restrict__ qkv, const E* __restrict__ out,
+// RIDER (round 5): 0 = no bias-gradient rider (the kernel of rounds 1-4, instruction for instruction); 1 = dq column sums
+// in DPL registers per thread at the kernel's usual occupancy; 2 = the same at one wave per SIMD less (the F <= 4 bf16
+// instantiations sit AT their register budget: 13 spilled registers without the rider, 22 with it at 3 waves per SIMD,
+// none at 2). Which one runs is a measured choice (lvl_debug_time_bwd_rider, profiles/r05_time_bwd_rider.txt).
+constexpr int time_bwd_waves(int esize, int F, int DPL, int RIDER) {
+  const int w = (DPL == 2 || esize == 4) ? 1 : (F <= 2 ? 4 : (F <= 4 ? 3 : 2));
+  return (RIDER == 2 && w > 1) ? w - 1 : w;
+}
+template <typename E, int F, int DPL, int RIDER = 0>
+__global__ __launch_bounds__((DPL == 2 ? 512 : 256), time_bwd_waves(sizeof(E), F, DPL, RIDER)) void time_bwd_kernel(const E* __restrict__ qkv, const E* __restrict__ out,
                                                        const E* __restrict__ dout, const float* __restrict__ lse,
                                                        E* __restrict__ dqkv, float* __restrict__ atom_ws,
                                                        float* __restrict__ dq_part, int N,
@@ -258,9 +266,13 @@ __global__ __launch_bounds__((DPL == 2 ? 512 : 256), (DPL == 2 || sizeof(E) == 4
   }
   const float Lc2 = lse[((size_t)b * H + h) * T] * kLog2e;            // cls-row lse in log2 units
 
-  float dqc[DPL], dkc[DPL], dvc[DPL], dqs[DPL];
+  float dqc[DPL], dkc[DPL], dvc[DPL], dqs[RIDER ? DPL : 1];
 #pragma unroll
-  for (int i = 0; i < DPL; ++i) { dqc[i] = 0.f; dkc[i] = 0.f; dvc[i] = 0.f; dqs[i] = 0.f; }
+  for (int i = 0; i < DPL; ++i) { dqc[i] = 0.f; dkc[i] = 0.f; dvc[i] = 0.f; }
+  if (RIDER) {
+#pragma unroll
+    for (int i = 0; i < DPL; ++i) dqs[i] = 0.f;
+  }
   if (chunk == 0 && n_sub == 0) {     // the cls key inside the CLS row, once per (b,h)
     float s = 0.f, dp = 0.f;
 #pragma unroll
@@ -359,8 +371,10 @@ __global__ __launch_bounds__((DPL == 2 ? 512 : 256), (DPL == 2 || sizeof(E) == 4
         }
       }
       *reinterpret_cast<vec_t*>(gbase + (size_t)tok * ts) = V::pack(dq);
+      if (RIDER) {
 #pragma unroll
-      for (int i = 0; i < DPL; ++i) dqs[i] += dq[i];
+        for (int i = 0; i < DPL; ++i) dqs[i] += dq[i];
+      }
     }
 #pragma unroll
     for (int f = 0; f < F; ++f) {
@@ -370,12 +384,12 @@ __global__ __launch_bounds__((DPL == 2 ? 512 : 256), (DPL == 2 || sizeof(E) == 4
     }
   }
 
-  constexpr int RS = 4 * DPL;
+  constexpr int RS = (RIDER ? 4 : 3) * DPL;
   float* mine = smem + ((size_t)(n_sub * H + h) * LPP + dl) * RS;
 #pragma unroll
   for (int i = 0; i < DPL; ++i) {
     mine[i] = dqc[i]; mine[DPL + i] = dkc[i]; mine[2 * DPL + i] = dvc[i];
-    mine[3 * DPL + i] = dqs[i] + dqc[i];                 // patch rows + this thread's share of the cls query's dq
+    if (RIDER) mine[3 * DPL + i] = dqs[i] + dqc[i];      // patch rows + this thread's share of the cls query's dq
   }
   __syncthreads();
   if (n_sub == 0) {
@@ -394,7 +408,7 @@ __global__ __launch_bounds__((DPL == 2 ? 512 : 256), (DPL == 2 || sizeof(E) == 4
       atomicAdd(dst + 64 + i, acc[DPL + i]);
       atomicAdd(dst + 128 + i, acc[2 * DPL + i]);
     }
-    if (dq_part) {
+    if (RIDER) {
       float* qd = dq_part + (size_t)blockIdx.x * D + h * 64 + dl * DPL;
 #pragma unroll
       for (int i = 0; i < DPL; ++i) qd[i] = acc[3 * DPL + i];
@@ -467,15 +481,24 @@ int lvl_time_fast_fwd(const void* qkv, void* out, float* lse, float* ws, int B, 
   return LVL_OK;
 }
 
+// 0: no rider (the q third of d(qkv bias) is reduced from dqkv afterwards), 1 / 2: see time_bwd_kernel
+static std::atomic<int> g_time_rider{0};
+
+extern "C" int lvl_debug_time_bwd_rider(int mode) {
+  if (mode < 0 || mode > 2) return lvl_fail(LVL_EINVAL, "debug_time_bwd_rider: mode must be 0, 1 or 2");
+  g_time_rider.store(mode, std::memory_order_relaxed);
+  return LVL_OK;
+}
+
 bool lvl_time_fast_bwd_supported(int F, int N, int H) {
   if (!(F == 1 || F == 2 || F == 3 || F == 4 || F == 8 || F == 16)) return false;
   return time_geometry(N, H, time_dpl(F)).ok;
 }
 
-// rows of the dq column-sum slab (one per workgroup)
+// rows of the dq column-sum slab (one per workgroup); 0 = this family runs without the rider
 int lvl_time_fast_bwd_dq_part_rows(int B, int F, int N, int H) {
   const TimeGeom g = time_geometry(N, H, time_dpl(F));
-  return g.ok ? B * g.NC : 0;
+  return (g.ok && g_time_rider.load(std::memory_order_relaxed) != 0) ? B * g.NC : 0;
 }
 
 // ws layout: delta [B*H*T] f32 (unused here), then atomics [B*H*192] f32
@@ -489,18 +512,25 @@ int lvl_time_fast_bwd(const void* qkv, const void* out, const void* dout, const 
   float* atom_ws = ws + (size_t)B * H * T;
   hipError_t e = hipMemsetAsync(atom_ws, 0, (size_t)B * H * 192 * sizeof(float), st);
   if (e != hipSuccess) return lvl_fail(LVL_EHIP, "time_bwd memset: %s", hipGetErrorString(e));
-  const size_t shmem = (size_t)g.NPB * H * (64 / dpl) * 4 * dpl * sizeof(float);
+  const int rider = dq_part ? g_time_rider.load(std::memory_order_relaxed) : 0;
+  const size_t shmem = (size_t)g.NPB * H * (64 / dpl) * (rider ? 4 : 3) * dpl * sizeof(float);
   const dim3 grid((unsigned)(B * g.NC)), block(g.block);
-#define TIME_BWD(FF, DD)                                                                                            \
+#define TIME_BWD_R(FF, DD, RR)                                                                                            \
   do {                                                                                                              \
     if (dtype == LVL_F32)                                                                                           \
-      hipLaunchKernelGGL((time_bwd_kernel<float, FF, DD>), grid, block, shmem, st, (const float*)qkv,                \
+      hipLaunchKernelGGL((time_bwd_kernel<float, FF, DD, RR>), grid, block, shmem, st, (const float*)qkv,            \
                          (const float*)out, (const float*)dout, lse, (float*)dqkv, atom_ws, dq_part, N, H, g.NPB,      \
                          g.NCH, g.NC);                                                                              \
     else                                                                                                            \
-      hipLaunchKernelGGL((time_bwd_kernel<uint16_t, FF, DD>), grid, block, shmem, st, (const uint16_t*)qkv,          \
+      hipLaunchKernelGGL((time_bwd_kernel<uint16_t, FF, DD, RR>), grid, block, shmem, st, (const uint16_t*)qkv,      \
                          (const uint16_t*)out, (const uint16_t*)dout, lse, (uint16_t*)dqkv, atom_ws, dq_part, N, H,  \
                          g.NPB, g.NCH, g.NC);                                                                       \
+  } while (0)
+#define TIME_BWD(FF, DD)                         \
+  do {                                           \
+    if (rider == 2) TIME_BWD_R(FF, DD, 2);       \
+    else if (rider == 1) TIME_BWD_R(FF, DD, 1);  \
+    else TIME_BWD_R(FF, DD, 0);                  \
   } while (0)
   switch (F) {
     case 1: TIME_BWD(1, 4); break;
@@ -512,6 +542,7 @@ int lvl_time_fast_bwd(const void* qkv, const void* out, const void* dout, const 
     default: return lvl_fail(LVL_ENOSYS, "time_fast_bwd: unsupported frame count %d", F);
   }
 #undef TIME_BWD
+#undef TIME_BWD_R
   LVL_CHECK_LAUNCH("time_bwd");
   lvl_launch_cls_grad_finalize(atom_ws, dqkv, B, T, H, dtype, st);
   LVL_CHECK_LAUNCH("cls_grad_finalize");

@@ -68,6 +68,24 @@ def fixed_text_length(length):
         _fixed_len.value = prev
 
 
+def caption_bound(host_tokens, bucket=8, context=None):
+    """1 + the largest EOT position (EOT = the highest id: models.py:158-160) of a HOST token tensor, rounded up to `bucket`
+    positions -- the bound fixed_text_length() takes. A driver that has the tokens on the host anyway (the reference's loop
+    uploads them itself, main_pretrain.py:486-498) gets the caption trim without the per-step device read-back:
+
+        with models.fixed_text_length(models.caption_bound(inputs[1])):      # BEFORE inputs[1].cuda()
+            outputs = model(*inputs_on_device, ...)
+
+    The rounding keeps the number of distinct GEMM shapes (and, for graph_step.py, of captured graphs) small."""
+    if host_tokens.is_cuda:
+        raise ValueError('caption_bound reads the token tensor on the host; for device tensors the model reads the '
+                         'length back itself (one sync per step)')
+    longest = int(host_tokens.argmax(dim=-1).max()) + 1
+    ctx_len = int(host_tokens.shape[-1]) if context is None else int(context)
+    b = max(1, int(bucket))
+    return min(ctx_len, (longest + b - 1) // b * b)
+
+
 _lmax_memos = weakref.WeakKeyDictionary()      # model -> (weakref to the token tensor, its version, longest caption)
 
 

@@ -206,10 +206,8 @@ def test_fp8_qk_end_to_end_bound_on_tsfl14_336():
     test_gpu_parity_bf16.py). e4m3 keeps 3 mantissa bits (RMS relative error 2^-4 / sqrt(3) = 3.6e-2 per element of q and
     k): a score sum_64 q_i k_i moves by 3.6e-2 * sqrt(2 / 64) |q||k| = 6.4e-3 |q||k|, i.e. ~0.1 in the softmax argument
     where |q||k| / 8 ~ 2-3 -- a ~10 % relative perturbation of every attention weight, averaged over 577 keys and over
-    16 heads per block: a few 1e-2 per block on the branch, sqrt(24) blocks. So: the fp8 path is expected at 2-4x the
-    bf16 path's distance; the bars below are what a training run can absorb (embeddings within 0.15 relative L2 of the
-    float32 reference, loss within 5e-2, gradient norms within 25 %), and the fp8 path may not be more than 6x further from
-    the reference than bf16 is. The measured distances are printed (pytest -s)."""
+    16 heads per block: about 1e-2 per block on the branch, sqrt(24) blocks. So: the fp8 path is expected at 1.5-4x the
+    bf16 path's distance. The measured distances are printed (pytest -s) and bound below."""
     from conftest import load_golden
     from helpers import build_model, fixture_weights
     from oracle.gen_golden import synthetic_inputs
@@ -251,7 +249,10 @@ def test_fp8_qk_end_to_end_bound_on_tsfl14_336():
     bf16, fp8 = run(False), run(True)
     print(f'[fp8 end to end, TSF-L/14@336] vs the float32 reference -- bf16: {bf16}; fp8 QK^T: {fp8}')
     assert fp8['embed'] != bf16['embed'], 'the fp8 switch had no effect on the model'
+    # measured (profiles/r05_fp8_end_to_end.txt): bf16 embeddings 1.2e-2 / loss 6e-4 / median gradient tensor 5.6e-2 (the
+    # predicted 1.7e-2 x (1..2) and its backward counterpart); fp8 QK^T 1.9e-2 / 7e-3 / 6.1e-2 -- 1.6x further on the
+    # embeddings, 1.1x on the gradients. Bars at ~2x the measurements.
     for r in (bf16, fp8):
-        assert r['embed'] < 0.15 and r['loss'] < 0.1 and r['norm_dev'] < 0.25, r
-    assert bf16['embed'] < 5e-2 and bf16['grad_rel_median'] < 0.3, bf16
-    assert fp8['embed'] <= 6 * bf16['embed'] + 1e-2 and fp8['grad_rel_median'] <= 6 * bf16['grad_rel_median'] + 2e-2, (bf16, fp8)
+        assert r['embed'] < 4e-2 and r['loss'] < 2e-2 and r['norm_dev'] < 2e-2, r
+    assert bf16['embed'] < 2.5e-2 and bf16['grad_rel_median'] < 0.12, bf16
+    assert fp8['embed'] <= 3 * bf16['embed'] and fp8['grad_rel_median'] <= 2 * bf16['grad_rel_median'], (bf16, fp8)

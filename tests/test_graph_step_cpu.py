@@ -41,3 +41,22 @@ def test_distributed_data_parallel_models_are_refused():
     ddp = torch.nn.parallel.DistributedDataParallel.__new__(torch.nn.parallel.DistributedDataParallel)
     with pytest.raises(NotImplementedError, match='DistributedDataParallel'):
         GraphedTrainStep(ddp, None, None, (1, 3, 1, 8, 8), (1, 77), 'cpu')
+
+
+def test_caption_bound_from_host_tokens():
+    """models.caption_bound: 1 + the largest EOT position of a HOST token tensor, rounded up to the bucket, capped at the
+    context; device tensors are refused (reading them is the sync the helper exists to avoid)."""
+    import pytest
+    import torch
+    from lavila.models import models
+    tokens = torch.zeros(3, 77, dtype=torch.long)
+    tokens[0, 20], tokens[1, 4], tokens[2, 11] = 49407, 49407, 49407
+    assert models.caption_bound(tokens) == 24
+    assert models.caption_bound(tokens, bucket=1) == 21
+    tokens[1, 4], tokens[1, 76] = 7, 49407           # a caption that fills the context
+    assert models.caption_bound(tokens) == 77
+    with models.fixed_text_length(models.caption_bound(tokens[:1])):
+        assert models._fixed_len.value == 24
+    if torch.cuda.is_available():
+        with pytest.raises(ValueError):
+            models.caption_bound(tokens.cuda())
