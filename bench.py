@@ -400,6 +400,13 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 or os.environ.get('LAVILA_BENCH_ONE_RANK_RCCL') == '1':
+        # A rank of a multi-GPU job: the RCCL communicator creates streams of its own, and HIP maps all streams of a process
+        # onto 4 hardware queues by default -- the text tower's side stream then shares a queue with the main stream and its
+        # overlap (worth 4 % of the step) is gone: +4.4 % step time with a communicator alive and nothing on the wire, 0.0 %
+        # with 8 queues (same-box A/B, profiles/r05_one_rank_group_bisect.txt). Read by the HIP runtime at its
+        # initialisation, so it is set before the first device call of the process. INTEGRATION.md section 4.
+        os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
     if world != args.gpus:
         raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}')
     assert torch.cuda.is_available(), 'bench.py needs MI355X GPUs (there is no CPU path)'

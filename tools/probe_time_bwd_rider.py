@@ -43,4 +43,4 @@ for rider in (0, 1, 2, 0, 1, 2):
             ref = db.clone()
         err = ((db - ref).abs().max() / ref.abs().max()).item()
         print(f'rider={rider} token={int(with_tok)}: {s.elapsed_time(e) / 20:.4f} ms per backward + bias gradient  (d bias vs first variant: {err:.1e})')
-C.lib().lvl_debug_time_bwd_rider(0)
+C.lib().lvl_debug_time_bwd_rider(-1)
