@@ -12,6 +12,8 @@
 // workgroup through LDS and across workgroups by cls_combine_kernel (attn_space_mfma.hip). In the backward
 // the CLS row's rank-1 terms are folded into dk/dv, and d(cls q), d(cls k), d(cls v) -- which collect
 // gradient from every location -- go through LDS + f32 atomics into a workspace (cls_grad_finalize_kernel).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -485,9 +487,14 @@ int lvl_time_fast_fwd(const void* qkv, void* out, float* lse, float* ws, int B, 
 // against 0.59-0.62 without the rider and 0.61 with it at 3 waves per SIMD; the spill-free kernel is faster than the
 // 13-spill one even before the saved pass, profiles/r05_time_bwd_rider.txt), 1 elsewhere (those instantiations have
 // registers to spare); 0: no rider (the q third of d(qkv bias) is reduced from dqkv afterwards); 1 / 2: see time_bwd_kernel
-static std::atomic<int> g_time_rider{-1};
+static std::atomic<int> g_time_rider{-2};          // -2: not read yet (LAVILA_TIME_BWD_RIDER in the environment, A/B runs)
 static int time_rider_mode(int F) {
-  const int m = g_time_rider.load(std::memory_order_relaxed);
+  int m = g_time_rider.load(std::memory_order_relaxed);
+  if (m == -2) {
+    const char* e = getenv("LAVILA_TIME_BWD_RIDER");
+    m = (e && e[0] >= '0' && e[0] <= '2' && !e[1]) ? e[0] - '0' : -1;
+    g_time_rider.store(m, std::memory_order_relaxed);
+  }
   return m >= 0 ? m : (F == 4 ? 2 : 1);
 }
 

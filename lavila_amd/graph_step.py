@@ -232,7 +232,12 @@ class GraphedTrainStep:
         grads = [p.grad for p in self.model.parameters() if p.grad is not None]
 
         def reduce():
-            dist.all_reduce_coalesced(grads, op=dist.ReduceOp.SUM)
+            if dist.get_backend() == 'nccl':               # RCCL: one grouped launch over the gradients in place
+                dist.all_reduce_coalesced(grads, op=dist.ReduceOp.SUM)
+            else:                                          # gloo (tests on one device): through one flat buffer
+                flat = torch._utils._flatten_dense_tensors(grads)
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+                torch._foreach_copy_(grads, torch._utils._unflatten_dense_tensors(flat, grads))
             if self.world > 1:
                 torch._foreach_div_(grads, float(self.world))
         seg = active_segments()
