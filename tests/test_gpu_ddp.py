@@ -394,10 +394,10 @@ def test_graphed_step_with_a_process_group_matches_the_ddp_loop_two_ranks():
     runs main_pretrain.py's eager DDP loop on one copy of the model and GraphedTrainStep on the bare module: the captured
     iteration is a chain of FOUR graph segments with the loss's two all-gathers and the gradient all-reduce between them.
     Losses agree step by step (same kernels; rounding noise of the cls-row atomics), parameters after four AdamW steps agree
-    in aggregate, both ranks hold the same parameters, and the three later calls were replays."""
+    in aggregate, both ranks hold the same parameters, and the three later calls were replays of the chain."""
     got = _run_graph_workers(2, 'gloo')
     for r in got:
-        assert r['replays'] == 2 and list(r['segments'].values()) == [4], r        # call 0 eager, call 1 capture, 2 replays
+        assert r["replays"] == 3 and list(r["segments"].values()) == [4], r        # call 0 eager, call 1 capture + replay, 2 replays
         for a, b in zip(r['eager'], r['graphed']):
             assert abs(a - b) <= 4e-3 * abs(a) + 1e-4, r
         assert r['max_param_diff'] <= 2 * 4 * 1e-3 + 1e-6 and r['frac_moved_apart'] < 0.02, r
@@ -411,6 +411,6 @@ def test_graphed_step_segments_replay_beside_a_live_rccl_communicator():
     the collectives were INSIDE the capture, round 4)."""
     got = _run_graph_workers(1, 'nccl')
     r = got[0]
-    assert r['replays'] == 2 and list(r['segments'].values()) == [2], r           # world 1: no loss gathers, one all-reduce
+    assert r["replays"] == 3 and list(r["segments"].values()) == [2], r           # world 1: no loss gathers, one all-reduce
     for a, b in zip(r['eager'], r['graphed']):
         assert abs(a - b) <= 4e-3 * abs(a) + 1e-4, r
