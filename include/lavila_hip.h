@@ -110,6 +110,13 @@ int lvl_patchify(const float* video, void* patches, int B, int C, int F, int H, 
  * x: [B,1+F*N,D] dtype. D % 8 == 0. */
 int lvl_embed_tokens_fwd(const void* pe, const float* cls, const float* pos, const float* temporal,
                          void* x, int B, int F, int N, int D, int dtype, void* stream);
+/* lvl_embed_tokens_bwd (round 5): the parameter gradients of the token assembly from dx [B, 1 + F N, D] (autograd of
+ * timesformer.py:353-366): dpos [N + 1, D] f32 (row 0 = the cls position = d cls_token, row 1 + n summed over batch and
+ * frames), dtem [tem_rows, D] f32 (row f summed over batch and locations; rows >= F zero). One pass over dx + a small
+ * second stage; d(patch embeddings) is dx[:, 1:] itself. ws: lvl_embed_tokens_bwd_ws(F, N, D) floats. */
+int64_t lvl_embed_tokens_bwd_ws(int F, int N, int D);
+int lvl_embed_tokens_bwd(const void* dx, float* dpos, float* dtem, float* ws, int B, int F, int N, int D, int tem_rows,
+                         int dtype, void* stream);
 
 /* ---- divided space-time attention core ---------------------------------------------------------------
  * Everything in VarAttention.forward between the qkv Linear and the proj Linear

@@ -190,6 +190,65 @@ __global__ __launch_bounds__(256) void embed_tokens_kernel(const T* __restrict__
   }
 }
 
+// ---- backward of the token assembly: d pos_embed, d temporal_embed, d cls_token from d x ----------------------------------
+// (timesformer.py:353-366 under autograd: pos / temporal rows are broadcast over the batch and over frames / locations.)
+// Stage 1: P[c][t][:] = sum over the c-th quarter of the batch of dx[b, t, :]  (one pass over dx, f32 partials);
+// stage 2: dpos[0] = sum_c P[c][0] (= d cls_token), dpos[1 + n] = sum_{c,f} P[c][1 + f N + n], dtem[f] = sum_{c,n} P[c][1 + f N + n].
+constexpr int kEmbedBwdChunks = 4;
+template <typename T>
+__global__ __launch_bounds__(128) void embed_bwd_stage1_kernel(const T* __restrict__ dx, float* __restrict__ part, int B,
+                                                               int T_, int D) {
+  const int t = blockIdx.x, c = blockIdx.y;
+  const int nvec = D >> 3;
+  const int b0 = (int)((int64_t)B * c / kEmbedBwdChunks), b1 = (int)((int64_t)B * (c + 1) / kEmbedBwdChunks);
+  for (int vc = threadIdx.x; vc < nvec; vc += blockDim.x) {
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const T* base = dx + (int64_t)t * D + vc * 8;
+    int b = b0;
+    for (; b + 3 < b1; b += 4) {
+      float x[4][8];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) Elem<T>::load8(base + (int64_t)(b + k) * T_ * D, x[k]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += x[k][j];
+    }
+    for (; b < b1; ++b) {
+      float x[8];
+      Elem<T>::load8(base + (int64_t)b * T_ * D, x);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += x[j];
+    }
+    float* dst = part + ((int64_t)c * T_ + t) * D + vc * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dst[j] = acc[j];
+  }
+}
+
+__global__ __launch_bounds__(256) void embed_bwd_stage2_kernel(const float* __restrict__ part, float* __restrict__ dpos,
+                                                               float* __restrict__ dtem, int F, int N, int D,
+                                                               int tem_rows) {
+  const int T_ = 1 + F * N, r = blockIdx.x;
+  for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    float acc = 0.f;
+    if (r <= N) {                                        // positional row r (row 0 = the cls position)
+      for (int c = 0; c < kEmbedBwdChunks; ++c) {
+        if (r == 0) acc += part[((int64_t)c * T_) * D + d];
+        else
+          for (int f = 0; f < F; ++f) acc += part[((int64_t)c * T_ + 1 + f * N + (r - 1)) * D + d];
+      }
+      dpos[(int64_t)r * D + d] = acc;
+    } else {                                             // temporal row f (rows beyond the clip's frames: zero)
+      const int f = r - (N + 1);
+      if (f < F)
+        for (int c = 0; c < kEmbedBwdChunks; ++c)
+          for (int n = 0; n < N; ++n) acc += part[((int64_t)c * T_ + 1 + f * N + n) * D + d];
+      if (f < tem_rows) dtem[(int64_t)f * D + d] = acc;
+    }
+  }
+}
+
 inline unsigned grid_for(int64_t total, int block) {
   int64_t g = (total + block - 1) / block;
   if (g > 16384) g = 16384;
@@ -391,6 +450,24 @@ extern "C" int lvl_embed_tokens_fwd(const void* pe, const float* cls, const floa
                                                (hipStream_t)stream, (const T*)pe, cls, pos, temporal, (T*)x, B, F, N,
                                                D));
   LVL_CHECK_LAUNCH("embed_tokens_fwd");
+  return LVL_OK;
+}
+
+extern "C" int64_t lvl_embed_tokens_bwd_ws(int F, int N, int D) { return (int64_t)kEmbedBwdChunks * (1 + (int64_t)F * N) * D; }
+
+extern "C" int lvl_embed_tokens_bwd(const void* dx, float* dpos, float* dtem, float* ws, int B, int F, int N, int D,
+                                    int tem_rows, int dtype, void* stream) {
+  LVL_REQUIRE(dx && dpos && dtem && ws, "embed_tokens_bwd: null pointer");
+  LVL_REQUIRE(B > 0 && F > 0 && N > 0 && D > 0 && D % 8 == 0 && tem_rows >= F,
+              "embed_tokens_bwd: bad shape B=%d F=%d N=%d D=%d tem_rows=%d", B, F, N, D, tem_rows);
+  LVL_REQUIRE(lvl_aligned16(dx) && lvl_aligned16(ws), "embed_tokens_bwd: pointers must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  const int T_ = 1 + F * N;
+  LVL_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((embed_bwd_stage1_kernel<T>), dim3((unsigned)T_, kEmbedBwdChunks), dim3(128),
+                                               0, st, (const T*)dx, ws, B, T_, D));
+  hipLaunchKernelGGL(embed_bwd_stage2_kernel, dim3((unsigned)(N + 1 + tem_rows)), dim3(256), 0, st, ws, dpos, dtem, F, N, D,
+                     tem_rows);
+  LVL_CHECK_LAUNCH("embed_tokens_bwd");
   return LVL_OK;
 }
 

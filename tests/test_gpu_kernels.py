@@ -153,9 +153,11 @@ def test_patchify_and_patch_embed(dt, B, Fr, img, P):
 
 
 @pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
-def test_embed_tokens(dt):
+@pytest.mark.parametrize('B,Fr,N,D,num_frames', [(3, 2, 5, 128, 4), (5, 4, 196, 768, 4), (2, 1, 7, 64, 1), (9, 3, 33, 256, 8)])
+def test_embed_tokens(dt, B, Fr, N, D, num_frames):
+    """Forward (cls concat + positional / temporal add) and, round 5, the backward on lvl_embed_tokens_bwd (one pass over dx:
+    d pos_embed, d temporal_embed incl. zero rows beyond the clip's frames, d cls_token) against autograd of the oracle."""
     from lavila_amd import ops
-    B, Fr, N, D, num_frames = 3, 2, 5, 128, 4
     g = torch.Generator().manual_seed(5)
     pe = _r(torch.randn(B, Fr * N, D, generator=g), dt)
     cls, pos, tem = (0.5 * torch.randn(s, generator=g) for s in ((1, 1, D), (1, N + 1, D), (1, num_frames, D)))
