@@ -901,6 +901,9 @@ def patchify(video: torch.Tensor, patch: int, dtype: torch.dtype, frame_major: b
     return out
 
 
+EMBED_BWD_KERNEL = os.environ.get('LAVILA_EMBED_BWD_KERNEL', '1') != '0'      # 0: framework reductions (A/B)
+
+
 class _EmbedTokensFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pe, cls_token, pos_embed, temporal_embed, frames, n_per_frame):
@@ -919,7 +922,7 @@ class _EmbedTokensFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dx):
         B, Fr, N, D, num_frames = ctx.dims
-        if dx.is_cuda and dx.dtype in (torch.bfloat16, torch.float32) and D % 8 == 0 and B > 0:
+        if EMBED_BWD_KERNEL and dx.is_cuda and dx.dtype in (torch.bfloat16, torch.float32) and D % 8 == 0 and B > 0:
             # one pass over dx (lvl_embed_tokens_bwd) instead of a float32 copy of it and three framework reductions
             dx = dx.contiguous()
             dpos = torch.empty(1, N + 1, D, dtype=torch.float32, device=dx.device)
@@ -927,8 +930,10 @@ class _EmbedTokensFn(torch.autograd.Function):
             ws = torch.empty(int(C.lib().lvl_embed_tokens_bwd_ws(Fr, N, D)), dtype=torch.float32, device=dx.device)
             C.check(C.lib().lvl_embed_tokens_bwd(C.ptr(dx), C.ptr(dpos), C.ptr(dtem), C.ptr(ws), B, Fr, N, D, num_frames,
                                                  C.dtype_code(dx), C.stream_ptr()), 'lvl_embed_tokens_bwd')
-            return (dx[:, 1:], dpos[:, 0].reshape(1, 1, D).to(ctx.pdt[0]), dpos.to(ctx.pdt[1]), dtem.to(ctx.pdt[2]),
-                    None, None)
+            # d cls_token is its own tensor, NOT a view of dpos: GradScaler.unscale_ / clip_grad_norm_ scale gradients in
+            # place, and two parameters sharing gradient storage would be scaled twice (caught by test_grad_scaler_step_*)
+            return (dx[:, 1:], dpos[:, 0].reshape(1, 1, D).to(ctx.pdt[0], copy=True), dpos.to(ctx.pdt[1]),
+                    dtem.to(ctx.pdt[2]), None, None)
         body = dx[:, 1:].reshape(B, Fr, N, D).float()
         d0 = dx[:, 0].float().sum(0)                                    # cls row: d cls_token = d pos[0]
         dpos = torch.cat([d0[None], body.sum((0, 1))], 0)[None]         # [1, N+1, D]
