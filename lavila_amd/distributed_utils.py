@@ -24,13 +24,17 @@ def all_gather_rows(t: torch.Tensor, group=None) -> torch.Tensor:
     world = dist.get_world_size(group)
     out = t.new_empty((world * t.shape[0],) + tuple(t.shape[1:]))
     src = t.contiguous()
-    if t.is_cuda and torch.cuda.is_current_stream_capturing():
-        from .graph_step import active_segments
-        seg = active_segments()
-        if seg is None:
-            raise RuntimeError('all_gather_rows inside a hipGraph capture that lavila_amd.graph_step does not own: '
-                               'collectives are kept between graph segments (GraphedTrainStep), not captured')
-        seg.eager(lambda: _all_gather(out, src, group))
+    if t.is_cuda:
+        from .graph_step import active_segments, run_on_collective_stream
+        op = lambda: run_on_collective_stream(lambda: _all_gather(out, src, group))      # noqa: E731
+        if torch.cuda.is_current_stream_capturing():
+            seg = active_segments()
+            if seg is None:
+                raise RuntimeError('all_gather_rows inside a hipGraph capture that lavila_amd.graph_step does not own: '
+                                   'collectives are kept between graph segments (GraphedTrainStep), not captured')
+            seg.eager(op)
+        else:
+            op()          # inside a GraphedTrainStep iteration: on its communication stream; otherwise the current stream
         return out
     _all_gather(out, src, group)
     return out

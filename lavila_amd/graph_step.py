@@ -57,6 +57,28 @@ def active_segments():
     return getattr(_active, 'seg', None)
 
 
+def collective_stream():
+    """The side stream a GraphedTrainStep iteration on this thread wants its collectives on (None otherwise)."""
+    return getattr(_active, 'comm', None)
+
+
+def run_on_collective_stream(fn):
+    """Run the collective `fn` on the step's COMMUNICATION stream, ordered behind and in front of the current stream.
+    Why not on the step's own stream: ProcessGroupNCCL records the completion event of a synchronous collective on the
+    stream it ran on, its watchdog thread polls that event until it has seen it complete -- and HIP refuses to query an
+    event whose stream is capturing at that moment (hipErrorCapturedEvent -> the watchdog throws -> the process aborts;
+    seen once in three runs of the suite with the collectives on the capture stream). A stream that never captures makes
+    the poll harmless whenever it happens."""
+    comm = collective_stream()
+    if comm is None:
+        return fn()
+    cur = torch.cuda.current_stream()
+    comm.wait_stream(cur)
+    with torch.cuda.stream(comm):
+        fn()
+    cur.wait_stream(comm)
+
+
 class _Segments:
     """graph | eager op | graph | ... recorded while ONE iteration runs under capture; replay() runs them in order.
     Every segment allocates from the same private pool (tensors that cross a segment boundary -- activations saved for the
@@ -83,7 +105,7 @@ class _Segments:
         replay at this point of the chain, start the next segment."""
         self.end()
         fn()
-        torch.cuda.current_stream().synchronize()      # nothing of the collective is pending when the capture resumes
+        torch.cuda.synchronize()                       # nothing of the collective is pending when the capture resumes
         self.items.append(fn)
         self.begin()
 
@@ -152,6 +174,7 @@ class GraphedTrainStep:
         # data parallel without the DDP wrapper: collectives between graph segments, gradients averaged here
         self.distributed = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size() if self.distributed else 1
+        self._comm = None            # the collectives' own stream (run_on_collective_stream), created with the step stream
         if self.distributed and broadcast_parameters:
             with torch.no_grad():
                 for t in list(self.model.parameters()) + list(self.model.buffers()):
@@ -161,6 +184,8 @@ class GraphedTrainStep:
         # anything that still references that iteration's autograd graph) would otherwise run on a stream outside the
         # capture -- which ends the capture with a crash inside hipStreamEndCapture, not with an error.
         self._stream = stream if stream is not None else torch.cuda.Stream(device=self.device)
+        if self.distributed:
+            self._comm = torch.cuda.Stream(device=self.device)
         self._eager_left = int(eager_calls) if eager_calls is not None else 1
         self.replays = 0
 
@@ -205,10 +230,15 @@ class GraphedTrainStep:
         if entry is None:
             entry = self._graphs[L] = self._capture(L)
         if self.distributed:
-            with torch.cuda.stream(self._stream):          # eager collectives between the segments: on the step's stream
-                self._stream.wait_stream(torch.cuda.current_stream(self.device))
-                entry[0].replay()
-            torch.cuda.current_stream(self.device).wait_stream(self._stream)
+            cur = torch.cuda.current_stream(self.device)
+            self._stream.wait_stream(cur)
+            with torch.cuda.stream(self._stream):          # graph segments on the step's stream, collectives on its side stream
+                _active.comm = self._comm
+                try:
+                    entry[0].replay()
+                finally:
+                    _active.comm = None
+            cur.wait_stream(self._stream)
         else:
             entry[0].replay()
         self.replays += 1
@@ -240,11 +270,12 @@ class GraphedTrainStep:
                 torch._foreach_copy_(grads, torch._utils._unflatten_dense_tensors(flat, grads))
             if self.world > 1:
                 torch._foreach_div_(grads, float(self.world))
+        op = lambda: run_on_collective_stream(reduce)      # noqa: E731
         seg = active_segments()
         if seg is not None:
-            seg.eager(reduce)
+            seg.eager(op)
         else:
-            reduce()
+            op()
 
     def _iteration(self, L):
         with _models.fixed_text_length(L):
@@ -265,7 +296,11 @@ class GraphedTrainStep:
         self._stream.wait_stream(cur)
         with torch.cuda.stream(self._stream):
             self.optimizer.zero_grad(set_to_none=True)
-            out = self._iteration(L)
+            _active.comm = self._comm
+            try:
+                out = self._iteration(L)
+            finally:
+                _active.comm = None
             self.optimizer.zero_grad(set_to_none=True)
         cur.wait_stream(self._stream)
         for v in out.values():
@@ -291,13 +326,13 @@ class GraphedTrainStep:
         cur = torch.cuda.current_stream(self.device)
         self._stream.wait_stream(cur)
         with torch.cuda.stream(self._stream):
-            _active.seg = seg
+            _active.seg, _active.comm = seg, self._comm
             try:
                 seg.begin()
                 out = self._iteration(L)
                 seg.end()
             finally:
-                _active.seg = None
+                _active.seg = _active.comm = None
         cur.wait_stream(self._stream)
         return seg, out
 
