@@ -485,14 +485,14 @@ def main():
     if (world > 1 or force_group) and os.environ.get('LAVILA_BENCH_NO_DDP') != '1':     # NO_DDP: bisecting the wrapper's cost
         net = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev_index], bucket_cap_mb=200,
                                                         gradient_as_bucket_view=os.environ.get('LAVILA_BENCH_NO_BUCKET_VIEW') != '1')
-    if net is not model and os.environ.get('LAVILA_BENCH_DDP_HOOK', 'allreduce') != 'none':
+    if net is not model and os.environ.get('LAVILA_BENCH_DDP_HOOK', 'none') != 'none':
         # DDP's default path divides every gradient by the world size in its own elementwise launch from the autograd hook
         # (180 four-microsecond launches per step here: profiles/r05_bench_kernel_stats_ddp_serial.csv); with a communication
         # hook registered DDP leaves the scaling to the hook, which divides the BUCKET once (4 launches per step).
         # allreduce_hook is torch's own restatement of the default all-reduce; bf16_compress_hook also halves the bytes on
         # xGMI (gradients cross the links in bf16, are accumulated into the float32 buckets on arrival). INTEGRATION.md section 4.
         from torch.distributed.algorithms.ddp_comm_hooks import default_hooks as _hooks
-        hook = {'allreduce': _hooks.allreduce_hook, 'bf16': _hooks.bf16_compress_hook}[os.environ.get('LAVILA_BENCH_DDP_HOOK', 'allreduce')]
+        hook = {'allreduce': _hooks.allreduce_hook, 'bf16': _hooks.bf16_compress_hook}[os.environ['LAVILA_BENCH_DDP_HOOK']]
         net.register_comm_hook(None, hook)
     crit = CLIPLoss(use_vissl=True, cache_labels=True, rank=rank, world_size=world)
     decay = [p for n, p in model.named_parameters() if not (p.ndim < 2 or 'bias' in n or 'ln' in n or 'bn' in n)]

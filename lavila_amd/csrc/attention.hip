@@ -179,8 +179,7 @@ extern "C" int lvl_divided_attn_bwd_bias(const void* qkv, const void* out, const
   const int D = H * 64;
   const int64_t rows = (int64_t)B * (1 + (int64_t)F * N);
   if (B == 0) {
-    hipError_t e = hipMemsetAsync(dbias, 0, (size_t)3 * D * sizeof(float), st);
-    return e == hipSuccess ? LVL_OK : lvl_fail(LVL_EHIP, "divided_attn_bwd_bias memset: %s", hipGetErrorString(e));
+    return lvl_zero_f32(dbias, (size_t)3 * D, st);
   }
   int part_rows;
   bwd_family(B, F, N, H, mode, dtype, &part_rows);

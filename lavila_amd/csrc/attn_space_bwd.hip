@@ -885,8 +885,7 @@ int lvl_space_mfma_bwd(const void* qkv, const void* out, const void* dout, const
   const int T = 1 + F * N;
   float* delta = ws;
   float* atom_ws = ws + (size_t)B * H * T;
-  hipError_t e = hipMemsetAsync(atom_ws, 0, (size_t)B * H * 192 * sizeof(float), st);
-  if (e != hipSuccess) return lvl_fail(LVL_EHIP, "space_bwd memset: %s", hipGetErrorString(e));
+  if (int rc = lvl_zero_f32(atom_ws, (size_t)B * H * 192, st)) return rc;      // a kernel, not a memset node: common.h
   if (N + 1 <= kFusedPairs * 32) {
     if (int rc = dtype == LVL_F32 ? dispatch_fused<PrecSplit>(qkv, out, dout, lse, dqkv, atom_ws, dq_part, B, F, N, H, st)
                                   : dispatch_fused<PrecBf16>(qkv, out, dout, lse, dqkv, atom_ws, dq_part, B, F, N, H, st))

@@ -1023,8 +1023,7 @@ int lvl_space_stream_bwd(const void* qkv, const void* out, const void* dout, con
   const int T = 1 + F * N;
   float* delta = ws;
   float* atom_ws = ws + (size_t)B * H * T;
-  hipError_t e = hipMemsetAsync(atom_ws, 0, (size_t)B * H * 192 * sizeof(float), st);
-  if (e != hipSuccess) return lvl_fail(LVL_EHIP, "space_stream_bwd memset: %s", hipGetErrorString(e));
+  if (int rc = lvl_zero_f32(atom_ws, (size_t)B * H * 192, st)) return rc;      // a kernel, not a memset node: common.h
   const int rc = dtype == LVL_F32
                      ? launch_stream_bwd<PrecSplit>(qkv, out, dout, lse, dqkv, delta, atom_ws, B, F, N, H, st)
                  : fp8_qk() ? launch_stream_bwd<PrecFp8QK>(qkv, out, dout, lse, dqkv, delta, atom_ws, B, F, N, H, st)

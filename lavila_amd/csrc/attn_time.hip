@@ -524,8 +524,7 @@ int lvl_time_fast_bwd(const void* qkv, const void* out, const void* dout, const 
   if (!g.ok) return lvl_fail(LVL_ENOSYS, "time_fast_bwd: unsupported head count %d", H);
   const int T = 1 + F * N;
   float* atom_ws = ws + (size_t)B * H * T;
-  hipError_t e = hipMemsetAsync(atom_ws, 0, (size_t)B * H * 192 * sizeof(float), st);
-  if (e != hipSuccess) return lvl_fail(LVL_EHIP, "time_bwd memset: %s", hipGetErrorString(e));
+  if (int rc = lvl_zero_f32(atom_ws, (size_t)B * H * 192, st)) return rc;      // a kernel, not a memset node: common.h
   const int rider = dq_part ? time_rider_mode(F) : 0;
   const size_t shmem = (size_t)g.NPB * H * (64 / dpl) * (rider ? 4 : 3) * dpl * sizeof(float);
   const dim3 grid((unsigned)(B * g.NC)), block(g.block);

@@ -434,8 +434,7 @@ int lvl_time_mfma_bwd(const void* qkv, const void* out, const void* dout, const 
   const Geo g = geometry(N);
   const int T = 1 + F * N;
   float* atom_ws = ws + (size_t)B * H * T;
-  hipError_t e = hipMemsetAsync(atom_ws, 0, (size_t)B * H * 192 * sizeof(float), st);
-  if (e != hipSuccess) return lvl_fail(LVL_EHIP, "time_mfma_bwd memset: %s", hipGetErrorString(e));
+  if (int rc = lvl_zero_f32(atom_ws, (size_t)B * H * 192, st)) return rc;      // a kernel, not a memset node: common.h
   if (int rc = lvl_allow_lds<time_mfma_bwd_kernel>()) return rc;
   hipLaunchKernelGGL(time_mfma_bwd_kernel, dim3((unsigned)(B * g.NC * (H / NWV))), dim3(NWV * 64),
                      NWV * (4 * IMG + 16 * OS) * sizeof(uint16_t), st,

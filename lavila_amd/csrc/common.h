@@ -30,6 +30,12 @@ int lvl_fail(int code, const char* fmt, ...);
 
 static inline bool lvl_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// Zero n floats with a KERNEL (core.hip). Not hipMemsetAsync: a memset node inside a replayed hipGraph is not reliable on
+// this ROCm build -- the replay's fill takes its 16-byte pattern from memory that has been handed to somebody else by then
+// (found by NaN-poisoning free device memory between two replays: the "zeroed" accumulators came back as {0, NaN, 0, 0}
+// repeated; tools/probe_graph_step_poison.py, profiles/r05_graph_memset_nodes.txt).
+int lvl_zero_f32(float* p, size_t n, hipStream_t st);
+
 // Kernels that use more than 64 KiB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised once.
 // compute units the persistent kernels size their grids for: the device's, or the limit set by lvl_set_compute_units
 int lvl_persistent_cus();

@@ -53,6 +53,26 @@ extern "C" int lvl_debug_late_workgroups(int mod) {
   return LVL_OK;
 }
 
+__global__ __launch_bounds__(256) void zero_f32_kernel(float* __restrict__ p, size_t n) {
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (((reinterpret_cast<uintptr_t>(p) & 15) | (n & 3)) == 0) {
+    float4* p4 = reinterpret_cast<float4*>(p);
+    for (const size_t n4 = n >> 2; i < n4; i += stride) p4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  } else {
+    for (; i < n; i += stride) p[i] = 0.f;
+  }
+}
+
+int lvl_zero_f32(float* p, size_t n, hipStream_t st) {
+  if (n == 0) return LVL_OK;
+  const size_t want = (n / 4 + 255) / 256;
+  const unsigned blocks = (unsigned)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+  hipLaunchKernelGGL(zero_f32_kernel, dim3(blocks), dim3(256), 0, st, p, n);
+  LVL_CHECK_LAUNCH("zero_f32");
+  return LVL_OK;
+}
+
 extern "C" const char* lvl_version(void) { return "lavila_hip 0.1 (gfx950)"; }
 extern "C" const char* lvl_last_error(void) { return lvl_err_buf; }
 

@@ -589,8 +589,7 @@ extern "C" int lvl_qkv_bias_grad(const void* dqkv, const void* dout, float* dbia
   LVL_REQUIRE(rows >= 0 && D > 0 && D % 8 == 0, "qkv_bias_grad: D=%d must be a multiple of 8", D);
   LVL_REQUIRE(lvl_aligned16(dqkv) && lvl_aligned16(dout), "qkv_bias_grad: pointers must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(dbias, 0, (size_t)3 * D * sizeof(float), st);      // the k third is exactly 0
-  if (e != hipSuccess) return lvl_fail(LVL_EHIP, "qkv_bias_grad memset: %s", hipGetErrorString(e));
+  if (int rc = lvl_zero_f32(dbias, (size_t)3 * D, st)) return rc;      // the k third is exactly 0 (a kernel, not a memset node)
   if (rows == 0) return LVL_OK;
   int64_t gy = rows < kBiasGradRowBlocks ? rows : kBiasGradRowBlocks;
   const dim3 grid((unsigned)((D / 8 + 127) / 128), (unsigned)gy, 2);

@@ -40,6 +40,7 @@ does; parameters are broadcast from rank 0 once. What a rank loses against DDP i
 with the backward (one coalesced all-reduce after it: ~4 ms of 172 on an 8-GPU xGMI ring); what it
 gains is a host that issues ~5 launches per step instead of ~1100.
 """
+import os
 import threading
 
 import torch
@@ -110,11 +111,16 @@ class _Segments:
         self.begin()
 
     def replay(self):
+        dbg = os.environ.get('LAVILA_GRAPH_DEBUG_SYNC') == '1'      # diagnosis: device-wide sync around every item
         for it in self.items:
+            if dbg:
+                torch.cuda.synchronize()
             if isinstance(it, torch.cuda.CUDAGraph):
                 it.replay()
             else:
                 it()
+        if dbg:
+            torch.cuda.synchronize()
 
     @property
     def graphs(self):
@@ -184,7 +190,7 @@ class GraphedTrainStep:
         # anything that still references that iteration's autograd graph) would otherwise run on a stream outside the
         # capture -- which ends the capture with a crash inside hipStreamEndCapture, not with an error.
         self._stream = stream if stream is not None else torch.cuda.Stream(device=self.device)
-        if self.distributed:
+        if self.distributed and os.environ.get('LAVILA_GRAPH_COMM_STREAM', '1') != '0':
             self._comm = torch.cuda.Stream(device=self.device)
         self._eager_left = int(eager_calls) if eager_calls is not None else 1
         self.replays = 0
@@ -264,6 +270,9 @@ class GraphedTrainStep:
         def reduce():
             if dist.get_backend() == 'nccl':               # RCCL: one grouped launch over the gradients in place
                 dist.all_reduce_coalesced(grads, op=dist.ReduceOp.SUM)
+            elif os.environ.get('LAVILA_GRAPH_REDUCE') == 'pertensor':      # diagnosis
+                for g_ in grads:
+                    dist.all_reduce(g_, op=dist.ReduceOp.SUM)
             else:                                          # gloo (tests on one device): through one flat buffer
                 flat = torch._utils._flatten_dense_tensors(grads)
                 dist.all_reduce(flat, op=dist.ReduceOp.SUM)

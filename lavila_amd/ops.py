@@ -200,10 +200,13 @@ def _wgrad(dy2, x2, wdt):
     """dW = dy^T x: the MFMA weight-gradient kernel; shapes it does not tile fall back to a library GEMM (logged)."""
     rows, n_out, n_in = dy2.shape[0], dy2.shape[1], x2.shape[1]
     ws_floats = -1
-    if (rows >= 32 and dy2.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16 and dy2.is_contiguous()
+    if (rows > 0 and dy2.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16 and dy2.is_contiguous()
             and x2.is_contiguous() and dy2.is_cuda):
         ws_floats = C.lib().lvl_workspace_floats(b'linear_wgrad', n_out, n_in)
     if ws_floats >= 0:
+        if rows < 32:       # the class-token / EOT-row Linears of a small batch: zero rows up to the kernel's one 32-row step
+            dy2 = torch.cat([dy2, dy2.new_zeros(32 - rows, n_out)])
+            x2 = torch.cat([x2, x2.new_zeros(32 - rows, n_in)])
         return linear_wgrad_raw(dy2, x2, False, int(ws_floats))[0].to(wdt)
     if dy2.dtype == torch.bfloat16 and rows >= 4096:
         warn_once(('wgrad', n_out, n_in), f'weight gradient [{n_out},{n_in}] falls back to a library GEMM '

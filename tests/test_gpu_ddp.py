@@ -328,29 +328,64 @@ def _graph_worker(rank, world, port, backend, q):
         model_g = copy.deepcopy(model_e)
         ddp = torch.nn.parallel.DistributedDataParallel(model_e, device_ids=[0])
         crit = CLIPLoss(use_vissl=True, cache_labels=True, rank=rank, world_size=world)
+        crit_e = crit
+        if os.environ.get('LAVILA_TEST_SEPARATE_CRIT') == '1':          # diagnosis switches
+            crit_e = CLIPLoss(use_vissl=True, cache_labels=True, rank=rank, world_size=world)
+        if os.environ.get('LAVILA_TEST_EAGER_NO_DDP') == '1':
+            ddp, crit_e = model_e, CLIPLoss(use_vissl=True, cache_labels=True, rank=0, world_size=1)
         kw = dict(lr=1e-3, eps=1e-3, fused=True, capturable=True)
         opt_e, opt_g = torch.optim.AdamW(model_e.parameters(), **kw), torch.optim.AdamW(model_g.parameters(), **kw)
         B = CFG_MFMA['batch']
         step = GraphedTrainStep(model_g, crit, opt_g, (B, 3, CFG_MFMA['frames'], CFG_MFMA['img'], CFG_MFMA['img']), (B, 77), dev)
         le, lg = [], []
-        for it in range(4):
+        phases = os.environ.get('LAVILA_TEST_PHASES') == '1'       # diagnosis: all eager steps first, then all graphed ones
+        order = ([(it, 'e') for it in range(4)] + [(it, 'g') for it in range(4)]) if phases else \
+            [(it, 'eg') for it in range(4)]
+        for it, what in order:
             video, tokens = O.synthetic_batch(world * B, CFG_MFMA['frames'], CFG_MFMA['img'], seed=40 + it)
             tokens = tokens.clone()
             tokens[:, 1:31] = tokens[:, 1:31] % 510 + 1
             tokens[:, 0], tokens[:, 31] = 510, 511
             sl = slice(rank * B, (rank + 1) * B)
             v, t = video[sl], tokens[sl]
-            with torch.autocast('cuda', dtype=torch.bfloat16):
-                loss = crit(ddp(v.cuda(), t.cuda(), use_checkpoint=False, norm_embed=True))['loss']
-            loss.backward()
-            opt_e.step()
-            opt_e.zero_grad(set_to_none=True)
-            model_e.logit_scale.data.clamp_(0, 4.6052)
-            le.append(float(loss))
-            lg.append(float(step(v, t)['loss']))
+            if 'e' in what:
+                with torch.autocast('cuda', dtype=torch.bfloat16):
+                    loss = crit_e(ddp(v.cuda(), t.cuda(), use_checkpoint=False, norm_embed=True))['loss']
+                loss.backward()
+                opt_e.step()
+                opt_e.zero_grad(set_to_none=True)
+                model_e.logit_scale.data.clamp_(0, 4.6052)
+                le.append(float(loss))
+            if 'g' in what:
+                if os.environ.get('LAVILA_TEST_POISON') == '1':
+                    # diagnosis: fill every cached free block of the streams in play with NaN -- a graph that reads memory it
+                    # does not own (a dangling pointer into the ordinary pool) turns NaN at once
+                    torch.cuda.synchronize()
+                    for st in [torch.cuda.current_stream(), step._stream] + ([step._comm] if step._comm is not None else []):
+                        with torch.cuda.stream(st):
+                            junk = [torch.full((n,), float('nan'), device=dev) for n in
+                                    [64, 512, 4096, 1 << 15, 1 << 18, 1 << 20, 1 << 22, 1 << 24] for _ in range(6)]
+                            junk += [torch.full((n,), float('nan'), device=dev, dtype=torch.bfloat16) for n in
+                                     [96, 768, 6144, 3 << 14, 3 << 17, 3 << 19] for _ in range(6)]
+                            del junk
+                    torch.cuda.synchronize()
+                if os.environ.get('LAVILA_TEST_EMPTY_CACHE') == '1':
+                    torch.cuda.synchronize()
+                    torch.cuda.empty_cache()
+                lg.append(float(step(v, t)['loss']))
+            if os.environ.get('LAVILA_TEST_VERBOSE') == '1' and 'g' in what and not phases:
+                torch.cuda.synchronize()
+                pe_ = torch.cat([p.detach().flatten().float() for p in model_e.parameters()])
+                pg_ = torch.cat([p.detach().flatten().float() for p in model_g.parameters()])
+                print(f'[rank {rank}] step {it}: loss eager {le[-1]:.6f} graphed {lg[-1]:.6f}  max |dp| {float((pe_ - pg_).abs().max()):.2e}  '
+                      f'frac > 0.25 lr {float(((pe_ - pg_).abs() > 2.5e-4).float().mean()):.4f}  checksum g {float(pg_.double().sum()):.6f} '
+                      f'e {float(pe_.double().sum()):.6f}', flush=True)
         torch.cuda.synchronize()
         pe = torch.cat([p.detach().flatten().float() for p in model_e.parameters()])
         pg = torch.cat([p.detach().flatten().float() for p in model_g.parameters()])
+        if os.environ.get('LAVILA_TEST_VERBOSE') == '1':
+            print(f'[rank {rank}] END: losses e {le} g {lg} max |dp| {float((pe - pg).abs().max()):.2e} frac '
+                  f'{float(((pe - pg).abs() > 2.5e-4).float().mean()):.4f} checksum g {float(pg.double().sum()):.6f}', flush=True)
         res = {'rank': rank, 'eager': le, 'graphed': lg, 'max_param_diff': float((pe - pg).abs().max()),
                'frac_moved_apart': float(((pe - pg).abs() > 2.5e-4).float().mean()), 'replays': step.replays,
                'segments': step.segments, 'param_checksum': float(pg.double().sum())}
