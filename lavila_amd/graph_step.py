@@ -25,6 +25,13 @@ lost or repeated: call k performs training step k.
 A caller that ran eager iterations of the same model before (on another stream) must drop what it kept of them (the loss
 tensor holds the autograd graph) before the first capture; torch warns about the stream mismatch when it has not.
 
+What a replay may read: its own pool, the parameters / optimizer state / static inputs -- nothing else. That is tested by
+filling every free block of the allocator with NaN between replays (tests/test_gpu_graph_step.py, tests/test_gpu_ddp.py).
+The test found, in round 5, that hipMemsetAsync NODES are not reliable in a replayed graph on this ROCm build (their fill
+pattern came back from recycled memory: "zeroed" accumulators held {0, NaN, 0, 0} repeated, and a training run drifted or
+went NaN depending on what the allocator handed out next to the graph); the C-ABI zeroes with a kernel since then
+(csrc/common.h: lvl_zero_f32; tests/test_boundary_cpu.py keeps memset / memcpy calls out of csrc).
+
 Limits, loudly: `update_freq` (gradient accumulation) other than 1, stochastic depth / dropout (the RNG offset of a
 replay is not advanced here), a changing batch shape, activation checkpointing, and DistributedDataParallel WRAPPERS:
 DDP's bucket all-reduces would be launched from inside the captured backward, and with collectives pending torch's NCCL
@@ -111,16 +118,11 @@ class _Segments:
         self.begin()
 
     def replay(self):
-        dbg = os.environ.get('LAVILA_GRAPH_DEBUG_SYNC') == '1'      # diagnosis: device-wide sync around every item
         for it in self.items:
-            if dbg:
-                torch.cuda.synchronize()
             if isinstance(it, torch.cuda.CUDAGraph):
                 it.replay()
             else:
                 it()
-        if dbg:
-            torch.cuda.synchronize()
 
     @property
     def graphs(self):
@@ -270,9 +272,6 @@ class GraphedTrainStep:
         def reduce():
             if dist.get_backend() == 'nccl':               # RCCL: one grouped launch over the gradients in place
                 dist.all_reduce_coalesced(grads, op=dist.ReduceOp.SUM)
-            elif os.environ.get('LAVILA_GRAPH_REDUCE') == 'pertensor':      # diagnosis
-                for g_ in grads:
-                    dist.all_reduce(g_, op=dist.ReduceOp.SUM)
             else:                                          # gloo (tests on one device): through one flat buffer
                 flat = torch._utils._flatten_dense_tensors(grads)
                 dist.all_reduce(flat, op=dist.ReduceOp.SUM)

@@ -412,3 +412,19 @@ def test_narrator_seam_state_dict_matches_reference_names():
         m(torch.zeros(1, 3, 2, 32, 32), torch.zeros(1, 8, dtype=torch.long))
     with pytest.raises(NotImplementedError):
         CrossAttention(64, parallel_ff=True)
+
+
+def test_no_memset_or_memcpy_nodes_in_the_c_abi():
+    """Every entry point may run under hipGraph capture (GraphedTrainStep). A hipMemsetAsync there becomes a memset NODE, and
+    a replayed memset node is not reliable on this ROCm build (round 5: its fill pattern came from recycled memory --
+    csrc/common.h, lvl_zero_f32); a hipMemcpyAsync from host memory would bake a host pointer into the graph. Fills and
+    copies inside the library are kernels."""
+    import glob
+    import re
+    bad = []
+    for path in sorted(glob.glob(os.path.join(ROOT, 'lavila_amd', 'csrc', '*'))):
+        for n, line in enumerate(open(path), 1):
+            code = line.split('//')[0]
+            if re.search(r'\bhipMem(set|cpy)\w*\s*\(', code):
+                bad.append(f'{os.path.basename(path)}:{n}: {line.strip()}')
+    assert not bad, bad

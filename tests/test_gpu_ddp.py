@@ -329,18 +329,15 @@ def _graph_worker(rank, world, port, backend, q):
         ddp = torch.nn.parallel.DistributedDataParallel(model_e, device_ids=[0])
         crit = CLIPLoss(use_vissl=True, cache_labels=True, rank=rank, world_size=world)
         crit_e = crit
-        if os.environ.get('LAVILA_TEST_SEPARATE_CRIT') == '1':          # diagnosis switches
-            crit_e = CLIPLoss(use_vissl=True, cache_labels=True, rank=rank, world_size=world)
-        if os.environ.get('LAVILA_TEST_EAGER_NO_DDP') == '1':
-            ddp, crit_e = model_e, CLIPLoss(use_vissl=True, cache_labels=True, rank=0, world_size=1)
         kw = dict(lr=1e-3, eps=1e-3, fused=True, capturable=True)
         opt_e, opt_g = torch.optim.AdamW(model_e.parameters(), **kw), torch.optim.AdamW(model_g.parameters(), **kw)
         B = CFG_MFMA['batch']
         step = GraphedTrainStep(model_g, crit, opt_g, (B, 3, CFG_MFMA['frames'], CFG_MFMA['img'], CFG_MFMA['img']), (B, 77), dev)
         le, lg = [], []
-        phases = os.environ.get('LAVILA_TEST_PHASES') == '1'       # diagnosis: all eager steps first, then all graphed ones
-        order = ([(it, 'e') for it in range(4)] + [(it, 'g') for it in range(4)]) if phases else \
-            [(it, 'eg') for it in range(4)]
+        # the eager DDP model and the graphed step take turns in ONE process: the allocator hands the eager iteration's
+        # temporaries the memory next to everything the graph left free (this order is what exposed the memset nodes)
+        phases = False
+        order = [(it, 'eg') for it in range(4)]
         for it, what in order:
             video, tokens = O.synthetic_batch(world * B, CFG_MFMA['frames'], CFG_MFMA['img'], seed=40 + it)
             tokens = tokens.clone()
@@ -357,21 +354,18 @@ def _graph_worker(rank, world, port, backend, q):
                 model_e.logit_scale.data.clamp_(0, 4.6052)
                 le.append(float(loss))
             if 'g' in what:
-                if os.environ.get('LAVILA_TEST_POISON') == '1':
-                    # diagnosis: fill every cached free block of the streams in play with NaN -- a graph that reads memory it
-                    # does not own (a dangling pointer into the ordinary pool) turns NaN at once
-                    torch.cuda.synchronize()
-                    for st in [torch.cuda.current_stream(), step._stream] + ([step._comm] if step._comm is not None else []):
-                        with torch.cuda.stream(st):
-                            junk = [torch.full((n,), float('nan'), device=dev) for n in
-                                    [64, 512, 4096, 1 << 15, 1 << 18, 1 << 20, 1 << 22, 1 << 24] for _ in range(6)]
-                            junk += [torch.full((n,), float('nan'), device=dev, dtype=torch.bfloat16) for n in
-                                     [96, 768, 6144, 3 << 14, 3 << 17, 3 << 19] for _ in range(6)]
-                            del junk
-                    torch.cuda.synchronize()
-                if os.environ.get('LAVILA_TEST_EMPTY_CACHE') == '1':
-                    torch.cuda.synchronize()
-                    torch.cuda.empty_cache()
+                # NaN into every cached free block of the streams in play (and fresh segments) in front of every graphed
+                # call: a replay that reads memory it does not own -- a dangling pointer into the ordinary pool, a graph
+                # memset node whose pattern lives in recycled memory (round 5: csrc/common.h lvl_zero_f32) -- goes NaN at once
+                torch.cuda.synchronize()
+                for st in [torch.cuda.current_stream(), step._stream] + ([step._comm] if step._comm is not None else []):
+                    with torch.cuda.stream(st):
+                        junk = [torch.full((n,), float('nan'), device=dev) for n in
+                                [64, 512, 4096, 1 << 15, 1 << 18, 1 << 20, 1 << 22, 1 << 24] for _ in range(6)]
+                        junk += [torch.full((n,), float('nan'), device=dev, dtype=torch.bfloat16) for n in
+                                 [96, 768, 6144, 3 << 14, 3 << 17, 3 << 19] for _ in range(6)]
+                        del junk
+                torch.cuda.synchronize()
                 lg.append(float(step(v, t)['loss']))
             if os.environ.get('LAVILA_TEST_VERBOSE') == '1' and 'g' in what and not phases:
                 torch.cuda.synchronize()

@@ -169,3 +169,60 @@ def test_evaluation_between_replays_sees_the_updated_weights():
         evals.append(fresh)
     assert step.replays >= 3
     assert not torch.equal(evals[0], evals[1]) and not torch.equal(evals[1], evals[2])
+
+
+def _poison_free_device_memory(streams, dev):
+    """NaN into the cached free blocks of the given streams' pools and into a fresh segment per size class."""
+    torch.cuda.synchronize()
+    for st in streams:
+        with torch.cuda.stream(st):
+            junk = [torch.full((n // 4,), float('nan'), device=dev) for n in
+                    (256, 2048, 16384, 131072, 1 << 20, 1 << 22, 1 << 24, 1 << 26) for _ in range(12)]
+            del junk
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize('geometry', ['small', 'tsfb'])
+def test_replay_does_not_depend_on_free_device_memory(geometry):
+    """Two runs of the same five steps (eager, capture, three replays); the second fills every free block of the allocator
+    with NaN in front of each call. A replay may only read what it owns: losses and final parameters must be IDENTICAL.
+    (Round 5: the hipMemsetAsync nodes of a replayed graph took their fill pattern from memory that had been recycled --
+    the 'zeroed' class-token accumulators of the attention backward came back as {0, NaN, 0, 0} repeated; csrc/common.h.)"""
+    from lavila.models.loss import CLIPLoss
+    from lavila_amd.graph_step import GraphedTrainStep
+    from oracle import oracle as O
+    cfg = dict(img=32, patch=16, frames=2, dim=256, depth=2, heads=4, t_width=256, t_heads=4, t_layers=2, vocab=512,
+               embed=64, batch=3, gated=False) if geometry == 'small' else \
+        dict(img=224, patch=16, frames=4, dim=768, depth=1, heads=12, t_width=512, t_heads=8, t_layers=1, vocab=512,
+             embed=256, batch=4, gated=False)
+    dev = torch.device('cuda', torch.cuda.current_device())
+
+    def run(poison):
+        model = build_model(cfg)
+        shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        model.load_state_dict(O.procedural_weights(shapes, seed=5))
+        model.to(dev).train()
+        crit = CLIPLoss(use_vissl=True, cache_labels=True, rank=0, world_size=1)
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, eps=1e-3, fused=True, capturable=True)
+        B = cfg['batch']
+        step = GraphedTrainStep(model, crit, opt, (B, 3, cfg['frames'], cfg['img'], cfg['img']), (B, 77), dev)
+        losses = []
+        for it in range(5):
+            video, tokens = O.synthetic_batch(B, cfg['frames'], cfg['img'], seed=40 + it)
+            tokens = tokens.clone()
+            tokens[:, 1:31] = tokens[:, 1:31] % 510 + 1
+            tokens[:, 0], tokens[:, 31] = 510, 511
+            if poison:
+                _poison_free_device_memory([torch.cuda.current_stream(), step._stream], dev)
+            losses.append(float(step(video, tokens)['loss']))
+        torch.cuda.synchronize()
+        assert step.replays == 4
+        return losses, torch.cat([p.detach().flatten().float() for p in model.parameters()]).cpu()
+
+    clean_l, clean_p = run(False)
+    dirty_l, dirty_p = run(True)
+    assert all(l == l for l in dirty_l) and bool(torch.isfinite(dirty_p).all()), (clean_l, dirty_l)
+    # the float32 atomics of the class-token rows make two runs differ in the last bits even without the poison
+    assert max(abs(a - b) for a, b in zip(clean_l, dirty_l)) < 2e-3, (clean_l, dirty_l)
+    moved = float(((clean_p - dirty_p).abs() > 2.5e-4).float().mean())
+    assert moved < 1e-3, f'{moved:.4f} of the parameters ended a quarter of a learning-rate step apart'
