@@ -502,12 +502,24 @@ def main():
     video, tokens = synthetic(args, rank, device, img)
     amp = torch.bfloat16 if args.dtype == 'bf16' else None
 
-    def step():
+    # The caption bound of the text tower's trim comes from the HOST tokens (the loader has them
+    # on the host before the upload, main_pretrain.py:489-498) -- computed inside every timed step, as a training loop
+    # would. LAVILA_BENCH_DEVICE_READBACK=1 (and the `device_readback` record of every default run) is the unmodified
+    # reference loop: the tower reads the longest caption back from the device, one host sync per step.
+    import contextlib
+    from lavila_amd import models as _mm
+    tokens_host = tokens.cpu()
+    host_bound_default = (os.environ.get('LAVILA_BENCH_DEVICE_READBACK') != '1' and
+                          os.environ.get('LAVILA_TEXT_TRIM', '1') != '0')
+
+    def step(host_bound=None):
         # a training loop receives a NEW token tensor every iteration (main_pretrain.py:489-498)
         toks = tokens if args.reuse_tokens else tokens.clone()
-        with torch.autocast('cuda', dtype=amp, enabled=amp is not None):
-            out = net(video, toks, use_checkpoint=False, norm_embed=True)
-            loss = crit(out)['loss']
+        use_bound = host_bound_default if host_bound is None else host_bound
+        with (_mm.fixed_text_length(_mm.caption_bound(tokens_host)) if use_bound else contextlib.nullcontext()):
+            with torch.autocast('cuda', dtype=amp, enabled=amp is not None):
+                out = net(video, toks, use_checkpoint=False, norm_embed=True)
+                loss = crit(out)['loss']
         loss.backward()
         opt.step()
         opt.zero_grad(set_to_none=True)
@@ -553,35 +565,31 @@ def main():
     if os.environ.get('LAVILA_TEXT_TRIM', '1') != '0' and not args.no_events:
         from lavila_amd import models as _m
         _m._TEXT_TRIM = False
-        step()
+        step(host_bound=False)
         fence()
         n2, h2, t2 = max(2, min(4, args.steps)), 0.0, time.perf_counter()
         for _ in range(n2):
             h0 = time.perf_counter()
-            step()
+            step(host_bound=False)
             h2 += time.perf_counter() - h0
         fence()
         no_trim = {'ms_per_step': round(1e3 * (time.perf_counter() - t2) / n2, 3),
                    'host_enqueue_ms_per_step': round(1e3 * h2 / n2, 1), 'steps': n2}
         _m._TEXT_TRIM = True
 
-    # the same step with the caption bound taken from the HOST tokens (models.caption_bound + fixed_text_length: the
-    # one-line driver change of INTEGRATION.md section 1c): same trimmed text tower, no device read-back, the host runs ahead
-    host_bound = None
-    if os.environ.get('LAVILA_TEXT_TRIM', '1') != '0' and not args.no_events:
-        from lavila_amd import models as _m
-        bound = _m.caption_bound(tokens.cpu())       # once, outside the timed loop: a real loader has the tokens on the host
-        with _m.fixed_text_length(bound):
-            step()
-            fence()
-            n4, h4, t4 = max(2, min(4, args.steps)), 0.0, time.perf_counter()
-            for _ in range(n4):
-                h0 = time.perf_counter()
-                step()
-                h4 += time.perf_counter() - h0
-            fence()
-        host_bound = {'ms_per_step': round(1e3 * (time.perf_counter() - t4) / n4, 3),
-                      'host_enqueue_ms_per_step': round(1e3 * h4 / n4, 1), 'steps': n4, 'bound': bound}
+    # the unmodified reference loop: the caption length read back from the device inside the text tower, every step
+    readback = None
+    if host_bound_default and not args.no_events:
+        step(host_bound=False)
+        fence()
+        n4, h4, t4 = max(2, min(4, args.steps)), 0.0, time.perf_counter()
+        for _ in range(n4):
+            h0 = time.perf_counter()
+            step(host_bound=False)
+            h4 += time.perf_counter() - h0
+        fence()
+        readback = {'ms_per_step': round(1e3 * (time.perf_counter() - t4) / n4, 3),
+                    'host_enqueue_ms_per_step': round(1e3 * h4 / n4, 1), 'steps': n4}
 
     # the same step with the LAST block of both towers computed on every row, as the reference does (the default computes
     # only the rows that reach the output -- cls / EOT -- which is exact: DESIGN.md section 4, "Last block")
@@ -681,12 +689,15 @@ def main():
                                    f'local batch {B}, global batch {world * B}, contrastive all-gather over RCCL',
                        'global_batch': world * B, 'parallelism': f'dp{world}', 'final_loss': round(final_loss, 4),
                        'linear_gemms': 'lvl_linear_tn / lvl_linear_wgrad (hand-written MFMA; no library GEMM on the path)',
-                       # host time spent inside step() -- includes the wait of the text tower's caption-length read-back
-                       # (models._longest_caption), which returns only when the previous step has drained
+                       # host time spent inside step() (the `device_readback` record's includes the wait of the text tower's
+                       # caption-length read-back, which returns only when the previous step has drained)
                        'host_enqueue_ms_per_step': round(1e3 * host_s / args.steps, 1),
                        'host_ms_of_each_step': [round(1e3 * h, 1) for h in host_steps[:32]],
                        'text_trim_off': no_trim,
-                       'host_caption_bound': host_bound,
+                       'caption_bound': ('models.caption_bound(host tokens) + fixed_text_length inside every timed step '
+                                         f'(bound {_mm.caption_bound(tokens_host)} of 77 positions; INTEGRATION.md section 1c)')
+                                        if host_bound_default else 'read back from the device by the text tower',
+                       'device_readback': readback,
                        'full_last_block': full_last,
                        # the same iteration as one replayed hipGraph per caption-length bucket (lavila_amd/graph_step.py)
                        'graphed_step': graphed,
