@@ -65,6 +65,8 @@ def parse():
     p.add_argument('--dtype', default='bf16', choices=['bf16', 'f32'])
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--cpu-batch', type=int, default=8)
+    p.add_argument('--event-stride', type=int, default=4,
+                   help='HIP-event pairs around the timed kernel families on every Nth step of the timed region (1 = all)')
     p.add_argument('--no-events', action='store_true', help='skip per-launch HIP events (A/B their overhead)')
     p.add_argument('--workload', default='pretrain', choices=['pretrain', 'narrator'],
                    help='pretrain (default) = BASELINE.json\'s metric; narrator = captions/s of BASELINE configs[4] '
@@ -539,11 +541,19 @@ def main():
             torch.cuda.synchronize()
             print(f'[bench rank {rank}] warm-up step {i}: {1e3 * (time.perf_counter() - h0):.1f} ms', file=sys.stderr, flush=True)
     fence()
-    timer.enabled = wtimer.enabled = gtimer.enabled = not args.no_events
+    # HIP-event pairs around the three timed kernel families on every `event_stride`-th step of the timed region (an event
+    # is a marker packet between two kernels: ~460 of them cost a step about 1 ms -- measured: 169.3-169.7 ms with events
+    # on every step against 168.2-168.8 for the same loop without -- so the instrumentation runs on a sample of the steps;
+    # rocprofv3's per-kernel averages of the same command are in profiles/)
+    stride = max(1, int(args.event_stride))
+    timed_steps = 0
     t0 = time.perf_counter()
     host_s = 0.0
     host_steps = []                # per-step host time inside step(): an outlier step shows here (no extra syncs)
-    for _ in range(args.steps):
+    for i_step in range(args.steps):
+        on = (not args.no_events) and i_step % stride == 0
+        timer.enabled = wtimer.enabled = gtimer.enabled = on
+        timed_steps += int(on)
         h0 = time.perf_counter()
         loss = step()
         host_steps.append(time.perf_counter() - h0)
@@ -635,6 +645,7 @@ def main():
                             'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 4),
                             'traffic': traffic, 'traffic_source': _traffic_source(tfile) if traffic else None,
                             'avg_ms': round(kms, 4), 'launches': len(timer.pairs),
+                            'timed_steps': f'{timed_steps} of {args.steps} (every {stride}th step of the timed region)',
                             'alg_bytes_per_launch': alg_bytes}
         def _by_epilogue(tm):
             """The launches that carry the residual epilogue (LVL_EPI_BIAS_RESIDUAL = 3: +1 read of a [rows, N] tensor per
@@ -665,6 +676,7 @@ def main():
                     'unit': 'TFLOP/s', 'frac': round(ach / MFMA_PEAK_TFLOPS, 4), 'traffic': traffic,
                     'traffic_source': _traffic_source(path) if traffic else None,
                     'avg_ms': round(tot_ms / len(tm.pairs), 4), 'launches': len(tm.pairs),
+                    'timed_steps': f'{timed_steps} of {args.steps} (every {stride}th step of the timed region)',
                     'alg_flops_per_launch': round(tot_fl / len(tm.pairs)), 'traffic_note': note,
                     # not the roofline peak: what an MFMA + fragment-read + barrier + LDS-DMA loop at this kernel's
                     # rates sustains on random bf16 data on this part (power-limited), measured by
