@@ -336,7 +336,6 @@ def _graph_worker(rank, world, port, backend, q):
         le, lg = [], []
         # the eager DDP model and the graphed step take turns in ONE process: the allocator hands the eager iteration's
         # temporaries the memory next to everything the graph left free (this order is what exposed the memset nodes)
-        phases = False
         order = [(it, 'eg') for it in range(4)]
         for it, what in order:
             video, tokens = O.synthetic_batch(world * B, CFG_MFMA['frames'], CFG_MFMA['img'], seed=40 + it)
@@ -367,7 +366,7 @@ def _graph_worker(rank, world, port, backend, q):
                         del junk
                 torch.cuda.synchronize()
                 lg.append(float(step(v, t)['loss']))
-            if os.environ.get('LAVILA_TEST_VERBOSE') == '1' and 'g' in what and not phases:
+            if os.environ.get('LAVILA_TEST_VERBOSE') == '1' and 'g' in what:
                 torch.cuda.synchronize()
                 pe_ = torch.cat([p.detach().flatten().float() for p in model_e.parameters()])
                 pg_ = torch.cat([p.detach().flatten().float() for p in model_g.parameters()])
