@@ -182,7 +182,7 @@ def _poison_free_device_memory(streams, dev):
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize('geometry', ['small', 'tsfb'])
+@pytest.mark.parametrize('geometry', ['small', 'tsfb', 'long_text'])
 def test_replay_does_not_depend_on_free_device_memory(geometry):
     """Two runs of the same five steps (eager, capture, three replays); the second fills every free block of the allocator
     with NaN in front of each call. A replay may only read what it owns: losses and final parameters must be IDENTICAL.
@@ -195,6 +195,14 @@ def test_replay_does_not_depend_on_free_device_memory(geometry):
                embed=64, batch=3, gated=False) if geometry == 'small' else \
         dict(img=224, patch=16, frames=4, dim=768, depth=1, heads=12, t_width=512, t_heads=8, t_layers=1, vocab=512,
              embed=256, batch=4, gated=False)
+    eot = 31
+    if geometry == 'long_text':
+        # 48 captions x 72 positions = 3456 token rows: above 3072 torch's embedding backward sorts the indices (rocPRIM
+        # radix sort -- which zeroes its histograms with hipMemsetAsync, i.e. memset NODES inside the replayed graph); the
+        # benched shape (256 x 32 rows) takes that path
+        cfg = dict(img=32, patch=16, frames=2, dim=256, depth=1, heads=4, t_width=256, t_heads=4, t_layers=1, vocab=512,
+                   embed=256, batch=48, gated=False)
+        eot = 70
     dev = torch.device('cuda', torch.cuda.current_device())
 
     def run(poison):
@@ -210,8 +218,9 @@ def test_replay_does_not_depend_on_free_device_memory(geometry):
         for it in range(5):
             video, tokens = O.synthetic_batch(B, cfg['frames'], cfg['img'], seed=40 + it)
             tokens = tokens.clone()
-            tokens[:, 1:31] = tokens[:, 1:31] % 510 + 1
-            tokens[:, 0], tokens[:, 31] = 510, 511
+            tokens[:, 1:eot] = tokens[:, 1:eot] % 510 + 1
+            tokens[:, 0], tokens[:, eot] = 510, 511
+            tokens[:, eot + 1:] = 0
             if poison:
                 _poison_free_device_memory([torch.cuda.current_stream(), step._stream], dev)
             losses.append(float(step(video, tokens)['loss']))
