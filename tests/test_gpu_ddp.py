@@ -357,7 +357,9 @@ def _graph_worker(rank, world, port, backend, q):
                 # call: a replay that reads memory it does not own -- a dangling pointer into the ordinary pool, a graph
                 # memset node whose pattern lives in recycled memory (round 5: csrc/common.h lvl_zero_f32) -- goes NaN at once
                 torch.cuda.synchronize()
-                for st in [torch.cuda.current_stream(), step._stream] + ([step._comm] if step._comm is not None else []):
+                # (not in front of the step's first, eager call: the property under test is what a REPLAY reads)
+                for st in ([torch.cuda.current_stream(), step._stream] + ([step._comm] if step._comm is not None else [])
+                           if it >= 1 else []):
                     with torch.cuda.stream(st):
                         junk = [torch.full((n,), float('nan'), device=dev) for n in
                                 [64, 512, 4096, 1 << 15, 1 << 18, 1 << 20, 1 << 22, 1 << 24] for _ in range(6)]
