@@ -76,6 +76,9 @@ def parse():
     p.add_argument('--graph-only', action='store_true',
                    help='internal: run only the graphed-step variant (lavila_amd/graph_step.py) and print its record; the '
                         'default run spawns this in a child process so that nothing in it can touch the headline')
+    p.add_argument('--checkpoint', action='store_true',
+                   help='use_checkpoint=True (main_pretrain.py:100,491-495: activation checkpointing per block, '
+                        'timesformer.py:175-187) -- for shapes whose activations do not fit, e.g. 16 frames at local batch 256')
     p.add_argument('--reuse-tokens', action='store_true',
                    help='feed the SAME token tensor object every step (A/B only: the caption-length read-back of the '
                         'text tower is memoised per tensor object; the default hands over a new tensor per step, as a '
@@ -389,7 +392,7 @@ def graph_only_main(args, device):
         idle.append(time.perf_counter() - h0)
         torch.cuda.synchronize()
     rec = {'ms_per_step': round(1e3 * el / n, 3), 'pairs_per_s': round(args.batch * n / el, 1),
-           'host_enqueue_ms_per_step': round(1e3 * host / n, 2),
+           'host_ms_in_step_call': round(1e3 * host / n, 2),
            'replay_call_ms_device_idle': round(1e3 * min(idle), 2), 'steps': n, 'caption_bucket': gstep.buckets,
            'final_loss': round(float(out['loss'].item()), 4)}
     print(json.dumps({'graphed_step': rec}), flush=True)
@@ -520,7 +523,7 @@ def main():
         use_bound = host_bound_default if host_bound is None else host_bound
         with (_mm.fixed_text_length(_mm.caption_bound(tokens_host)) if use_bound else contextlib.nullcontext()):
             with torch.autocast('cuda', dtype=amp, enabled=amp is not None):
-                out = net(video, toks, use_checkpoint=False, norm_embed=True)
+                out = net(video, toks, use_checkpoint=args.checkpoint, norm_embed=True)
                 loss = crit(out)['loss']
         loss.backward()
         opt.step()
@@ -541,6 +544,7 @@ def main():
             torch.cuda.synchronize()
             print(f'[bench rank {rank}] warm-up step {i}: {1e3 * (time.perf_counter() - h0):.1f} ms', file=sys.stderr, flush=True)
     fence()
+    torch.cuda.reset_peak_memory_stats(device)
     # HIP-event pairs around the three timed kernel families on every `event_stride`-th step of the timed region (an event
     # is a marker packet between two kernels: ~460 of them cost a step about 1 ms -- measured: 169.3-169.7 ms with events
     # on every step against 168.2-168.8 for the same loop without -- so the instrumentation runs on a sample of the steps;
@@ -568,6 +572,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     final_loss = float(loss.item())
+    # device memory of the timed region (the caching allocator's own high-water marks; HBM3E per MI355X: 288 GB)
+    peak_alloc_gb = round(torch.cuda.max_memory_allocated(device) / 1e9, 2)
+    peak_reserved_gb = round(torch.cuda.max_memory_reserved(device) / 1e9, 2)
 
     # the cost of the text tower's per-step caption-length read-back, made visible: the same step with the trim (and
     # with it the host read) switched off -- all 77 positions computed, the host free to run ahead
@@ -584,7 +591,7 @@ def main():
             h2 += time.perf_counter() - h0
         fence()
         no_trim = {'ms_per_step': round(1e3 * (time.perf_counter() - t2) / n2, 3),
-                   'host_enqueue_ms_per_step': round(1e3 * h2 / n2, 1), 'steps': n2}
+                   'host_ms_in_step_call': round(1e3 * h2 / n2, 1), 'steps': n2}
         _m._TEXT_TRIM = True
 
     # the unmodified reference loop: the caption length read back from the device inside the text tower, every step
@@ -599,7 +606,7 @@ def main():
             h4 += time.perf_counter() - h0
         fence()
         readback = {'ms_per_step': round(1e3 * (time.perf_counter() - t4) / n4, 3),
-                    'host_enqueue_ms_per_step': round(1e3 * h4 / n4, 1), 'steps': n4}
+                    'host_ms_in_step_call': round(1e3 * h4 / n4, 1), 'steps': n4}
 
     # the same step with the LAST block of both towers computed on every row, as the reference does (the default computes
     # only the rows that reach the output -- cls / EOT -- which is exact: DESIGN.md section 4, "Last block")
@@ -692,7 +699,9 @@ def main():
                                        'reduction, all video-tower weight gradients)', 'traffic_wgrad.json')
         tower = 'TSF-L/14' if 'LARGE' in args.model else 'TSF-B/16'
         line = {
-            'metric': f'clip-text pairs/s (whole node), {tower} {Fr}x{img}^2 + CLIP text tower, fwd+loss+bwd+AdamW',
+            'metric': f'clip-text pairs/s (whole node), {tower} {Fr}x{img}^2 + CLIP text tower, fwd+loss+bwd+AdamW'
+                      + (' (caption bound from the host tokens: INTEGRATION.md 1c one-line driver change; unmodified loop = '
+                         'config.device_readback)' if host_bound_default else ''),
             'value': round(world * B * args.steps / elapsed, 2), 'unit': 'clip-text pairs/s', 'n_gpus': world,
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
@@ -701,9 +710,14 @@ def main():
                                    f'local batch {B}, global batch {world * B}, contrastive all-gather over RCCL',
                        'global_batch': world * B, 'parallelism': f'dp{world}', 'final_loss': round(final_loss, 4),
                        'linear_gemms': 'lvl_linear_tn / lvl_linear_wgrad (hand-written MFMA; no library GEMM on the path)',
-                       # host time spent inside step() (the `device_readback` record's includes the wait of the text tower's
-                       # caption-length read-back, which returns only when the previous step has drained)
-                       'host_enqueue_ms_per_step': round(1e3 * host_s / args.steps, 1),
+                       'peak_mem_gb': peak_alloc_gb, 'peak_mem_reserved_gb': peak_reserved_gb,
+                       'use_checkpoint': bool(args.checkpoint),
+                       # wall time the host spends INSIDE step() -- not host work: once the launch queue is full every call
+                       # blocks until the device has drained a step's worth (back-pressure; the `device_readback` record's
+                       # also includes the text tower's caption-length read-back). `host_work_ms_per_step` is the smallest
+                       # step() call of the region, i.e. what the enqueue itself costs when nothing blocks it
+                       'host_ms_in_step_call': round(1e3 * host_s / args.steps, 1),
+                       'host_work_ms_per_step': round(1e3 * min(host_steps), 1) if host_steps else None,
                        'host_ms_of_each_step': [round(1e3 * h, 1) for h in host_steps[:32]],
                        'text_trim_off': no_trim,
                        'caption_bound': ('models.caption_bound(host tokens) + fixed_text_length inside every timed step '

@@ -118,6 +118,22 @@ int64_t lvl_embed_tokens_bwd_ws(int F, int N, int D);
 int lvl_embed_tokens_bwd(const void* dx, float* dpos, float* dtem, float* ws, int B, int F, int N, int D, int tem_rows,
                          int dtype, void* stream);
 
+/* ---- text tower: token + positional embedding (round 6) ------------------------------------------------
+ * x[b, l, :] = table[tokens[b, l], :] + pos[l, :]   (CLIP.encode_text, models.py:152-153: `self.token_embedding(text)`
+ * + `self.positional_embedding`; under autocast the sum is rounded once to `dtype`). tokens: int64, row stride
+ * tok_stride elements (a `text[:, :L]` view of the [B, 77] batch is read in place), ids clamped to [0, V); table [V, W],
+ * pos [>= L, W] f32; x [B, L, W] dtype. W % 4 == 0.
+ * lvl_text_embed_bwd: autograd of the same two lines -- d table [V, W] f32 (= nn.Embedding's dense backward: row v is the
+ * sum of the dx rows whose token is v, added in ascending row order; rows of unused ids zero) and d pos [ctx, W] f32
+ * (row l = sum over the batch, rows >= L zero) -- without a sort, without float atomics and without memset nodes (torch's
+ * embedding_dense_backward sorts with rocPRIM above 3072 rows, whose histogram memsets become unreliable memset NODES in a
+ * replayed hipGraph). ws: lvl_text_embed_bwd_ws(B, L, V) int32 words. W <= 2048. */
+int lvl_text_embed_fwd(const int64_t* tokens, int64_t tok_stride, const float* table, const float* pos, void* x, int B,
+                       int L, int W, int V, int dtype, void* stream);
+int64_t lvl_text_embed_bwd_ws(int B, int L, int V);
+int lvl_text_embed_bwd(const void* dx, const int64_t* tokens, int64_t tok_stride, float* dtable, float* dpos, int* ws,
+                       int B, int L, int W, int V, int ctx, int dtype, void* stream);
+
 /* ---- divided space-time attention core ---------------------------------------------------------------
  * Everything in VarAttention.forward between the qkv Linear and the proj Linear
  * (timesformer.py:110-140 incl. attn() :35-39): head split, q *= 64^-0.5, CLS query over all T
@@ -126,7 +142,9 @@ int lvl_embed_tokens_bwd(const void* dx, float* dpos, float* dtem, float* ws, in
  * qkv: [B,T,3*H*64] dtype (T = 1+F*N; q|k|v thirds, head-major inside each third);
  * out/dout: [B,T,H*64] dtype; lse: [B,H,T] f32 (log-sum-exp of every query row, saved for backward);
  * dqkv: [B,T,3*H*64] dtype. Workspaces (f32): fwd lvl_workspace_floats("divided_attn_fwd", B*H, T)
- * (partial records of the CLS row), bwd lvl_workspace_floats("divided_attn_bwd", B*H, T). */
+ * (partial records of the CLS row), bwd lvl_workspace_floats("divided_attn_bwd", B*H, T) (delta + up to 64 partial
+ * records [192] f32 per (b, h) of the cls token's d(q|k|v), one per frame / location chunk, summed in slot order: the
+ * backward has no floating-point atomics and is run-to-run bit-identical since round 6). */
 int lvl_divided_attn_fwd(const void* qkv, void* out, float* lse, float* ws, int B, int F, int N,
                          int H, int mode, int dtype, void* stream);
 int lvl_divided_attn_bwd(const void* qkv, const void* out, const void* dout, const float* lse,

@@ -61,6 +61,9 @@ SIGNATURES = {
     'lvl_vec_mat_f32': (_I, [_P, _P, _P, _I, _I, _P]),
     'lvl_embed_tokens_bwd_ws': (_L, [_I, _I, _I]),
     'lvl_embed_tokens_bwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    'lvl_text_embed_fwd': (_I, [_P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    'lvl_text_embed_bwd_ws': (_L, [_I, _I, _I]),
+    'lvl_text_embed_bwd': (_I, [_P, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'lvl_debug_time_bwd_rider': (_I, [_I]),
     'lvl_linear_skinny': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'lvl_linear_skinny_f32c': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),

@@ -378,13 +378,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 1 : (P::kSplit ? 2 : 4))) void 
       }
     }
 
-    // ---- the cls KEY (row 0 of tile 0) collects gradient from every frame: f32 atomics ----------------------
+    // ---- the cls KEY (row 0 of tile 0) collects gradient from every frame: this frame's share goes to slot f of the
+    // partial slab (one writer per slot; cls_grad_finalize_kernel adds the slots up in order: no atomics, deterministic)
     if (kt == 0 && g == 0) {
-      float* kv0 = atom_ws + ((size_t)b * H + h) * 192 + 64;
+      float* kv0 = atom_ws + (((size_t)b * H + h) * F + f) * 192 + 64;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        atomicAdd(kv0 + dt * 16 + c, adk[dt][0] * 0.125f);
-        atomicAdd(kv0 + 64 + dt * 16 + c, adv[dt][0]);
+        kv0[dt * 16 + c] = adk[dt][0] * 0.125f;
+        kv0[64 + dt * 16 + c] = adv[dt][0];
       }
     }
     store_tile_rows<P>(ot, adk, 0.125f, lane, [&](int row) { return dkb + (size_t)(tok0 + kt * 16 + row - 1) * ts; },
@@ -394,9 +395,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 ? 1 : (P::kSplit ? 2 : 4))) void 
   }
 
   if constexpr (TEXT) return;
-  // ---- d(cls query): the per-tile sums were accumulated in LDS; one global atomic per channel ---------------
+  // ---- d(cls query): the per-tile sums were accumulated in LDS; this frame's share goes to slot f --------------
   __syncthreads();
-  if (tid < 64) atomicAdd(atom_ws + ((size_t)b * H + h) * 192 + tid, dqc[tid] * 0.125f);
+  if (tid < 64) atom_ws[(((size_t)b * H + h) * F + f) * 192 + tid] = dqc[tid] * 0.125f;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -441,11 +442,11 @@ __device__ __forceinline__ void store_token_channels(typename P::io_t* row, cons
   for (int dt = 0; dt < 4; ++dt)
     P::store4(row + dt * 16 + g * 4, o[dt][0] * mul, o[dt][1] * mul, o[dt][2] * mul, o[dt][3] * mul);
 }
-__device__ __forceinline__ void atomic_token_channels(float* dst, const f32x4 (&o)[4], float mul, int g) {
+// the same into one slot of the f32 partial slab of the cls token's gradients (a slot part has ONE writer)
+__device__ __forceinline__ void slab_token_channels(float* dst, const f32x4 (&o)[4], float mul, int g) {
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) atomicAdd(dst + dt * 16 + g * 4 + r, o[dt][r] * mul);
+    *reinterpret_cast<float4*>(dst + dt * 16 + g * 4) = make_float4(o[dt][0] * mul, o[dt][1] * mul, o[dt][2] * mul, o[dt][3] * mul);
 }
 
 template <typename P, int NKP>
@@ -478,7 +479,7 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : 2)) void space_bwd_fused_kern
   const io_t* obase = out + (size_t)b * T * D + h * 64;
   const io_t* dobase = dout + (size_t)b * T * D + h * 64;
   const float* lrow = lse + ((size_t)b * H + h) * T;
-  float* cls_ws = atom_ws + ((size_t)b * H + h) * 192;  // d cls q | d cls k | d cls v
+  float* cls_ws = atom_ws + (((size_t)b * H + h) * F + f) * 192;  // this frame's slot: d cls q | d cls k | d cls v
   const int c = lane & 15, g = lane >> 4;
   const FragOff fo = frag_offsets(lane);
   // token of query row qr: patch rows, then the cls token; padding rows alias a valid token (never stored)
@@ -604,7 +605,7 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : 2)) void space_bwd_fused_kern
       if (qrow < N)
         store_token_channels<P>(dqkv + (size_t)b * T * ts + (size_t)(tok0 + qrow) * ts + h * 64, o[t], 0.125f, g);
       else if (qrow == N)
-        atomic_token_channels(cls_ws, o[t], 0.125f, g);          // this frame's share of d(cls q)
+        slab_token_channels(cls_ws, o[t], 0.125f, g);            // this frame's share of d(cls q)
       if (dq_part && qrow <= N) {
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) qsum[dt] += o[t][dt];
@@ -753,9 +754,9 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : 2)) void space_bwd_fused_kern
         io_t* row = dkb + (size_t)(tok0 + krow - 1) * ts;
         store_token_channels<P>(row, adk[t], 0.125f, g);
         store_token_channels<P>(row + D, adv[t], 1.0f, g);
-      } else if (krow == 0) {          // the cls KEY collects gradient from every frame: f32 atomics
-        atomic_token_channels(cls_ws + 64, adk[t], 0.125f, g);
-        atomic_token_channels(cls_ws + 128, adv[t], 1.0f, g);
+      } else if (krow == 0) {          // the cls KEY collects gradient from every frame: this frame's slot
+        slab_token_channels(cls_ws + 64, adk[t], 0.125f, g);
+        slab_token_channels(cls_ws + 128, adv[t], 1.0f, g);
       }
     }
   }
@@ -792,10 +793,19 @@ int dispatch_fused(const void* qkv, const void* out, const void* dout, const flo
 // dqkv[b, token 0, :] = (d cls q | d cls k | d cls v) from the f32 atomic workspace
 template <typename P>
 __global__ __launch_bounds__(192) void cls_grad_finalize_kernel(const float* __restrict__ atom_ws,
-                                                                typename P::io_t* __restrict__ dqkv, int T, int H) {
+                                                                typename P::io_t* __restrict__ dqkv, int T, int H,
+                                                                int nslots) {
+  // The cls token's d(q | k | v) of one (b, h): the sum of `nslots` partial records [192] f32, one per contributing
+  // workgroup (space kernels: one per frame; time kernels: one per location chunk), added up in slot order. Round 6: the
+  // contributors used f32 atomicAdd on ONE record -- the order of four to twenty-five additions then depended on timing, and
+  // through the cls query of the time attention a last-bit difference flipped a bf16 rounding of dqkv about one step in six
+  // at the TSF-B geometry: the "second outcome" of the step (profiles/r06_second_outcome.txt).
   const int h = blockIdx.x % H, b = blockIdx.x / H, t = threadIdx.x;      // t in [0,192): part = t/64
   const int D = H * 64;
-  dqkv[(size_t)b * T * 3 * D + (t >> 6) * D + h * 64 + (t & 63)] = P::from_f32(atom_ws[((size_t)b * H + h) * 192 + t]);
+  const float* rec = atom_ws + ((size_t)b * H + h) * nslots * 192 + t;
+  float acc = 0.f;
+  for (int s = 0; s < nslots; ++s) acc += rec[(size_t)s * 192];
+  dqkv[(size_t)b * T * 3 * D + (t >> 6) * D + h * 64 + (t & 63)] = P::from_f32(acc);
 }
 
 template <typename P, int NKT, bool TEXT = false, int NW = 8, bool MASKALL = false>
@@ -858,13 +868,14 @@ int dispatch_dq(int nkeys, const void* qkv, const void* out, const void* dout, c
 
 }  // namespace
 
-void lvl_launch_cls_grad_finalize(const float* atom_ws, void* dqkv, int B, int T, int H, int dtype, hipStream_t st) {
+void lvl_launch_cls_grad_finalize(const float* atom_ws, void* dqkv, int B, int T, int H, int nslots, int dtype,
+                                  hipStream_t st) {
   if (dtype == LVL_F32)
     hipLaunchKernelGGL(cls_grad_finalize_kernel<PrecSplit>, dim3((unsigned)(B * H)), dim3(192), 0, st, atom_ws,
-                       (float*)dqkv, T, H);
+                       (float*)dqkv, T, H, nslots);
   else
     hipLaunchKernelGGL(cls_grad_finalize_kernel<PrecBf16>, dim3((unsigned)(B * H)), dim3(192), 0, st, atom_ws,
-                       (uint16_t*)dqkv, T, H);
+                       (uint16_t*)dqkv, T, H, nslots);
 }
 
 // float32 (f32-class, PrecSplit): the fused kernel only (up to 288 keys; its four images fit the LDS)
@@ -878,14 +889,13 @@ bool lvl_space_mfma_bwd_supported(int F, int N, int dtype) {
 // rows of the dq column-sum slab the fused kernel writes (0: this shape runs on kernels without the rider)
 int lvl_space_mfma_bwd_dq_part_rows(int B, int F, int N) { return N + 1 <= kFusedPairs * 32 ? B * F : 0; }
 
-// ws layout: delta [B*H*T] f32, then atomics [B*H*192] f32 (d cls q | d cls k | d cls v)
+// ws layout: delta [B*H*T] f32, then the cls token's partial records [B*H][F][192] f32 (d cls q | d cls k | d cls v per frame)
 // dq_part (nullable): [B*F, H*64] f32 partial column sums of dQ, written when lvl_space_mfma_bwd_dq_part_rows > 0
 int lvl_space_mfma_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* ws,
                        float* dq_part, int B, int F, int N, int H, int dtype, hipStream_t st) {
   const int T = 1 + F * N;
   float* delta = ws;
-  float* atom_ws = ws + (size_t)B * H * T;
-  if (int rc = lvl_zero_f32(atom_ws, (size_t)B * H * 192, st)) return rc;      // a kernel, not a memset node: common.h
+  float* atom_ws = ws + (size_t)B * H * T;            // every slot is written whole by its frame's workgroup: no zeroing
   if (N + 1 <= kFusedPairs * 32) {
     if (int rc = dtype == LVL_F32 ? dispatch_fused<PrecSplit>(qkv, out, dout, lse, dqkv, atom_ws, dq_part, B, F, N, H, st)
                                   : dispatch_fused<PrecBf16>(qkv, out, dout, lse, dqkv, atom_ws, dq_part, B, F, N, H, st))
@@ -895,7 +905,7 @@ int lvl_space_mfma_bwd(const void* qkv, const void* out, const void* dout, const
     if (int rc = dispatch_dq<PrecBf16, false>(N + 1, qkv, out, dout, lse, dqkv, delta, B, F, N, H, st)) return rc;
     if (int rc = launch_dkv<PrecBf16, false>(qkv, out, dout, lse, delta, dqkv, atom_ws, B, F, N, H, st)) return rc;
   }
-  lvl_launch_cls_grad_finalize(atom_ws, dqkv, B, T, H, dtype, st);
+  lvl_launch_cls_grad_finalize(atom_ws, dqkv, B, T, H, F, dtype, st);
   LVL_CHECK_LAUNCH("cls_grad_finalize");
   return LVL_OK;
 }

@@ -401,7 +401,7 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : 3)) void space_stream_dq_kern
   const io_t* dobase = dout + (size_t)b * T * D + h * 64;
   const float* lrow = lse + ((size_t)b * H + h) * T;
   float* drow = delta + ((size_t)b * H + h) * T;
-  float* cls_slab = atom_ws + ((size_t)b * H + h) * 192;        // d cls q | d cls k | d cls v
+  float* cls_slab = atom_ws + (((size_t)b * H + h) * F + f) * 192;        // d cls q | d cls k | d cls v
   const int c = lane & 15, g = lane >> 4;
   const int nqt = (N + 15) / 16, ntiles = nqt + 1;
   const FragOff fo = frag_offsets(lane);
@@ -583,11 +583,11 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : 3)) void space_stream_dq_kern
     if (!live[t]) continue;
     const int qrow = qt[t] * 16 + c;
     if (cls_t[t]) {
-      if (c == 0) {                               // this frame's share of d(cls q)
+      if (c == 0) {                               // this frame's share of d(cls q): slot f of the partial slab (one writer)
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) atomicAdd(cls_slab + dt * 16 + g * 4 + r, o[t][dt][r] * 0.125f);
+          *reinterpret_cast<float4*>(cls_slab + dt * 16 + g * 4) =
+              make_float4(o[t][dt][0] * 0.125f, o[t][dt][1] * 0.125f, o[t][dt][2] * 0.125f, o[t][dt][3] * 0.125f);
       }
     } else if (qrow < N) {
       io_t* row = dqkv + (size_t)b * T * ts + (size_t)(tok0 + qrow) * ts + h * 64;
@@ -633,7 +633,7 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : 2)) void space_stream_dkv_ker
   const io_t* dobase = dout + (size_t)b * T * D + h * 64;
   const float* lrow = lse + ((size_t)b * H + h) * T;
   const float* drow = delta + ((size_t)b * H + h) * T;
-  float* cls_slab = atom_ws + ((size_t)b * H + h) * 192;
+  float* cls_slab = atom_ws + (((size_t)b * H + h) * F + f) * 192;
   const int c = lane & 15, g = lane >> 4;
   const int nkt = (nkeys + 15) / 16;
   const FragOff fo = frag_offsets(lane);
@@ -871,14 +871,14 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : 2)) void space_stream_dkv_ker
                   adk[t][dt][3] * 0.125f);
         P::store4(row + D + dt * 16 + g * 4, adv[t][dt][0], adv[t][dt][1], adv[t][dt][2], adv[t][dt][3]);
       }
-    } else if (krow == 0) {          // the cls KEY collects gradient from every frame: f32 atomics
+    } else if (krow == 0) {          // the cls KEY collects gradient from every frame: this frame's slot (one writer)
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          atomicAdd(cls_slab + 64 + dt * 16 + g * 4 + r, adk[t][dt][r] * 0.125f);
-          atomicAdd(cls_slab + 128 + dt * 16 + g * 4 + r, adv[t][dt][r]);
-        }
+      for (int dt = 0; dt < 4; ++dt) {
+        *reinterpret_cast<float4*>(cls_slab + 64 + dt * 16 + g * 4) =
+            make_float4(adk[t][dt][0] * 0.125f, adk[t][dt][1] * 0.125f, adk[t][dt][2] * 0.125f, adk[t][dt][3] * 0.125f);
+        *reinterpret_cast<float4*>(cls_slab + 128 + dt * 16 + g * 4) =
+            make_float4(adv[t][dt][0], adv[t][dt][1], adv[t][dt][2], adv[t][dt][3]);
+      }
     }
   }
 }
@@ -968,7 +968,8 @@ int launch_stream_bwd(const void* qkv, const void* out, const void* dout, const 
 
 void lvl_launch_cls_combine(const float* ws, void* out, float* lse, int B, int H, int nparts, int T, int dtype,
                             hipStream_t st);
-void lvl_launch_cls_grad_finalize(const float* atom_ws, void* dqkv, int B, int T, int H, int dtype, hipStream_t st);
+void lvl_launch_cls_grad_finalize(const float* atom_ws, void* dqkv, int B, int T, int H, int nslots, int dtype,
+                                  hipStream_t st);
 
 // Test / measurement hook: 1 = the streaming kernels for EVERY space group (parity tests at small shapes, A/B against the
 // resident kernels), -1 = never, 0 = the shipped choice (lvl_space_stream_wanted).
@@ -1022,14 +1023,13 @@ int lvl_space_stream_bwd(const void* qkv, const void* out, const void* dout, con
                          int B, int F, int N, int H, int dtype, hipStream_t st) {
   const int T = 1 + F * N;
   float* delta = ws;
-  float* atom_ws = ws + (size_t)B * H * T;
-  if (int rc = lvl_zero_f32(atom_ws, (size_t)B * H * 192, st)) return rc;      // a kernel, not a memset node: common.h
+  float* atom_ws = ws + (size_t)B * H * T;            // partial records [B*H][F][192]: every slot has its writer, no zeroing
   const int rc = dtype == LVL_F32
                      ? launch_stream_bwd<PrecSplit>(qkv, out, dout, lse, dqkv, delta, atom_ws, B, F, N, H, st)
                  : fp8_qk() ? launch_stream_bwd<PrecFp8QK>(qkv, out, dout, lse, dqkv, delta, atom_ws, B, F, N, H, st)
                             : launch_stream_bwd<PrecBf16>(qkv, out, dout, lse, dqkv, delta, atom_ws, B, F, N, H, st);
   if (rc != LVL_OK) return rc;
-  lvl_launch_cls_grad_finalize(atom_ws, dqkv, B, T, H, dtype, st);
+  lvl_launch_cls_grad_finalize(atom_ws, dqkv, B, T, H, F, dtype, st);
   LVL_CHECK_LAUNCH("cls_grad_finalize");
   return LVL_OK;
 }

@@ -403,12 +403,14 @@ __global__ __launch_bounds__((DPL == 2 ? 512 : 256), time_bwd_waves(sizeof(E), F
 #pragma unroll
       for (int i = 0; i < RS; ++i) acc[i] += r[i];
     }
-    float* dst = atom_ws + ((size_t)b * H + h) * 192 + dl * DPL;
+    // this chunk's record of the cls token's d(q | k | v): slot `chunk` of the (b, h) partial slab, one writer, plain
+    // stores; cls_grad_finalize_kernel adds the NC slots up in order (round 6: deterministic, no f32 atomics)
+    float* dst = atom_ws + (((size_t)b * H + h) * NC + chunk) * 192 + dl * DPL;
 #pragma unroll
     for (int i = 0; i < DPL; ++i) {
-      atomicAdd(dst + i, acc[i]);
-      atomicAdd(dst + 64 + i, acc[DPL + i]);
-      atomicAdd(dst + 128 + i, acc[2 * DPL + i]);
+      dst[i] = acc[i];
+      dst[64 + i] = acc[DPL + i];
+      dst[128 + i] = acc[2 * DPL + i];
     }
     if (RIDER) {
       float* qd = dq_part + (size_t)blockIdx.x * D + h * 64 + dl * DPL;
@@ -444,7 +446,8 @@ TimeGeom time_geometry(int N, int H, int dpl) {
 
 void lvl_launch_cls_combine(const float* ws, void* out, float* lse, int B, int H, int nparts, int T, int dtype,
                             hipStream_t st);
-void lvl_launch_cls_grad_finalize(const float* atom_ws, void* dqkv, int B, int T, int H, int dtype, hipStream_t st);
+void lvl_launch_cls_grad_finalize(const float* atom_ws, void* dqkv, int B, int T, int H, int nslots, int dtype,
+                                  hipStream_t st);
 
 bool lvl_time_fast_supported(int F, int N, int H) {
   if (!(F == 1 || F == 2 || F == 3 || F == 4 || F == 8 || F == 16)) return false;
@@ -515,7 +518,7 @@ int lvl_time_fast_bwd_dq_part_rows(int B, int F, int N, int H) {
   return (g.ok && time_rider_mode(F) != 0) ? B * g.NC : 0;
 }
 
-// ws layout: delta [B*H*T] f32 (unused here), then atomics [B*H*192] f32
+// ws layout: delta [B*H*T] f32 (unused here), then the cls token's partial records [B*H][NC][192] f32
 // dq_part (nullable): [lvl_time_fast_bwd_dq_part_rows, H*64] f32 partial column sums of dq (bias-gradient rider)
 int lvl_time_fast_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* ws,
                       float* dq_part, int B, int F, int N, int H, int dtype, hipStream_t st) {
@@ -523,8 +526,7 @@ int lvl_time_fast_bwd(const void* qkv, const void* out, const void* dout, const 
   const TimeGeom g = time_geometry(N, H, dpl);
   if (!g.ok) return lvl_fail(LVL_ENOSYS, "time_fast_bwd: unsupported head count %d", H);
   const int T = 1 + F * N;
-  float* atom_ws = ws + (size_t)B * H * T;
-  if (int rc = lvl_zero_f32(atom_ws, (size_t)B * H * 192, st)) return rc;      // a kernel, not a memset node: common.h
+  float* atom_ws = ws + (size_t)B * H * T;            // every (b, h, chunk) slot is written whole by its workgroup: no zeroing
   const int rider = dq_part ? time_rider_mode(F) : 0;
   const size_t shmem = (size_t)g.NPB * H * (64 / dpl) * (rider ? 4 : 3) * dpl * sizeof(float);
   const dim3 grid((unsigned)(B * g.NC)), block(g.block);
@@ -557,7 +559,7 @@ int lvl_time_fast_bwd(const void* qkv, const void* out, const void* dout, const 
 #undef TIME_BWD
 #undef TIME_BWD_R
   LVL_CHECK_LAUNCH("time_bwd");
-  lvl_launch_cls_grad_finalize(atom_ws, dqkv, B, T, H, dtype, st);
+  lvl_launch_cls_grad_finalize(atom_ws, dqkv, B, T, H, g.NC, dtype, st);
   LVL_CHECK_LAUNCH("cls_grad_finalize");
   return LVL_OK;
 }

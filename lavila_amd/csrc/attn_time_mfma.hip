@@ -391,14 +391,15 @@ __global__ __launch_bounds__(NWV * 64) void time_mfma_bwd_kernel(const uint16_t*
     store_tile_rows<PrecBf16>(ot, odk, 0.125f, lane, [&](int row) { return row_ptr(row, 1); }, [&](int row) { return row < F; });
     store_tile_rows<PrecBf16>(ot, odv, 1.0f, lane, [&](int row) { return row_ptr(row, 2); }, [&](int row) { return row < F; });
   }
-  // the cls token's gradients: row 0 of the accumulated tiles (lanes g == 0), one atomic per channel and wave
+  // the cls token's gradients: row 0 of the accumulated tiles (lanes g == 0) -> this chunk's slot of the (b, h) partial
+  // slab, one writer per slot; cls_grad_finalize_kernel adds the NC slots up in order (round 6: no f32 atomics)
   if (g == 0) {
-    float* dst = atom_ws + ((size_t)b * H + h) * 192;
+    float* dst = atom_ws + (((size_t)b * H + h) * NC + chunk) * 192;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
-      atomicAdd(dst + dt * 16 + c, aq[dt][0] * 0.125f);
-      atomicAdd(dst + 64 + dt * 16 + c, ak[dt][0] * 0.125f);
-      atomicAdd(dst + 128 + dt * 16 + c, av[dt][0]);
+      dst[dt * 16 + c] = aq[dt][0] * 0.125f;
+      dst[64 + dt * 16 + c] = ak[dt][0] * 0.125f;
+      dst[128 + dt * 16 + c] = av[dt][0];
     }
   }
 }
@@ -414,7 +415,8 @@ inline Geo geometry(int N) {
 
 void lvl_launch_cls_combine(const float* ws, void* out, float* lse, int B, int H, int nparts, int T, int dtype,
                             hipStream_t st);
-void lvl_launch_cls_grad_finalize(const float* atom_ws, void* dqkv, int B, int T, int H, int dtype, hipStream_t st);
+void lvl_launch_cls_grad_finalize(const float* atom_ws, void* dqkv, int B, int T, int H, int nslots, int dtype,
+                                  hipStream_t st);
 
 bool lvl_time_mfma_supported(int F, int N, int H) { return F >= 5 && F <= 16 && N >= 1 && H % NWV == 0; }
 
@@ -428,20 +430,19 @@ int lvl_time_mfma_fwd(const void* qkv, void* out, float* lse, float* ws, int B, 
   return LVL_OK;
 }
 
-// ws layout: delta [B*H*T] f32 (unused here), then atomics [B*H*192] f32
+// ws layout: delta [B*H*T] f32 (unused here), then the cls token's partial records [B*H][NC][192] f32
 int lvl_time_mfma_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, float* ws,
                       int B, int F, int N, int H, hipStream_t st) {
   const Geo g = geometry(N);
   const int T = 1 + F * N;
-  float* atom_ws = ws + (size_t)B * H * T;
-  if (int rc = lvl_zero_f32(atom_ws, (size_t)B * H * 192, st)) return rc;      // a kernel, not a memset node: common.h
+  float* atom_ws = ws + (size_t)B * H * T;            // every (b, h, chunk) slot is written whole by its wave: no zeroing
   if (int rc = lvl_allow_lds<time_mfma_bwd_kernel>()) return rc;
   hipLaunchKernelGGL(time_mfma_bwd_kernel, dim3((unsigned)(B * g.NC * (H / NWV))), dim3(NWV * 64),
                      NWV * (4 * IMG + 16 * OS) * sizeof(uint16_t), st,
                      (const uint16_t*)qkv, (const uint16_t*)out, (const uint16_t*)dout, lse, (uint16_t*)dqkv, atom_ws, F,
                      N, H, g.NCH, g.NC);
   LVL_CHECK_LAUNCH("time_mfma_bwd");
-  lvl_launch_cls_grad_finalize(atom_ws, dqkv, B, T, H, LVL_BF16, st);
+  lvl_launch_cls_grad_finalize(atom_ws, dqkv, B, T, H, g.NC, LVL_BF16, st);
   LVL_CHECK_LAUNCH("cls_grad_finalize");
   return LVL_OK;
 }

@@ -82,7 +82,9 @@ extern "C" int64_t lvl_workspace_floats(const char* op, int64_t rows, int64_t co
   if (!strcmp(op, "layernorm_bwd")) return (int64_t)(lvl_ln_bwd_parts() + lvl_colsum_mid_rows()) * 3 * cols;
   if (!strcmp(op, "bias_quickgelu_bwd")) return (int64_t)(lvl_gelu_bwd_row_blocks() + lvl_colsum_mid_rows()) * cols;
   if (!strcmp(op, "divided_attn_fwd")) return rows * 64 * 66;   // <= 64 CLS-row partial records per (b,h)
-  if (!strcmp(op, "divided_attn_bwd")) return rows * cols + rows * 192;   // delta [B*H, T] + cls-grad atomics
+  // delta [B*H, T] + the cls token's partial gradient records: <= 64 slots of [192] per (b, h) (one per frame / per
+  // location chunk, added up in order by cls_grad_finalize_kernel)
+  if (!strcmp(op, "divided_attn_bwd")) return rows * cols + rows * 192 * 64;
   if (!strcmp(op, "causal_attn_bwd")) return rows * cols;    // delta [B*H, L]
   if (!strcmp(op, "qkv_bias_grad")) return (int64_t)(lvl_qkv_bias_row_blocks() + lvl_colsum_mid_rows()) * 2 * cols;   // cols = D
   if (!strcmp(op, "linear_wgrad")) return lvl_wgrad_workspace_floats(rows, cols);   // rows = N (out), cols = K (in); -1: no tiling

@@ -58,6 +58,52 @@ from . import ops
 
 _active = threading.local()
 
+# hipGraphNodeType, in the runtime's order (hip_runtime_api.h)
+NODE_TYPES = ('kernel', 'memcpy', 'memset', 'host', 'graph', 'empty', 'wait_event', 'event_record', 'sem_signal', 'sem_wait',
+              'mem_alloc', 'mem_free', 'memcpy_from_symbol', 'memcpy_to_symbol')
+_hip_rt = None
+
+
+def _hip_runtime():
+    """The libamdhip64 this process already runs on (torch's), through ctypes: graph introspection only."""
+    global _hip_rt
+    if _hip_rt is None:
+        import ctypes
+        path = None
+        with open('/proc/self/maps') as f:
+            for line in f:
+                if 'libamdhip64' in line:
+                    path = line.split()[-1]
+                    break
+        if path is None:
+            raise RuntimeError('libamdhip64 is not mapped into this process')
+        _hip_rt = ctypes.CDLL(path)
+    return _hip_rt
+
+
+def graph_node_types(graph):
+    """{node type: count} of a captured torch.cuda.CUDAGraph built with keep_graph=True (hipGraphGetNodes +
+    hipGraphNodeGetType). What it is for: a hipMemsetAsync recorded as a memset NODE is not reliable under replay on this
+    ROCm build (module docstring) -- the C-ABI has none, but a library call inside the captured iteration may (torch's
+    embedding backward above 3072 rows: rocPRIM's radix sort zeroes its histograms that way)."""
+    import ctypes
+    hip = _hip_runtime()
+    raw = ctypes.c_void_p(int(graph.raw_cuda_graph()))
+    n = ctypes.c_size_t(0)
+    if hip.hipGraphGetNodes(raw, None, ctypes.byref(n)) != 0:
+        raise RuntimeError('hipGraphGetNodes failed')
+    nodes = (ctypes.c_void_p * max(1, n.value))()
+    if hip.hipGraphGetNodes(raw, nodes, ctypes.byref(n)) != 0:
+        raise RuntimeError('hipGraphGetNodes failed')
+    counts = {}
+    for i in range(n.value):
+        t = ctypes.c_int(-1)
+        if hip.hipGraphNodeGetType(ctypes.c_void_p(nodes[i]), ctypes.byref(t)) != 0:
+            raise RuntimeError('hipGraphNodeGetType failed')
+        name = NODE_TYPES[t.value] if 0 <= t.value < len(NODE_TYPES) else f'type{t.value}'
+        counts[name] = counts.get(name, 0) + 1
+    return counts
+
 
 def active_segments():
     """The _Segments object of the capture in progress on this thread (None outside GraphedTrainStep captures): what
@@ -87,6 +133,11 @@ def run_on_collective_stream(fn):
     cur.wait_stream(comm)
 
 
+# Census of the captured graphs' node types after every capture (graph_node_types); LAVILA_GRAPH_AUDIT=0 switches it off
+# (the graphs are then built without keep_graph).
+AUDIT_NODES = os.environ.get('LAVILA_GRAPH_AUDIT', '1') != '0'
+
+
 class _Segments:
     """graph | eager op | graph | ... recorded while ONE iteration runs under capture; replay() runs them in order.
     Every segment allocates from the same private pool (tensors that cross a segment boundary -- activations saved for the
@@ -100,7 +151,7 @@ class _Segments:
         self._cur = None
 
     def begin(self):
-        self._cur = torch.cuda.CUDAGraph()
+        self._cur = torch.cuda.CUDAGraph(keep_graph=True) if AUDIT_NODES else torch.cuda.CUDAGraph()
         self._cur.capture_begin(pool=self.pool, capture_error_mode=self.error_mode)
 
     def end(self):
@@ -178,6 +229,7 @@ class GraphedTrainStep:
             if not torch.is_tensor(grp['lr']):
                 grp['lr'] = torch.tensor(float(grp['lr']), dtype=torch.float32, device=self.device)
         self._graphs = {}            # rounded caption length -> (segments, outputs)
+        self.node_types = {}         # rounded caption length -> {hipGraph node type: count} (LAVILA_GRAPH_AUDIT)
         self._pool = None
         # data parallel without the DDP wrapper: collectives between graph segments, gradients averaged here
         self.distributed = dist.is_available() and dist.is_initialized()
@@ -323,9 +375,10 @@ class GraphedTrainStep:
         # one pool for every bucket: nothing a graph allocates is read after the next call (outputs are per call, the
         # gradients are rewritten by each replay before its optimizer step reads them)
         if not self.distributed:
-            graph = torch.cuda.CUDAGraph()
+            graph = torch.cuda.CUDAGraph(keep_graph=True) if AUDIT_NODES else torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, pool=self._pool, stream=self._stream):
                 out = self._iteration(L)
+            self._audit(L, [graph])
             return graph, out
         # with a process group: the iteration as a chain of graph segments with the collectives between them
         import gc
@@ -342,7 +395,28 @@ class GraphedTrainStep:
             finally:
                 _active.seg = _active.comm = None
         cur.wait_stream(self._stream)
+        self._audit(L, [g for g in seg.items if isinstance(g, torch.cuda.CUDAGraph)])
         return seg, out
+
+    def _audit(self, L, graphs):
+        """Node census of what was just captured (self.node_types[L]); memset nodes are refused loudly: their fill pattern
+        is read from recycled memory at replay on this ROCm build (module docstring), i.e. a silently wrong training run."""
+        if not AUDIT_NODES:
+            return
+        total = {}
+        for g in graphs:
+            for k, v in graph_node_types(g).items():
+                total[k] = total.get(k, 0) + v
+        self.node_types[L] = total
+        if total.get('memset', 0):
+            msg = (f'GraphedTrainStep: the captured iteration (caption bucket {L}) holds {total["memset"]} memset node(s) '
+                   '-- a library call inside the step zeroes with hipMemsetAsync; under replay their fill pattern is read '
+                   'from recycled memory on this ROCm build. lavila_amd itself records none (tests/test_boundary_cpu.py)')
+            if os.environ.get('LAVILA_GRAPH_MEMSET_NODES', 'error') == 'warn':
+                import warnings
+                warnings.warn(msg)
+            else:
+                raise RuntimeError(msg + '; LAVILA_GRAPH_MEMSET_NODES=warn lets the replay run anyway')
 
     @property
     def buckets(self):

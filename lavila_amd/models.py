@@ -201,11 +201,18 @@ class CLIP(nn.Module):
                 rows = rows.clamp(max=text.shape[1] - 1)
             elif rows_max is not None:
                 text = text[:, :_longest_caption(self, text, rows, rows_max)]
-            x = self.token_embedding(text) + self.positional_embedding[:text.shape[1]]          # [B, L, W]
-            if x.dtype == torch.float16:                   # model.half(): compute in bf16 (f32 stream if asked for)
-                x = x.float() if ops.RESIDUAL_F32 else x.to(torch.bfloat16)
-            elif torch.is_autocast_enabled() and not ops.RESIDUAL_F32:
-                x = x.to(ops.autocast_dtype())
+            emb = self.token_embedding
+            plain = (type(emb) is nn.Embedding and emb.padding_idx is None and emb.max_norm is None
+                     and not emb.scale_grad_by_freq and not emb.sparse and not emb._forward_hooks
+                     and not emb._forward_pre_hooks)
+            act = (ops.autocast_dtype() if (torch.is_autocast_enabled() and not ops.RESIDUAL_F32) else None) or torch.float32
+            x = ops.text_embed(text, emb.weight, self.positional_embedding, act) if plain else None    # gather + add, one kernel
+            if x is None:
+                x = self.token_embedding(text) + self.positional_embedding[:text.shape[1]]      # [B, L, W]
+                if x.dtype == torch.float16:               # model.half(): compute in bf16 (f32 stream if asked for)
+                    x = x.float() if ops.RESIDUAL_F32 else x.to(torch.bfloat16)
+                elif torch.is_autocast_enabled() and not ops.RESIDUAL_F32:
+                    x = x.to(ops.autocast_dtype())
             x = self.transformer.forward_batch_major(x, self.ln_final, use_checkpoint=use_checkpoint, rows=rows)
             if x.dtype != self.text_projection.dtype and not torch.is_autocast_enabled():
                 x = x.to(self.text_projection.dtype)

@@ -950,6 +950,54 @@ def embed_tokens(pe, cls_token, pos_embed, temporal_embed, frames, n_per_frame):
     return _EmbedTokensFn.apply(lowp(pe), cls_token, pos_embed, temporal_embed, frames, n_per_frame)
 
 
+TEXT_EMBED_KERNEL = os.environ.get('LAVILA_TEXT_EMBED_KERNEL', '1') != '0'
+
+
+class _TextEmbedFn(torch.autograd.Function):
+    """x = token_embedding(text) + positional_embedding[:L] (models.py:152-153) as one gather kernel, and its backward as
+    a sort-free deterministic segmented sum (csrc/text_embed.hip): torch's embedding_dense_backward takes a rocPRIM radix
+    sort above 3072 token rows, whose histogram memsets turn into memset NODES of a replayed hipGraph."""
+
+    @staticmethod
+    def forward(ctx, text, table, pos, out_dtype):
+        B, L = text.shape
+        V, W = table.shape
+        tab, p = _f32(table), _f32(pos)
+        C.require_device(tab, p)
+        x = torch.empty(B, L, W, dtype=out_dtype, device=table.device)
+        C.check(C.lib().lvl_text_embed_fwd(C.ptr(text), text.stride(0), C.ptr(tab), C.ptr(p), C.ptr(x), B, L, W, V,
+                                           C.dtype_code(x), C.stream_ptr()), 'lvl_text_embed_fwd')
+        ctx.text = text                       # an index tensor (no gradient, not an output): kept as a plain attribute
+        ctx.meta = (V, W, pos.shape[0], table.dtype, pos.dtype)
+        return x
+
+    @staticmethod
+    def backward(ctx, dx):
+        text = ctx.text
+        B, L = text.shape
+        V, W, ctx_len, tdt, pdt = ctx.meta
+        dx = dx.contiguous()
+        dtable = torch.empty(V, W, dtype=torch.float32, device=dx.device)
+        dpos = torch.empty(ctx_len, W, dtype=torch.float32, device=dx.device)
+        ws = torch.empty(int(C.lib().lvl_text_embed_bwd_ws(B, L, V)), dtype=torch.int32, device=dx.device)
+        C.check(C.lib().lvl_text_embed_bwd(C.ptr(dx), C.ptr(text), text.stride(0), C.ptr(dtable), C.ptr(dpos), C.ptr(ws),
+                                           B, L, W, V, ctx_len, C.dtype_code(dx), C.stream_ptr()), 'lvl_text_embed_bwd')
+        return None, dtable.to(tdt), dpos.to(pdt), None
+
+
+def text_embed(text, table, pos, out_dtype):
+    """CLIP.encode_text's first two lines on the own kernels when they apply (a device int64 [B, L] view whose rows are
+    contiguous, float32 table / positions of a width that is a multiple of 4 and at most 2048); None otherwise (the caller
+    keeps nn.Embedding)."""
+    if not (TEXT_EMBED_KERNEL and text.is_cuda and text.dtype == torch.int64 and text.dim() == 2 and text.stride(1) == 1
+            and text.shape[0] > 0 and text.shape[1] > 0
+            and table.dtype == torch.float32 and pos.dtype == torch.float32 and table.is_contiguous()
+            and pos.is_contiguous() and table.shape[1] % 4 == 0 and table.shape[1] <= 2048
+            and pos.shape[0] >= text.shape[1] and out_dtype in (torch.float32, torch.bfloat16)):
+        return None
+    return _TextEmbedFn.apply(text, table, pos, out_dtype)
+
+
 # --------------------------------------------------------------------------------------------------
 # attention cores
 # --------------------------------------------------------------------------------------------------

@@ -216,6 +216,68 @@ def test_divided_attention_core(dt, mode, B, Fr, N, H):
     _check_qkv_bias_grad(bias.grad, qo.grad, dt)
 
 
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('mode', ['space', 'time'])
+@pytest.mark.parametrize('B,Fr,N,H', [(3, 4, 196, 12), (2, 16, 49, 4), (2, 2, 400, 2), (2, 3, 5, 2)])
+def test_divided_attention_backward_is_bitwise_reproducible(dt, mode, B, Fr, N, H):
+    """Round 6: the cls token's d(q | k | v) is the sum of one partial record per frame (space kernels) / per location chunk
+    (time kernels), added up in slot order by cls_grad_finalize_kernel -- no floating-point atomics any more. With f32
+    atomicAdd on one record the order of 4..25 additions depended on timing; at the TSF-B geometry (196 locations, 25
+    chunks) that flipped a bf16 rounding of dqkv's cls row about one step in six and the training step had two
+    outcomes (profiles/r06_second_outcome.txt). Ten backward passes must agree to the bit, the bias gradient included;
+    shapes: the fused space / register time kernels (TSF-B), the MFMA time kernels (16 frames), the streaming space
+    kernels (400 locations), tiny groups."""
+    from lavila_amd import ops
+    qkv, dout = _attn_case(B, Fr, N, H, 5)
+    qg = qkv.to(DEV, dt).requires_grad_(True)
+    bias = torch.zeros(qkv.shape[-1], device=DEV, requires_grad=True)
+    go = dout.to(DEV, dt)
+    first = None
+    for _ in range(10):
+        qg.grad = bias.grad = None
+        ops.divided_attention(qg, Fr, N, H, mode, bias=bias).backward(go)
+        got = (qg.grad.clone(), bias.grad.clone())
+        if first is None:
+            first = got
+        assert torch.equal(got[0], first[0]) and torch.equal(got[1], first[1])
+    assert bool(torch.isfinite(first[0].float()).all())
+
+
+@pytest.mark.parametrize('dt', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('B,L,ctx,V,W', [(5, 7, 77, 64, 512), (64, 72, 77, 512, 256), (256, 32, 77, 49408, 512), (3, 77, 77, 49408, 768),
+                                         (1, 1, 4, 3, 8)])
+def test_text_embedding_matches_nn_embedding(dt, B, L, ctx, V, W):
+    """lvl_text_embed_fwd / _bwd against `token_embedding(text) + positional_embedding` (models.py:152-153) under autograd:
+    the forward equals torch's to the bit (one f32 add, one rounding), d(table) / d(positional_embedding) equal float64
+    sums of the same dx rows to float32 rounding, a second backward is bit-identical (no float atomics, no sort), and the
+    token tensor is read through a strided `text[:, :L]` view. Tokens are drawn from a small range so that most rows have
+    duplicates (the case the reduction exists for); (64, 72) is above torch's 3072-row switch to the rocPRIM sort path."""
+    from lavila_amd import ops
+    g = torch.Generator().manual_seed(3 + B + L)
+    full = torch.randint(0, min(V, 97), (B, ctx), generator=g)
+    full[:, 0] = V - 1
+    table = (torch.randn(V, W, generator=g) * 0.1).to(DEV).requires_grad_(True)
+    pos = (torch.randn(ctx, W, generator=g) * 0.1).to(DEV).requires_grad_(True)
+    text = full.to(DEV)[:, :L]
+    up = torch.randn(B, L, W, generator=g).to(DEV)
+    x = ops.text_embed(text, table, pos, dt)
+    assert x is not None and x.dtype == dt
+    want = (torch.nn.functional.embedding(text, table) + pos[:L]).to(dt)
+    assert torch.equal(x, want)
+    (x.float() * up).sum().backward()
+    dt1, dp1 = table.grad.clone(), pos.grad.clone()
+    table.grad = pos.grad = None
+    (ops.text_embed(text, table, pos, dt).float() * up).sum().backward()
+    assert torch.equal(table.grad, dt1) and torch.equal(pos.grad, dp1)
+    dx = up.to(dt).double()                                    # what the backward kernel reads: dx rounded to dt
+    ref_t = torch.zeros(V, W, dtype=torch.float64, device=DEV).index_add_(0, text.reshape(-1), dx.reshape(-1, W))
+    ref_p = torch.zeros(ctx, W, dtype=torch.float64, device=DEV)
+    ref_p[:L] = dx.sum(0)
+    assert (dt1.double() - ref_t).abs().max().item() <= 1e-6 * max(1.0, ref_t.abs().max().item())
+    assert (dp1.double() - ref_p).abs().max().item() <= 1e-6 * max(1.0, ref_p.abs().max().item())
+    assert float(dp1[L:].abs().max() if L < ctx else 0.0) == 0.0
+
+
 @pytest.mark.parametrize('mode', ['space', 'time'])
 @pytest.mark.parametrize('site', ['residual_epilogue', 'add_layernorm_pass'])
 def test_colsum_tokens_give_the_bias_gradient_without_reading_dout(mode, site, monkeypatch):
