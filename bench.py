@@ -496,9 +496,14 @@ def main():
         # hook registered DDP leaves the scaling to the hook, which divides the BUCKET once (4 launches per step).
         # allreduce_hook is torch's own restatement of the default all-reduce; bf16_compress_hook also halves the bytes on
         # xGMI (gradients cross the links in bf16, are accumulated into the float32 buckets on arrival). INTEGRATION.md section 4.
-        from torch.distributed.algorithms.ddp_comm_hooks import default_hooks as _hooks
-        hook = {'allreduce': _hooks.allreduce_hook, 'bf16': _hooks.bf16_compress_hook}[os.environ['LAVILA_BENCH_DDP_HOOK']]
-        net.register_comm_hook(None, hook)
+        which = os.environ['LAVILA_BENCH_DDP_HOOK']
+        if which == 'builtin':
+            # the reducer's own C++ all-reduce hook: one division per BUCKET inside the reducer, no Python callback per
+            # bucket (the Python allreduce_hook measured slower than the default path: 191 vs 172 ms, round 5)
+            net._register_builtin_comm_hook(dist.BuiltinCommHookType.ALLREDUCE)
+        else:
+            from torch.distributed.algorithms.ddp_comm_hooks import default_hooks as _hooks
+            net.register_comm_hook(None, {'allreduce': _hooks.allreduce_hook, 'bf16': _hooks.bf16_compress_hook}[which])
     crit = CLIPLoss(use_vissl=True, cache_labels=True, rank=rank, world_size=world)
     decay = [p for n, p in model.named_parameters() if not (p.ndim < 2 or 'bias' in n or 'ln' in n or 'bn' in n)]
     no_decay = [p for n, p in model.named_parameters() if (p.ndim < 2 or 'bias' in n or 'ln' in n or 'bn' in n)]

@@ -319,7 +319,14 @@ class GraphedTrainStep:
     def _average_gradients(self):
         """What DistributedDataParallel does with its buckets, as ONE coalesced all-reduce behind the backward (the
         gradients are graph-owned tensors at fixed addresses: the recorded closure reduces them in place at every replay)."""
-        grads = [p.grad for p in self.model.parameters() if p.grad is not None]
+        # every rank must reduce the SAME list: a parameter that got no gradient on this rank only (unused on some ranks)
+        # would otherwise give mismatched all-reduce sizes -- a hang, not an error (ADVICE r5)
+        missing = [n for n, p in self.model.named_parameters() if p.requires_grad and p.grad is None]
+        if missing:
+            raise RuntimeError(f'GraphedTrainStep: {len(missing)} trainable parameter(s) received no gradient in the captured '
+                               f'iteration (e.g. {missing[0]}): data-parallel replay needs every rank to reduce the same '
+                               'tensors -- freeze them (requires_grad=False) or use the eager DistributedDataParallel loop')
+        grads = [p.grad for p in self.model.parameters() if p.requires_grad]
 
         def reduce():
             if dist.get_backend() == 'nccl':               # RCCL: one grouped launch over the gradients in place

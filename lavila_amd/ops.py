@@ -504,7 +504,7 @@ class _LinearTokenFn(torch.autograd.Function):
         ctx.meta = (weight.dtype, x.shape)
         ctx.set_materialize_grads(False)        # an unused token arrives as None, not as zeros
         y = linear_tn_raw(x2, w, None, C.EPI_BIAS)
-        return y.reshape(*x.shape[:-1], weight.shape[0]), x.new_empty(weight.shape[0], dtype=torch.float32)
+        return y.reshape(*x.shape[:-1], weight.shape[0]), x.new_zeros(weight.shape[0], dtype=torch.float32)   # token VALUE: unused, defined (zeros)
 
     @staticmethod
     def backward(ctx, dy, dytoken):
@@ -709,7 +709,8 @@ class _LinearResidualLayerNormFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, ds, dh):
-        x2, wt, s, g, mean, rstd = ctx.saved_tensors[:6]
+        saved = ctx.saved_tensors             # ONE access: torch.utils.checkpoint's unpack hook refuses a second one
+        x2, wt, s, g, mean, rstd = saved[:6]
         wdt, bdt, gdt, betadt, xshape = ctx.meta
         dh2 = dh.reshape(s.shape)
         dadd = None if ds is None else ds.reshape(s.shape).contiguous()
@@ -720,7 +721,7 @@ class _LinearResidualLayerNormFn(torch.autograd.Function):
             dx = linear_tn_raw(dsum, wt, None, C.EPI_BIAS).reshape(xshape) if ctx.needs_input_grad[0] else None
             dw = _wgrad(dsum, x2, wdt) if ctx.needs_input_grad[1] else None
             # token rule: column sums of dx = (column sums of dsum) . W  (dx = dsum W)
-            dtok = vec_mat(dcol, ctx.saved_tensors[6]) if want_tok else None
+            dtok = vec_mat(dcol, saved[6]) if want_tok else None
         db = dcol.to(bdt) if (bdt is not None and ctx.needs_input_grad[2]) else None
         return (dx, dw, db, dsum.reshape(ds.shape if ds is not None else dh.shape), dg.to(gdt), dbeta.to(betadt), None,
                 dtok)
@@ -1048,7 +1049,7 @@ class _DividedAttnFn(torch.autograd.Function):
         # an unused token must arrive in backward as None (= "nobody computed the column sums"), not as zeros
         ctx.set_materialize_grads(False)
         if want_token:
-            return out, out.new_empty(D, dtype=torch.float32)
+            return out, out.new_zeros(D, dtype=torch.float32)      # the token's VALUE is never read; zeros, not uninitialised memory (hooks, anomaly mode)
         return out
 
     @staticmethod

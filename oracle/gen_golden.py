@@ -37,14 +37,8 @@ CONFIGS = {
     # BASELINE.json configs[0]: CLIP_OPENAI_TIMESFORMER_BASE shape, 2 frames 112^2, batch 4
     'config1_tsfb_112': dict(img=112, patch=16, frames=2, dim=768, depth=12, heads=12, t_width=512,
                              t_heads=8, t_layers=12, vocab=49408, embed=256, batch=4, gated=False),
-    # BASELINE.json configs[1]'s clip shape (the benched one): TSF-B/16, 4 frames of 224^2, batch 8 (round 4)
-    'config2_tsfb_224_b8': dict(img=224, patch=16, frames=4, dim=768, depth=12, heads=12, t_width=512,
-                                t_heads=8, t_layers=12, vocab=49408, embed=256, batch=8, gated=False),
-    # CLIP_OPENAI_TIMESFORMER_LARGE / _LARGE_336PX shapes (models.py:374-491): forward AND backward pins (round 4)
-    'tsfl14_224_b2': dict(img=224, patch=14, frames=4, dim=1024, depth=24, heads=16, t_width=768,
-                          t_heads=12, t_layers=12, vocab=49408, embed=256, batch=2, gated=False),
-    'tsfl14_336_b2': dict(img=336, patch=14, frames=2, dim=1024, depth=24, heads=16, t_width=768,
-                          t_heads=12, t_layers=12, vocab=49408, embed=256, batch=2, gated=False),
+    # (round 4's format-1 fixtures of these shapes -- config2_tsfb_224_b8, tsfl14_224_b2, tsfl14_336_b2 -- were replaced by
+    # the *_spread fixtures below in round 5 and are no longer generated)
     # round 5: "spread" fixtures (oracle.synthetic_batch / procedural_weights with spread=True: samples that do NOT
     # collapse onto one embedding, ragged captions, attention scores of a few units) with every 1-D gradient of six
     # blocks + row slices of their weight gradients stored in full (fixture format 2, compared per tensor on the
