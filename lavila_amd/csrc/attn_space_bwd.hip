@@ -638,7 +638,19 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : 2)) void space_bwd_fused_kern
       }
     }
   };
-  load_kv(wave < NKP ? wave : 0);
+  // This wave's FIRST key pair comes from the K, V images while they are still in LDS (they are overwritten behind the
+  // barrier below): the same fragments as load_kv's (row c of the tile, channels g*8.. and 32 + g*8..; padded rows are
+  // zero in the images) without a second trip over the fabric -- 4 of the 7 key pairs of a TSF-B group. The second pair
+  // of waves 0..2 is fetched from global memory inside the loop as before (round 6).
+  if (wave < NKP) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        kk[t][hh] = P::tile_op(img0, LO, 2 * wave + t, fo.a[hh]);
+        vv[t][hh] = P::tile_op(img1, LO, 2 * wave + t, fo.a[hh]);
+      }
+  }
   {   // Q and dO rows (patch queries, then the cls query as row N): the loads fly while the slower waves finish
       // phase 1, the images are overwritten after the barrier
     constexpr int RPP = NT / 8;

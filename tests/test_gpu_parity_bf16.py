@@ -489,3 +489,47 @@ def test_large_models_forward_bf16_vs_oracle(ctor, frames):
     for k in ('image_embed', 'text_embed'):
         err = ((out[k].float().cpu() - oo[k]).norm() / oo[k].norm()).item()
         assert err < 4e-2, (k, err)
+
+
+def test_benched_training_step_is_a_function_of_its_inputs():
+    """"the result of the benched bf16 step is not proven to be a function of its inputs". The benched model
+    (CLIP_OPENAI_TIMESFORMER_BASE, 12 + 12 blocks, 4 x 224^2, bf16 autocast, two towers on two streams, fused AdamW, the
+    logit-scale clamp of main_pretrain.py:527-528) at a local batch of 24 -- every kernel family and launch geometry of the
+    bench line -- run twice from the same weights on three batches: losses, every gradient of the last step and every
+    parameter after it must agree TO THE BIT. (Until round 6 the cls token's gradient was summed with f32 atomics; at this
+    clip geometry the order of the 25 additions flipped a bf16 rounding about one step in six.)"""
+    import contextlib
+    import io
+    from lavila.models import models
+    from lavila.models.loss import CLIPLoss
+    B = 24
+
+    def run():
+        torch.manual_seed(0)
+        with contextlib.redirect_stdout(io.StringIO()):
+            model = models.CLIP_OPENAI_TIMESFORMER_BASE(num_frames=4, project_embed_dim=256)
+        shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+        model.load_state_dict(O.procedural_weights(shapes, seed=17))
+        model.to(DEV).train()
+        crit = CLIPLoss()
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-4, eps=1e-6, fused=True)
+        losses = []
+        for it in range(3):
+            video, tokens = O.synthetic_batch(B, 4, 224, seed=50 + it)
+            opt.zero_grad(set_to_none=True)
+            with torch.autocast('cuda', dtype=torch.bfloat16):
+                loss = crit(model(video.to(DEV), tokens.to(DEV), norm_embed=True))['loss']
+            loss.backward()
+            grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+            opt.step()
+            model.logit_scale.data.clamp_(0, 4.6052)
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        return losses, grads, {n: p.detach().clone() for n, p in model.named_parameters()}
+
+    l0, g0, p0 = run()
+    l1, g1, p1 = run()
+    assert l0 == l1, (l0, l1)
+    assert all(v == v for v in l0)
+    bad = [n for n in g0 if not torch.equal(g0[n], g1[n])] + [n for n in p0 if not torch.equal(p0[n], p1[n])]
+    assert not bad, bad[:8]

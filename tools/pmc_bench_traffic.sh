@@ -41,8 +41,8 @@ def family(sub, min_bytes, tag, note):
                  'bytes = 2*1024*FETCH_SIZE + 1024*WRITE_SIZE (gfx950: wide reads are tallied at half), averaged over the launches'}
     json.dump(j, open(f'{out}/{tag}.json', 'w'), indent=1)
     print(tag, j['launches'], 'launches, avg', j['traffic_bytes_per_launch'] / 1e9, 'GB (min', j['min'] / 1e9, 'max', j['max'] / 1e9, ')')
-family('gemm_tn_kernel', 2e8, 'r05_traffic_gemm_tn', 'all video-tower lvl_linear_tn launches (forward + input gradient, shape mix of the step)')
-family('wgrad_kernel<4, 2, 6, 6', 2e8, 'r05_traffic_wgrad', 'all video-tower lvl_linear_wgrad launches (shape mix of the step)')
-family('13, false, 8, false', 1e8, 'r05_traffic_space_fwd', 'space-mode lvl_divided_attn_fwd launches')
-family("space_bwd_fused_kernel", 1e8, "r05_traffic_space_bwd", "space-mode lvl_divided_attn_bwd launches (fused kernel)")
+family('gemm_tn_kernel', 2e8, 'r06_traffic_gemm_tn', 'all video-tower lvl_linear_tn launches (forward + input gradient, shape mix of the step)')
+family('wgrad_kernel<4, 2, 6, 6', 2e8, 'r06_traffic_wgrad', 'all video-tower lvl_linear_wgrad launches (shape mix of the step)')
+family('13, false, 8, false', 1e8, 'r06_traffic_space_fwd', 'space-mode lvl_divided_attn_fwd launches')
+family("space_bwd_fused_kernel", 1e8, "r06_traffic_space_bwd", "space-mode lvl_divided_attn_bwd launches (fused kernel)")
 PY
