@@ -122,9 +122,10 @@ int lvl_embed_tokens_bwd(const void* dx, float* dpos, float* dtem, float* ws, in
  * x[b, l, :] = table[tokens[b, l], :] + pos[l, :]   (CLIP.encode_text, models.py:152-153: `self.token_embedding(text)`
  * + `self.positional_embedding`; under autocast the sum is rounded once to `dtype`). tokens: int64, row stride
  * tok_stride elements (a `text[:, :L]` view of the [B, 77] batch is read in place), ids clamped to [0, V); table [V, W],
- * pos [>= L, W] f32; x [B, L, W] dtype. W % 4 == 0.
+ * pos [>= L, W] f32; x [B, L, W] dtype. W % 4 == 0 (forward), W % 8 == 0 (backward).
  * lvl_text_embed_bwd: autograd of the same two lines -- d table [V, W] f32 (= nn.Embedding's dense backward: row v is the
- * sum of the dx rows whose token is v, added in ascending row order; rows of unused ids zero) and d pos [ctx, W] f32
+ * sum of the dx rows whose token is v, added in a fixed order -- eight contiguous row ranges, ascending inside each; rows of
+ * unused ids zero) and d pos [ctx, W] f32
  * (row l = sum over the batch, rows >= L zero) -- without a sort, without float atomics and without memset nodes (torch's
  * embedding_dense_backward sorts with rocPRIM above 3072 rows, whose histogram memsets become unreliable memset NODES in a
  * replayed hipGraph). ws: lvl_text_embed_bwd_ws(B, L, V) int32 words. W <= 2048. */

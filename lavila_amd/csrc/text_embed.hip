@@ -7,10 +7,11 @@
 // (profiles/r05_graph_memset_nodes.txt; the benched shape, 256 captions x 32 positions = 8192 rows, takes that path).
 // Here: forward = gather + add + one rounding; backward = a deterministic segmented sum without a sort --
 //   stage 1  first[v] = min row with token v (integer atomicMin: order-independent), count[v] (integer atomicAdd);
-//   stage 2  one workgroup per token row r: the row that is FIRST of its token adds up the dx rows of all its duplicates in
-//            ascending row order (wave-wide compare + ballot over the token list, so a token that occurs once costs one
-//            row copy) and stores d table[v] -- no float atomics, run-to-run identical; rows of unused tokens are zeroed
-//            by the same launch sequence (lvl_zero_f32: a kernel);
+//   stage 2  one workgroup per token row r: the row that is FIRST of its token adds up the dx rows of all its duplicates (its
+//            8 waves take 8 contiguous row ranges, each in ascending order; the partial sums are combined in range order:
+//            wave-wide compare + ballot over the token list, so a token that occurs once costs one row copy) and stores
+//            d table[v] -- no float atomics, run-to-run identical; rows of unused tokens are zeroed by the same launch
+//            sequence (lvl_zero_f32: a kernel);
 //   d pos[l] = sum over the batch of dx[b, l, :] in batch order (rows >= L zero).
 #include "common.h"
 
@@ -55,45 +56,98 @@ __global__ __launch_bounds__(256) void text_embed_census_kernel(const int64_t* _
   atomicAdd(count + v, 1);
 }
 
+// d table[v] for the token v of row r, computed by the workgroup of the FIRST row that holds v (the others leave at once).
+// A token that occurs once is a row copy. Otherwise the 8 waves cut the rows behind r into 8 contiguous ranges, every wave adds
+// up the matching dx rows of its range in ascending order (wave-wide compare + ballot over the token list, two row loads in
+// flight), and wave 0 adds the 8 partial sums to the first row in range order -- a fixed order whatever the timing. Heavy
+// duplicates are the rule, not the exception: start / end tokens occur once per caption, padding ids thousands of times
+// (ragged captions), and their rows would otherwise be one serial chain of dependent loads.
+constexpr int kTabWaves = 8;
 template <typename T>
-__global__ __launch_bounds__(128) void text_embed_bwd_table_kernel(const T* __restrict__ dx, const int* __restrict__ tok32,
-                                                                   const int* __restrict__ first,
-                                                                   const int* __restrict__ count, float* __restrict__ dtable,
-                                                                   int R, int W) {
+__global__ __launch_bounds__(kTabWaves * 64) void text_embed_bwd_table_kernel(const T* __restrict__ dx,
+                                                                              const int* __restrict__ tok32,
+                                                                              const int* __restrict__ first,
+                                                                              const int* __restrict__ count,
+                                                                              float* __restrict__ dtable, int R, int W) {
+  __shared__ float part[kTabWaves][4][64][8];           // [wave][column group][lane][8 columns] = 64 KiB
   const int r = blockIdx.x;
   const int v = tok32[r];
-  if (first[v] != r) return;                             // a later duplicate: its leader adds it up
-  const int lane = threadIdx.x & 63;
-  int left = count[v] - 1;
+  if (first[v] != r) return;                             // a later duplicate: its first row adds it up
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = count[v];
   float* out = dtable + (int64_t)v * W;
-  // this thread's columns: c0, c0 + 512, ... (W <= 2048: 4 register groups)
-  float acc[4][4];
-  const int c0 = threadIdx.x * 4;
+  float acc[4][8];
 #pragma unroll
   for (int k = 0; k < 4; ++k)
-    if (c0 + k * 512 < W) Elem<T>::load4(dx + (int64_t)r * W + c0 + k * 512, acc[k]);
-  // duplicates in ascending row order: every wave walks the token list 64 rows at a time (both waves of the workgroup
-  // find the same rows; each adds them into its own columns)
-  for (int base = r + 1; left > 0 && base < R; base += 64) {
-    const int rr = base + lane;
-    unsigned long long m = __ballot(rr < R && tok32[rr] == v);
-    while (m) {
-      const int j = __builtin_ctzll(m);
-      m &= m - 1;
-      --left;
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (c0 + k * 512 < W) {
-          float d[4];
-          Elem<T>::load4(dx + (int64_t)(base + j) * W + c0 + k * 512, d);
+    for (int i = 0; i < 8; ++i) acc[k][i] = 0.f;
+  auto add_row = [&](int row) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) acc[k][i] += d[i];
+    for (int k = 0; k < 4; ++k) {
+      const int c = (k * 64 + lane) * 8;
+      if (c < W) {
+        float d[8];
+        Elem<T>::load8(dx + (int64_t)row * W + c, d);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[k][i] += d[i];
+      }
+    }
+  };
+  if (wave == 0) add_row(r);                              // the first row itself: wave 0 starts from it
+  if (n > 1) {
+    const int span = R - (r + 1);
+    const int per = ((span + kTabWaves - 1) / kTabWaves + 63) & ~63;      // rows per wave, a multiple of the scan width
+    const int lo = r + 1 + wave * per, hi = min(R, lo + per);
+    for (int base = lo; base < hi; base += 64) {
+      const int rr = base + lane;
+      unsigned long long m = __ballot(rr < hi && tok32[rr] == v);
+      while (m) {
+        const int j0 = __builtin_ctzll(m);
+        m &= m - 1;
+        if (m) {                                           // two matches: both rows' loads are issued before either add
+          const int j1 = __builtin_ctzll(m);
+          m &= m - 1;
+          float d0[4][8], d1[4][8];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int c = (k * 64 + lane) * 8;
+            if (c < W) {
+              Elem<T>::load8(dx + (int64_t)(base + j0) * W + c, d0[k]);
+              Elem<T>::load8(dx + (int64_t)(base + j1) * W + c, d1[k]);
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if ((k * 64 + lane) * 8 < W) {
+#pragma unroll
+              for (int i = 0; i < 8; ++i) acc[k][i] = (acc[k][i] + d0[k][i]) + d1[k][i];
+            }
+        } else {
+          add_row(base + j0);
         }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) part[wave][k][lane][i] = acc[k][i];
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+      for (int w = 1; w < kTabWaves; ++w)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[k][i] += part[w][k][lane][i];
     }
   }
+  if (wave == 0) {
 #pragma unroll
-  for (int k = 0; k < 4; ++k)
-    if (c0 + k * 512 < W) Elem<float>::store4(out + c0 + k * 512, acc[k]);
+    for (int k = 0; k < 4; ++k) {
+      const int c = (k * 64 + lane) * 8;
+      if (c < W) Elem<float>::store8(out + c, acc[k]);
+    }
+  }
 }
 
 // d pos[l] = sum_b dx[b, l, :]: 4 batch quarters x 128 column threads per workgroup, the quarters' partial sums added in
@@ -150,11 +204,11 @@ extern "C" int64_t lvl_text_embed_bwd_ws(int B, int L, int V) { return (int64_t)
 extern "C" int lvl_text_embed_bwd(const void* dx, const int64_t* tokens, int64_t tok_stride, float* dtable, float* dpos,
                                   int* ws, int B, int L, int W, int V, int ctx, int dtype, void* stream) {
   LVL_REQUIRE(dx && tokens && dtable && dpos && ws, "text_embed_bwd: null pointer");
-  LVL_REQUIRE(B > 0 && L > 0 && V > 0 && W > 0 && W % 4 == 0 && W <= 2048 && ctx >= L && tok_stride >= L,
+  LVL_REQUIRE(B > 0 && L > 0 && V > 0 && W > 0 && W % 8 == 0 && W <= 2048 && ctx >= L && tok_stride >= L,
               "text_embed_bwd: bad shape B=%d L=%d W=%d V=%d ctx=%d", B, L, W, V, ctx);
   LVL_REQUIRE((int64_t)B * L < (1ll << 31), "text_embed_bwd: too many token rows");
-  LVL_REQUIRE(lvl_aligned16(dtable) && lvl_aligned16(dpos) && (reinterpret_cast<uintptr_t>(dx) & 7) == 0,
-              "text_embed_bwd: dtable / dpos must be 16-byte aligned, dx 8-byte aligned");
+  LVL_REQUIRE(lvl_aligned16(dtable) && lvl_aligned16(dpos) && lvl_aligned16(dx),
+              "text_embed_bwd: dtable / dpos / dx must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   const int R = B * L;
   int* tok32 = ws;
@@ -164,7 +218,7 @@ extern "C" int lvl_text_embed_bwd(const void* dx, const int64_t* tokens, int64_t
   hipLaunchKernelGGL(text_embed_init_kernel, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, first, count, V);
   hipLaunchKernelGGL(text_embed_census_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, tokens, tok_stride, tok32,
                      first, count, R, L, V);
-  LVL_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((text_embed_bwd_table_kernel<T>), dim3((unsigned)R), dim3(128), 0, st,
+  LVL_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((text_embed_bwd_table_kernel<T>), dim3((unsigned)R), dim3(kTabWaves * 64), 0, st,
                                                (const T*)dx, tok32, first, count, dtable, R, W));
   LVL_DISPATCH_DTYPE(dtype, hipLaunchKernelGGL((text_embed_bwd_pos_kernel<T>), dim3((unsigned)ctx), dim3(512), 0, st,
                                                (const T*)dx, dpos, B, L, W));

@@ -988,12 +988,12 @@ class _TextEmbedFn(torch.autograd.Function):
 
 def text_embed(text, table, pos, out_dtype):
     """CLIP.encode_text's first two lines on the own kernels when they apply (a device int64 [B, L] view whose rows are
-    contiguous, float32 table / positions of a width that is a multiple of 4 and at most 2048); None otherwise (the caller
+    contiguous, float32 table / positions of a width that is a multiple of 8 and at most 2048); None otherwise (the caller
     keeps nn.Embedding)."""
     if not (TEXT_EMBED_KERNEL and text.is_cuda and text.dtype == torch.int64 and text.dim() == 2 and text.stride(1) == 1
             and text.shape[0] > 0 and text.shape[1] > 0
             and table.dtype == torch.float32 and pos.dtype == torch.float32 and table.is_contiguous()
-            and pos.is_contiguous() and table.shape[1] % 4 == 0 and table.shape[1] <= 2048
+            and pos.is_contiguous() and table.shape[1] % 8 == 0 and table.shape[1] <= 2048
             and pos.shape[0] >= text.shape[1] and out_dtype in (torch.float32, torch.bfloat16)):
         return None
     return _TextEmbedFn.apply(text, table, pos, out_dtype)

@@ -251,11 +251,14 @@ def test_text_embedding_matches_nn_embedding(dt, B, L, ctx, V, W):
     the forward equals torch's to the bit (one f32 add, one rounding), d(table) / d(positional_embedding) equal float64
     sums of the same dx rows to float32 rounding, a second backward is bit-identical (no float atomics, no sort), and the
     token tensor is read through a strided `text[:, :L]` view. Tokens are drawn from a small range so that most rows have
-    duplicates (the case the reduction exists for); (64, 72) is above torch's 3072-row switch to the rocPRIM sort path."""
+    duplicates (the case the reduction exists for), the larger cases add a padding id with thousands of duplicates; (64, 72) is
+    above torch's 3072-row switch to the rocPRIM sort path."""
     from lavila_amd import ops
     g = torch.Generator().manual_seed(3 + B + L)
     full = torch.randint(0, min(V, 97), (B, ctx), generator=g)
     full[:, 0] = V - 1
+    if B >= 64:                          # ragged captions: the padding id fills a quarter of the positions (thousands of duplicates)
+        full[:, (3 * L) // 4:] = 0
     table = (torch.randn(V, W, generator=g) * 0.1).to(DEV).requires_grad_(True)
     pos = (torch.randn(ctx, W, generator=g) * 0.1).to(DEV).requires_grad_(True)
     text = full.to(DEV)[:, :L]
