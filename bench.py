@@ -121,11 +121,11 @@ class KernelTimer:
 
 def _traffic_file(stem):
     """Newest committed PMC traffic summary of a kernel family (profiles/rNN_<stem>, tools/pmc_bench_traffic.sh)."""
-    for rnd in ('r05', 'r04', 'r03', 'r02'):
+    for rnd in ('r06', 'r05', 'r04', 'r03', 'r02'):
         path = os.path.join(ROOT, 'profiles', f'{rnd}_{stem}')
         if os.path.isfile(path):
             return path
-    return os.path.join(ROOT, 'profiles', 'r05_' + stem)
+    return os.path.join(ROOT, 'profiles', 'r06_' + stem)
 
 
 def _traffic_source(path):
@@ -473,6 +473,11 @@ def main():
     img = model.visual.patch_embed.img_size[0]
     timer = KernelTimer()
     ops.divided_attn_fwd_raw = timer.wrap(ops.divided_attn_fwd_raw, lambda qkv, f, n, h, mode: mode == 0)   # space
+    # the space-mode attention BACKWARD call (fused kernel + cls-gradient finalize + the bias-gradient column sums it
+    # carries): the kernel furthest below its roof on this configuration, reported as `roofline_hbm_bwd`
+    btimer = KernelTimer()
+    ops._DividedAttnFn.backward = staticmethod(btimer.wrap(ops._DividedAttnFn.backward,
+                                                           lambda ctx, *g: ctx.cfg[4] == 0 and ctx.cfg[0] == args.batch))
     # every all-token video-tower launch (M = local batch x tokens per clip rows, whatever the local batch is) of the
     # two hand-written MFMA GEMM families; the text tower's launches (<= 77 rows per caption, on the second stream) and
     # the cls-row launches of the last block (one row per clip) are not in the aggregate
@@ -561,7 +566,7 @@ def main():
     host_steps = []                # per-step host time inside step(): an outlier step shows here (no extra syncs)
     for i_step in range(args.steps):
         on = (not args.no_events) and i_step % stride == 0
-        timer.enabled = wtimer.enabled = gtimer.enabled = on
+        timer.enabled = wtimer.enabled = gtimer.enabled = btimer.enabled = on
         timed_steps += int(on)
         h0 = time.perf_counter()
         loss = step()
@@ -571,7 +576,7 @@ def main():
             print(f'[bench rank {rank}] step: host {1e3 * host_steps[-1]:.1f} ms', file=sys.stderr, flush=True)
     fence()
     elapsed = time.perf_counter() - t0
-    timer.enabled = wtimer.enabled = gtimer.enabled = False
+    timer.enabled = wtimer.enabled = gtimer.enabled = btimer.enabled = False
     t = torch.tensor([elapsed], device=device, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -659,6 +664,22 @@ def main():
                             'avg_ms': round(kms, 4), 'launches': len(timer.pairs),
                             'timed_steps': f'{timed_steps} of {args.steps} (every {stride}th step of the timed region)',
                             'alg_bytes_per_launch': alg_bytes}
+        roofline_hbm_bwd = None
+        bms = btimer.mean_ms()
+        if bms:
+            balg = B * (2 * T * 3 * D + 2 * T * D) * esize      # read qkv, out, dout; write dqkv
+            btraffic = None
+            bfile = _traffic_file('traffic_space_bwd.json')
+            if os.path.isfile(bfile) and (B, Fr, N, D) == (256, 4, 196, 768) and amp is not None:
+                btraffic = json.load(open(bfile))['traffic_bytes_per_launch']
+            bach = balg / (bms * 1e-3) / 1e9
+            roofline_hbm_bwd = {'bound': 'hbm', 'kernel': 'lvl_divided_attn_bwd_bias[space] (space_bwd_fused_kernel + cls-gradient '
+                                                          'finalize + the bias-gradient column sums of the same call)',
+                                'achieved': round(bach, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                'frac': round(bach / HBM_PEAK_GBS, 4), 'traffic': btraffic,
+                                'traffic_source': _traffic_source(bfile) if btraffic else None,
+                                'avg_ms': round(bms, 4), 'launches': len(btimer.pairs), 'alg_bytes_per_launch': balg}
+
         def _by_epilogue(tm):
             """The launches that carry the residual epilogue (LVL_EPI_BIAS_RESIDUAL = 3: +1 read of a [rows, N] tensor per
             launch, the LayerNorm pass it replaces is gone from the step) priced apart from the others."""
@@ -750,6 +771,7 @@ def main():
             'roofline': roofline,
             'roofline_wgrad': roofline_wgrad,
             'roofline_hbm': roofline_hbm,
+            'roofline_hbm_bwd': roofline_hbm_bwd,
         }
         if rehearsal:
             line['config']['note'] = rehearsal
