@@ -30,6 +30,12 @@ CONFIGS = {
                    embed=64, batch=5, gated=False),
     'tsfb': dict(img=224, patch=16, frames=4, dim=768, depth=1, heads=12, t_width=512, t_heads=8, t_layers=1, vocab=512,
                  embed=256, batch=3, gated=False),
+    # the geometry of tests/test_gpu_graph_step.py's poisoned-replay test (batch 4: 16 space groups, 3140 token rows)
+    'tsfb4': dict(img=224, patch=16, frames=4, dim=768, depth=1, heads=12, t_width=512, t_heads=8, t_layers=1, vocab=512,
+                  embed=256, batch=4, gated=False),
+    # two video blocks: the full chain (residual epilogues, pending MLP, tokens) in front of the cls-only last block
+    'tsfb4x2': dict(img=224, patch=16, frames=4, dim=768, depth=2, heads=12, t_width=512, t_heads=8, t_layers=2, vocab=512,
+                    embed=256, batch=4, gated=False),
 }
 HOST_ONLY = ('_ws', 'workspace', 'last_error', 'lvl_set_', 'lvl_debug', '_rows', '_floats', 'lvl_version')
 
