@@ -32,7 +32,8 @@ extern "C" {
 enum { LVL_F32 = 0, LVL_BF16 = 1 };
 enum { LVL_OK = 0, LVL_EINVAL = -22, LVL_ENOSYS = -38, LVL_EHIP = -5 };
 enum { LVL_ATTN_SPACE = 0, LVL_ATTN_TIME = 1, LVL_ATTN_CAUSAL = 2 /* lvl_attention_fast_path only */ };
-enum { LVL_EPI_BIAS = 0, LVL_EPI_BIAS_QUICKGELU = 1, LVL_EPI_QUICKGELU_BWD = 2, LVL_EPI_BIAS_RESIDUAL = 3 };
+enum { LVL_EPI_BIAS = 0, LVL_EPI_BIAS_QUICKGELU = 1, LVL_EPI_QUICKGELU_BWD = 2, LVL_EPI_BIAS_RESIDUAL = 3,
+       LVL_EPI_BIAS_QUICKGELU_DERIV = 4, LVL_EPI_MUL_AUX_COLSUM = 5 };
 /* activations of the narrator decoder's MLPs (lvl_act_inplace) */
 enum { LVL_ACT_GELU_NEW = 0, LVL_ACT_SQRELU = 1 };
 
@@ -356,8 +357,14 @@ int lvl_sample_next_token(const void* logits, int64_t row_stride, int rows, int 
  *   LVL_EPI_BIAS_RESIDUAL    y = acc + bias + aux_in: the Linear's output added to the residual stream, in f32 before the
  *                            one rounding of the sum -- `x + attn(norm1(x))`, `x + mlp(norm2(x))` (timesformer.py:183-196;
  *                            openai_model.py:199-200) leave proj / fc2 as the new stream; aux_in [M,N], y's dtype
- * aux_out / aux_in: [M,N] bf16. N % 256 == 0 and K % 64 == 0 (operands < 4 GiB), else LVL_ENOSYS. Workspace (QUICKGELU_BWD only):
- * lvl_workspace_floats("linear_tn", M, N) floats.
+ *   LVL_EPI_BIAS_QUICKGELU_DERIV   (bf16 only) u = acc + bias (f32, not rounded); y = u * sigmoid(1.702 u);
+ *                            aux_out = d quickgelu(u) = s (1 + 1.702 u (1 - s)), s = sigmoid(1.702 u): the training form of
+ *                            LVL_EPI_BIAS_QUICKGELU -- autograd's backward of timesformer.py:52-54 needs the derivative,
+ *                            not u, and the forward holds s in a register (one exp2 + one reciprocal serve both outputs)
+ *   LVL_EPI_MUL_AUX_COLSUM   (bf16 only) y = acc * aux_in; colsum[N] f32 = column sums of y: LVL_EPI_QUICKGELU_BWD on the
+ *                            stored derivative (no transcendental in the backward's epilogue)
+ * aux_out / aux_in: [M,N] bf16. N % 256 == 0 and K % 64 == 0 (operands < 4 GiB), else LVL_ENOSYS. Workspace (QUICKGELU_BWD /
+ * MUL_AUX_COLSUM only): lvl_workspace_floats("linear_tn", M, N) floats.
  * dtype = LVL_F32 selects the F32-CLASS MODE of the same kernel (the parity configuration, north_star "within 1e-3
  * fp32"): x [M, 3K0] and w [N, 3K0] are the bf16 term images lvl_split_bf16x3 writes (role 0 for x, role 1 for w;
  * K = 3*K0, K0 % 64 == 0), so that one pass accumulates xh.wh + xh.wl + xl.wh in f32 (~2^-17 relative per product);

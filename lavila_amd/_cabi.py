@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, 'lib', 'liblavila_hip.so')
 
 LVL_F32, LVL_BF16 = 0, 1
 ATTN_SPACE, ATTN_TIME = 0, 1
-EPI_BIAS, EPI_BIAS_QUICKGELU, EPI_QUICKGELU_BWD, EPI_BIAS_RESIDUAL = 0, 1, 2, 3
+EPI_BIAS, EPI_BIAS_QUICKGELU, EPI_QUICKGELU_BWD, EPI_BIAS_RESIDUAL, EPI_BIAS_QUICKGELU_DERIV, EPI_MUL_AUX_COLSUM = 0, 1, 2, 3, 4, 5
 ACT_GELU_NEW, ACT_SQRELU = 0, 1
 
 _c = ctypes

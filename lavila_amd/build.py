@@ -20,7 +20,10 @@ ARCH = 'gfx950'
 # Per-file flags. -fno-honor-nans for the MFMA attention kernels: without it every fmaxf on an MFMA result gets a
 # canonicalising v_max x,x in front (a quarter of the softmax's VALU instructions); their scores are never NaN (finite
 # operands, -inf only through the masks, every inf - inf guarded by a select) -- attn_mfma_common.h, max3_raw.
-EXTRA_FLAGS = {'attn_space_mfma.hip': ['-fno-honor-nans'], 'attn_space_stream.hip': ['-fno-honor-nans']}
+# -fno-slp-vectorize for the TN GEMM: the SLP vectoriser turns pairs of f32 multiplies / adds of the epilogues into v_pk_*_f32,
+# which run at half the rate of the scalar instructions on gfx950 (tools/probes/valu_gelu.hip; round 6).
+EXTRA_FLAGS = {'attn_space_mfma.hip': ['-fno-honor-nans'], 'attn_space_stream.hip': ['-fno-honor-nans'],
+               'gemm_tn_mfma.hip': ['-fno-slp-vectorize']}
 
 
 def _hipcc():

@@ -15,6 +15,12 @@
 //                                                                          `x + attn(...)`, `x + mlp(...)` adds
 //                                                                          (timesformer.py:183-196) leave the GEMM as
 //                                                                          the new residual stream
+//   4  u = acc + bias ; y = u * sigmoid(1.702 u) ; aux_out = quickgelu'(u) epilogue 1 for training (bf16 only): the
+//                                                                          backward needs the DERIVATIVE, and the forward
+//                                                                          has sigmoid(1.702 u) in a register already
+//   5  y = acc * aux_in ; column sums of y -> partial slab                 epilogue 2 on the stored derivative: no
+//                                                                          transcendental in the backward (epilogue 2
+//                                                                          is VALU-bound: +6 us per 28-us tile)
 //
 // f32-CLASS MODE (template F32O, C-ABI dtype LVL_F32): the SAME kernel -- tile walk, LDS-DMA ring, swizzle, MFMA phases,
 // bias image, epilogue arithmetic -- with float32 results. The operands are bf16 TERM IMAGES of float32 matrices
@@ -103,6 +109,19 @@ __device__ __forceinline__ float quick_gelu_grad(float u) {
   return s * (1.f + 1.702f * u * (1.f - s));
 }
 
+// QuickGELU pieces of the bf16 epilogues, scalar f32 on purpose: v_pk_mul / v_pk_add / v_pk_fma_f32 run at HALF the rate
+// of their scalar forms on this part (tools/probes/valu_gelu.hip, profiles/r06_gemm_epilogues.txt: ~8 cycles per wave64
+// instruction against ~2) -- the file is compiled with -fno-slp-vectorize so that the compiler does not form them either.
+// quickgelu(u) = u r, r = sigmoid(1.702 u) = 1 / (1 + 2^(-1.702 log2(e) u)); quickgelu'(u) = r (1 + 1.702 u (1 - r))
+// = r + 1.702 (u r)(1 - r).
+__device__ __forceinline__ float bf16_lo(uint32_t p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t p) { return __uint_as_float(p & 0xffff0000u); }
+__device__ __forceinline__ void qgelu1(float u, float& y, float& r) {
+  r = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(u * (-1.702f * 1.44269504088896341f)));
+  y = u * r;
+}
+__device__ __forceinline__ float qgelu_grad1(float y, float r) { return fmaf((1.f - r) * y, 1.702f, r); }
+
 // lanes l < 32 and l + 32 hold adjacent 8-byte pieces (4 bf16) of the same output row for two neighbouring
 // column groups `a` (columns c..c+3 | c+4..c+7) and `b` (c+8.. | c+12..): one half-swap per dword leaves the
 // lower lane with 16 contiguous bytes of group a and the upper lane with 16 contiguous bytes of group b.
@@ -132,6 +151,17 @@ __device__ __forceinline__ void gm_store16(void* p, uint4 v) {
   asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(__builtin_bit_cast(lvl_u32x4, v)) : "memory");
 #endif
 }
+
+// build-time shape of the aux_in epilogues (see `epilogue`): row groups requested up front, re-read of xA / wA
+#ifndef GM_UPFRONT_RES
+#define GM_UPFRONT_RES 4
+#endif
+#ifndef GM_UPFRONT_COLSUM
+#define GM_UPFRONT_COLSUM 3
+#endif
+#ifndef GM_REREAD_RES
+#define GM_REREAD_RES 1
+#endif
 
 template <int EPI, bool F32O>
 __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
@@ -287,6 +317,7 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
   // 32x32x16 operand: lane l carries row (l & 31), contraction elements 8*(l>>5) .. +7 of the K=16 slice kk, i.e.
   // logical chunk 2*kk + (l>>5) of the row's eight 16-byte chunks.
   const int r5 = lane & 31, hi = lane >> 5;
+  const int r5_ = r5, hi_ = hi;
   uint32_t xa[4], wa[4];
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) {
@@ -334,28 +365,24 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
     }
   };
 
+  uint4 xA[8], xB[8], wA[4], wB[4];      // operand fragments of the K loop (declared here: the epilogue re-reads xA / wA)
+  int par = 0;                            // ring half (slot offset 0 / 4) of the K block being multiplied
+
   auto epilogue = [&](int tm, int tn, int ti) {
     const int64_t m0 = (int64_t)tm * TM;
     const int n0 = tn * TN;
-    float csum[32];
-    // EPI 2: the 8 pre-activation pieces of a row group are loaded one row group AHEAD (issued before the previous
-    // group's stores, so their latency overlaps its arithmetic instead of serialising eight round trips per tile)
-    constexpr bool AUXIN = EPI == 2 || EPI == 3;      // aux_in rows ride one row group ahead of the stores
-    uint2 ub_next[AUXIN ? 8 : 1];
-    auto load_u = [&](int j) {
-      const int64_t m = m0 + (j >> 1) * 128 + wm * 64 + (j & 1) * 32 + r5;
-      const uint16_t* urow = reinterpret_cast<const uint16_t*>(aux_in) + (m < M ? m : M - 1) * (int64_t)N + n0 + wn * 64 + 4 * hi;
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int rq = 0; rq < 4; ++rq) ub_next[i * 4 + rq] = *reinterpret_cast<const uint2*>(urow + i * 32 + 8 * rq);
-    };
-    if (EPI == 2) {
+    // the lane's row / column-half as the epilogue sees them: opaque copies, so that the per-lane 64-bit row offsets
+    // (tile-invariant: (wm*64 + r5) * N + ...) are computed here, per tile, instead of being hoisted out of the tile
+    // loop into registers the K loop does not have (they were spilled, and reloaded BEHIND the result stores)
+    int r5 = r5_, hi = hi_;
+    asm volatile("" : "+v"(r5), "+v"(hi));
+    constexpr bool COLSUM = EPI == 2 || EPI == 5;                 // column sums of y leave as a partial slab
+    constexpr bool AUXIN = EPI == 2 || EPI == 3 || EPI == 5;      // an aux_in row rides with every result row
+    constexpr bool TWO_OUT = EPI == 1 || EPI == 4;
+    float csum[COLSUM ? 32 : 1];          // value c = column (c>>4)*32 + ((c>>2)&3)*8 + 4*hi + (c&3) of the wave's 64
+    if (COLSUM) {
 #pragma unroll
       for (int c = 0; c < 32; ++c) csum[c] = 0.f;
-    }
-    if (AUXIN) {
-      if constexpr (!F32O) load_u(0);
     }
     if constexpr (F32O) {
       // float32 results (f32-class mode): an accumulator quad IS 4 consecutive output columns of one row -> one
@@ -403,16 +430,58 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
         }
       }
     } else {
+    // bf16 results. The hardware's vmcnt counts result stores, the compiler's wait insertion counts loads only: a wait it
+    // places for an aux_in load (residual stream / QuickGELU derivative / pre-activation rows) BEHIND a group's stores is
+    // too strict by the number of those stores and waits for their acknowledgement -- one store drain per row group, +10 us
+    // per tile with the loads one group ahead of the stores (round 6: proj + residual 0.34 ms against 0.23 ms for the plain
+    // epilogue on the same shape). So the aux rows of ALL FOUR row groups are requested, and every one of them has landed
+    // (`landed`: a register use the compiler has to wait for), before the first store leaves; from there on nothing is
+    // pending and packing and stores interleave freely. Registers: UPFRONT groups are requested at once, the rest when
+    // group 0 is packed and its accumulators are dead; HOLD groups are packed before the first store; with REREAD the next
+    // tile's first fragments (xA / wA, read during the last K block) are not carried across the epilogue but read again
+    // from the ring under the last stores (the column-sum epilogues hold 32 running sums on top of the aux rows).
+    constexpr int UPFRONT = COLSUM ? GM_UPFRONT_COLSUM : GM_UPFRONT_RES;
+    constexpr int HOLD = UPFRONT == 4 ? 1 : 2;
+    constexpr bool REREAD = COLSUM ? true : (GM_REREAD_RES != 0);
+    uint2 ub[AUXIN ? 4 : 1][8];
+    auto load_u = [&](int j, uint2 (&dst)[8]) {
+      const int64_t m = m0 + (j >> 1) * 128 + wm * 64 + (j & 1) * 32 + r5;
+      const uint16_t* urow = reinterpret_cast<const uint16_t*>(aux_in) + (m < M ? m : M - 1) * (int64_t)N + n0 + wn * 64 + 4 * hi;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) dst[i * 4 + rq] = *reinterpret_cast<const uint2*>(urow + i * 32 + 8 * rq);
+    };
+    auto landed = [&](const uint2 (&src)[8]) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) asm volatile("" ::"v"(src[q].x), "v"(src[q].y));
+    };
+    if constexpr (AUXIN) {
+#pragma unroll
+      for (int j = 0; j < UPFRONT; ++j) load_u(j, ub[j]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    uint4 yv[AUXIN ? HOLD : 1][2][2], uv[2][2];      // [row group][qn][jj]: 16 bytes = columns qn*32 + 16*jj + 8*hi .. +7 of row r5
+    auto store_group = [&](int j, const uint4 (&y4)[2][2]) {
+      // 16-byte stores: lower lanes take columns 16*jj .. +7, upper lanes 16*jj + 8 .. +15 of a column group
+      // (an LDS-staged variant that leaves as full 128-byte lines measured no faster: the tail is not line-bound)
+      const int64_t m = m0 + (j >> 1) * 128 + wm * 64 + (j & 1) * 32 + r5;
+      if (m < M) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) {
+            const int64_t o = m * (int64_t)N + n0 + wn * 64 + i * 32 + 16 * jj + 8 * hi;
+            gm_store16(Y + o, y4[i][jj]);
+            if (TWO_OUT) gm_store16(aux_out + o, uv[i][jj]);
+          }
+      }
+    };
 #pragma unroll
     for (int j = 0; j < 4; ++j) {          // row group (qm, mt): 32 rows
       const int64_t mg = m0 + (j >> 1) * 128 + wm * 64 + (j & 1) * 32;
-      uint2 ub_cur[AUXIN ? 8 : 1];
-      if (AUXIN) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) ub_cur[q] = ub_next[q];
-        if (j < 3) load_u(j + 1);
-      }
-      uint4 yv[2][2], uv[2][2];           // [qn][jj]: 16 bytes = columns qn*32 + 16*jj + 8*hi .. +7 of row r5
+      const float rowv = mg + r5 < M ? 1.f : 0.f;      // rows behind M (tail tile) stay out of the column sums
+      uint4 (&y4)[2][2] = yv[AUXIN && j < HOLD ? j : 0];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {        // column group qn
         const gm_f32x16& a16 = acc[j >> 1][i][j & 1];
@@ -426,56 +495,80 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
             upk[rq] = make_uint2(f32x2_to_bf16x2(v[0], v[1]), f32x2_to_bf16x2(v[2], v[3]));
             // the activation sees the ROUNDED pre-activation (what the reference's bf16 Linear output holds and
             // what the backward reads back)
-            v[0] = quick_gelu(__uint_as_float(upk[rq].x << 16));
-            v[1] = quick_gelu(__uint_as_float(upk[rq].x & 0xffff0000u));
-            v[2] = quick_gelu(__uint_as_float(upk[rq].y << 16));
-            v[3] = quick_gelu(__uint_as_float(upk[rq].y & 0xffff0000u));
+            float r;
+            qgelu1(bf16_lo(upk[rq].x), v[0], r);
+            qgelu1(bf16_hi(upk[rq].x), v[1], r);
+            qgelu1(bf16_lo(upk[rq].y), v[2], r);
+            qgelu1(bf16_hi(upk[rq].y), v[3], r);
           }
-          if (EPI == 3) {              // + the residual row (bf16), in f32 before the one rounding of the sum
-            const uint2 rb = ub_cur[i * 4 + rq];
-            v[0] += __uint_as_float(rb.x << 16);
-            v[1] += __uint_as_float(rb.x & 0xffff0000u);
-            v[2] += __uint_as_float(rb.y << 16);
-            v[3] += __uint_as_float(rb.y & 0xffff0000u);
-          }
-          if (EPI == 2) {
-            const bool valid = mg + r5 < M;
-            const uint2 ub = ub_cur[i * 4 + rq];
-            v[0] *= quick_gelu_grad(__uint_as_float(ub.x << 16));
-            v[1] *= quick_gelu_grad(__uint_as_float(ub.x & 0xffff0000u));
-            v[2] *= quick_gelu_grad(__uint_as_float(ub.y << 16));
-            v[3] *= quick_gelu_grad(__uint_as_float(ub.y & 0xffff0000u));
-            if (valid) {
+          if (EPI == 4) {                // y = quickgelu(u), aux_out = quickgelu'(u): one exp2 + one rcp serve both
+            float g[4];
 #pragma unroll
-              for (int e = 0; e < 4; ++e) csum[i * 16 + rq * 4 + e] += v[e];
+            for (int e = 0; e < 4; ++e) {
+              float y, r;
+              qgelu1(v[e], y, r);
+              g[e] = qgelu_grad1(y, r);
+              v[e] = y;
             }
+            upk[rq] = make_uint2(f32x2_to_bf16x2(g[0], g[1]), f32x2_to_bf16x2(g[2], g[3]));
+          }
+          if (AUXIN) {
+            const uint2 ab = ub[j][i * 4 + rq];
+            const float a4[4] = {bf16_lo(ab.x), bf16_hi(ab.x), bf16_lo(ab.y), bf16_hi(ab.y)};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              if (EPI == 3) v[e] += a4[e];        // + the residual row (bf16), in f32 before the one rounding of the sum
+              if (EPI == 5) v[e] *= a4[e];        // the forward left quickgelu'(u) itself
+              if (EPI == 2) {
+                float y, r;
+                qgelu1(a4[e], y, r);
+                v[e] *= qgelu_grad1(y, r);
+              }
+            }
+          }
+          if (COLSUM) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) csum[i * 16 + rq * 4 + e] = fmaf(v[e], rowv, csum[i * 16 + rq * 4 + e]);
           }
           ypk[rq] = make_uint2(f32x2_to_bf16x2(v[0], v[1]), f32x2_to_bf16x2(v[2], v[3]));
         }
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
-          yv[i][jj] = widen_pair(ypk[2 * jj], ypk[2 * jj + 1]);
-          if (EPI == 1) uv[i][jj] = widen_pair(upk[2 * jj], upk[2 * jj + 1]);
+          y4[i][jj] = widen_pair(ypk[2 * jj], ypk[2 * jj + 1]);
+          if (TWO_OUT) uv[i][jj] = widen_pair(upk[2 * jj], upk[2 * jj + 1]);
         }
       }
-      // 16-byte stores: lower lanes take columns 16*jj .. +7, upper lanes 16*jj + 8 .. +15 of a column group
-      // (an LDS-staged variant that leaves as full 128-byte lines measured no faster: the tail is not line-bound)
-      const int64_t m = mg + r5;
-      if (m < M) {
+      if constexpr (AUXIN) {
+        if (j == 0 && UPFRONT < 4) {
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+          for (int jn = UPFRONT; jn < 4; ++jn) load_u(jn, ub[jn]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (j == HOLD - 1) {               // every aux row has landed: stores may leave
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int jj = 0; jj < 2; ++jj) {
-            const int64_t o = m * (int64_t)N + n0 + wn * 64 + i * 32 + 16 * jj + 8 * hi;
-            gm_store16(Y + o, yv[i][jj]);
-            if (EPI == 1) gm_store16(aux_out + o, uv[i][jj]);
-          }
+          for (int jn = HOLD; jn < 4; ++jn) landed(ub[jn]);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int jp = 0; jp < HOLD; ++jp) store_group(jp, yv[jp]);
+        }
+        if (REREAD && j == 3) {
+          __builtin_amdgcn_sched_barrier(0);
+          read_x(par + S_X0, xA);
+          read_w(par + S_W0, wA);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (j >= HOLD) store_group(j, y4);
+      } else {
+        store_group(j, y4);
       }
     }
     }
-    if (EPI == 2) {
+    if (COLSUM) {
       // column sums over the wave's 128 rows: 32 values per lane, summed over the 32 lanes of each half-wave by a
       // halving butterfly (31 exchanges): lane r5 ends up with the total of value index c = r5
+      float (&cs)[COLSUM ? 32 : 1] = csum;
       int cnt2 = 16;
 #pragma unroll
       for (int mask = 16; mask >= 1; mask >>= 1) {
@@ -483,16 +576,16 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
           if (c < cnt2) {
-            const float lo = csum[c], hv = csum[c + cnt2];
+            const float lo = cs[c], hv = cs[c + cnt2];
             const float send = up ? lo : hv, keep = up ? hv : lo;
-            csum[c] = keep + __shfl_xor(send, mask, 64);
+            cs[c] = keep + __shfl_xor(send, mask, 64);
           }
         }
         cnt2 >>= 1;
       }
       const int c = r5;
       const int col = (c >> 4) * 32 + ((c >> 2) & 3) * 8 + 4 * hi + (c & 3);
-      colpart[(size_t)(tm * 2 + wm) * N + n0 + wn * 64 + col] = csum[0];
+      colpart[(size_t)(tm * 2 + wm) * N + n0 + wn * 64 + col] = cs[0];
     }
   };
 
@@ -524,7 +617,6 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
     if (my_tiles) pull();                       // tile 1: the reply lands during the prologue fills and tile 0's first blocks
   }
   GM_STAMP();
-  uint4 xA[8], xB[8], wA[4], wB[4];
   if (my_tiles > 0) {
   fetch_tile(0);
 #pragma unroll
@@ -575,7 +667,6 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
   __builtin_amdgcn_sched_barrier(0);
   GM_STAMP();
   init_acc(0);
-  int par = 0;
   // One K block = four phases. A0 / A1 are added to the vmcnt allowance of the barriers in front of P0,P1 / P2,P3:
   // vector-memory operations retire in issue order, so in the first block(s) after an epilogue -- while the slot a
   // barrier waits for was still filled BEFORE that epilogue -- the epilogue's NS result stores sit between the
@@ -583,7 +674,7 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
   // tile ~2 us of idle matrix pipe).
   // (f32-class mode: its 32 / 64 wider stores would overflow the 6-bit vmcnt field together with the fills -- no
   // allowance there: the first blocks of the next tile also wait for the previous tile's stores)
-  constexpr int NS = F32O ? 0 : (EPI == 1 ? 32 : 16);
+  constexpr int NS = F32O ? 0 : (EPI == 1 || EPI == 4 ? 32 : 16);
   auto k_block = [&](auto a0_, auto a1_) {
     constexpr int A0 = decltype(a0_)::value, A1 = decltype(a1_)::value;
     const uint8_t* sb = smem + par * SLOT;
@@ -739,6 +830,10 @@ extern "C" int lvl_linear_tn(const void* x, const void* w, const float* bias, vo
         const int P = (int)(2 * ((M + TM - 1) / TM));
         return lvl_launch_column_reduce(ws, P, N, N, ws + (size_t)P * N, colsum, nullptr, nullptr, st);
       }
+      case LVL_EPI_BIAS_QUICKGELU_DERIV:
+      case LVL_EPI_MUL_AUX_COLSUM:
+        return lvl_fail(LVL_ENOSYS, "linear_tn: epilogue %d is a bf16 epilogue (the f32-class mode keeps the pre-activation: "
+                                    "LVL_EPI_BIAS_QUICKGELU / LVL_EPI_QUICKGELU_BWD)", epilogue);
       default:
         return lvl_fail(LVL_EINVAL, "linear_tn: unknown epilogue %d", epilogue);
     }
@@ -756,6 +851,17 @@ extern "C" int lvl_linear_tn(const void* x, const void* w, const float* bias, vo
       LVL_REQUIRE(aux_in != nullptr && colsum != nullptr && ws != nullptr && lvl_aligned16(ws),
                   "linear_tn: the QuickGELU-backward epilogue needs aux_in, colsum and a workspace");
       const int rc = launch_tn<2>(x, w, nullptr, y, nullptr, aux_in, ws, M, N, K, sched, st);
+      if (rc != LVL_OK) return rc;
+      const int P = (int)(2 * ((M + TM - 1) / TM));
+      return lvl_launch_column_reduce(ws, P, N, N, ws + (size_t)P * N, colsum, nullptr, nullptr, st);
+    }
+    case LVL_EPI_BIAS_QUICKGELU_DERIV:
+      LVL_REQUIRE(aux_out != nullptr, "linear_tn: the QuickGELU + derivative epilogue writes quickgelu'(u) to aux_out");
+      return launch_tn<4>(x, w, bias, y, aux_out, nullptr, nullptr, M, N, K, sched, st);
+    case LVL_EPI_MUL_AUX_COLSUM: {
+      LVL_REQUIRE(aux_in != nullptr && colsum != nullptr && ws != nullptr && lvl_aligned16(ws),
+                  "linear_tn: the multiply-by-aux epilogue needs aux_in, colsum and a workspace");
+      const int rc = launch_tn<5>(x, w, nullptr, y, nullptr, aux_in, ws, M, N, K, sched, st);
       if (rc != LVL_OK) return rc;
       const int P = (int)(2 * ((M + TM - 1) / TM));
       return lvl_launch_column_reduce(ws, P, N, N, ws + (size_t)P * N, colsum, nullptr, nullptr, st);

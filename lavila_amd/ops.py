@@ -294,12 +294,18 @@ class _LinearFn(torch.autograd.Function):
         return dx, dw, db
 
 
+# What the fused MLP keeps for its backward in bf16: quickgelu'(u) (default) or the pre-activation u (LAVILA_GELU_DERIV=0).
+GELU_DERIV = os.environ.get('LAVILA_GELU_DERIV', '1') != '0'
+
+
 class _MlpFn(torch.autograd.Function):
     """y = fc2(QuickGELU(fc1(x) + b1)) without fc2's bias (the caller leaves it pending for the next fused
     residual + LayerNorm): timesformer.py:52-58 / openai_model.py:189-192. Two lvl_linear_tn calls forward (the
-    first one adds the bias, applies the activation and keeps the pre-activation u), and in backward the QuickGELU
+    first one adds the bias, applies the activation and keeps what the backward needs), and in backward the QuickGELU
     derivative and the fc1 bias gradient are the epilogue of fc2's input-gradient GEMM: the [rows, 4D] tensors are
-    touched by GEMM epilogues only."""
+    touched by GEMM epilogues only. What is kept (GELU_DERIV): bf16 keeps quickgelu'(u) itself -- the forward epilogue
+    has sigmoid(1.702 u) in a register, the backward epilogue then is one multiply (LVL_EPI_BIAS_QUICKGELU_DERIV /
+    LVL_EPI_MUL_AUX_COLSUM; LAVILA_GELU_DERIV=0 keeps the pre-activation u as the f32-class mode always does)."""
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2):
@@ -309,7 +315,9 @@ class _MlpFn(torch.autograd.Function):
         f32 = ctx.f32 = x.dtype == torch.float32        # f32-class mode: term images in, float32 u / a / y
         w1b, w1t = weight_copies(w1, f32)
         w2b, w2t = weight_copies(w2, f32)
-        a, u = linear_tn_raw(split3(x2, 0) if f32 else x2, w1b, _f32(b1), C.EPI_BIAS_QUICKGELU, f32=f32)
+        ctx.deriv = GELU_DERIV and not f32
+        a, u = linear_tn_raw(split3(x2, 0) if f32 else x2, w1b, _f32(b1),
+                             C.EPI_BIAS_QUICKGELU_DERIV if ctx.deriv else C.EPI_BIAS_QUICKGELU, f32=f32)
         y = linear_tn_raw(split3(a, 0) if f32 else a, w2b, None, C.EPI_BIAS, f32=f32)
         ctx.save_for_backward(x2, u, a, w1t, w2t)
         ctx.meta = (w1.dtype, None if b1 is None else b1.dtype, w2.dtype, x.shape)
@@ -330,7 +338,7 @@ class _MlpFn(torch.autograd.Function):
                   if ctx.needs_input_grad[0] else None)
             dw1 = _wgrad_f32(du, x2, w1dt) if ctx.needs_input_grad[1] else None
             return dx, dw1, (db1.to(b1dt) if (b1dt is not None and ctx.needs_input_grad[2]) else None), dw2
-        du, db1 = linear_tn_raw(dy2, w2t, None, C.EPI_QUICKGELU_BWD, aux_in=u)
+        du, db1 = linear_tn_raw(dy2, w2t, None, C.EPI_MUL_AUX_COLSUM if ctx.deriv else C.EPI_QUICKGELU_BWD, aux_in=u)
         dw2 = _wgrad(dy2, a, w2dt) if ctx.needs_input_grad[3] else None
         dx = linear_tn_raw(du, w1t, None, C.EPI_BIAS).reshape(xshape) if ctx.needs_input_grad[0] else None
         dw1 = _wgrad(du, x2, w1dt) if ctx.needs_input_grad[1] else None
@@ -407,24 +415,25 @@ def sched_block(device, words=16):
 
 def linear_tn_raw(x, w, bias=None, epilogue=C.EPI_BIAS, aux_in=None, f32=False):
     """One lvl_linear_tn call on bf16 tensors: y[M,N] = epilogue(x[M,K] . w[N,K]^T).
-    Returns y (EPI_BIAS; EPI_BIAS_RESIDUAL: + aux_in [M,N]), (y, u) (EPI_BIAS_QUICKGELU) or (y, colsum) (EPI_QUICKGELU_BWD).
+    Returns y (EPI_BIAS; EPI_BIAS_RESIDUAL: + aux_in [M,N]), (y, u) (EPI_BIAS_QUICKGELU), (y, quickgelu'(u))
+    (EPI_BIAS_QUICKGELU_DERIV) or (y, colsum) (EPI_QUICKGELU_BWD, EPI_MUL_AUX_COLSUM).
     f32=True: the kernel's f32-class mode -- x, w are bf16 term images (split3), y / u / aux_in float32."""
     C.require_device(x, w, bias, aux_in)
     M, K = x.shape
     N = w.shape[0]
     y = torch.empty(M, N, dtype=torch.float32 if f32 else torch.bfloat16, device=x.device)
     aux_out = colsum = ws = None
-    if epilogue == C.EPI_BIAS_QUICKGELU:
+    if epilogue in (C.EPI_BIAS_QUICKGELU, C.EPI_BIAS_QUICKGELU_DERIV):
         aux_out = torch.empty_like(y)
-    elif epilogue == C.EPI_QUICKGELU_BWD:
+    elif epilogue in (C.EPI_QUICKGELU_BWD, C.EPI_MUL_AUX_COLSUM):
         colsum = torch.empty(N, dtype=torch.float32, device=x.device)
         ws = C.workspace('linear_tn', M, N, x.device)
     C.check(C.lib().lvl_linear_tn(C.ptr(x), C.ptr(w), C.ptr(bias), C.ptr(y), C.ptr(aux_out), C.ptr(aux_in),
                                   C.ptr(colsum), C.ptr(ws), C.ptr(sched_block(x.device)), M, N, K, epilogue,
                                   C.LVL_F32 if f32 else C.LVL_BF16, C.stream_ptr()), 'lvl_linear_tn')
-    if epilogue == C.EPI_BIAS_QUICKGELU:
+    if epilogue in (C.EPI_BIAS_QUICKGELU, C.EPI_BIAS_QUICKGELU_DERIV):
         return y, aux_out
-    if epilogue == C.EPI_QUICKGELU_BWD:
+    if epilogue in (C.EPI_QUICKGELU_BWD, C.EPI_MUL_AUX_COLSUM):
         return y, colsum
     return y
 
@@ -757,7 +766,8 @@ class _MlpResidualLayerNormFn(torch.autograd.Function):
         res2 = res2 if res2.is_contiguous() else res2.contiguous()
         w1b, w1t = weight_copies(w1)
         w2b, w2t = weight_copies(w2)
-        a, u = linear_tn_raw(x2, w1b, _f32(b1), C.EPI_BIAS_QUICKGELU)
+        ctx.deriv = GELU_DERIV
+        a, u = linear_tn_raw(x2, w1b, _f32(b1), C.EPI_BIAS_QUICKGELU_DERIV if ctx.deriv else C.EPI_BIAS_QUICKGELU)
         s = linear_tn_raw(a, w2b, _f32(b2), C.EPI_BIAS_RESIDUAL, aux_in=res2)
         g = _f32(gamma)
         h, _, mean, rstd = layernorm_fwd_raw(s, None, None, g, _f32(beta), eps, False)
@@ -774,7 +784,8 @@ class _MlpResidualLayerNormFn(torch.autograd.Function):
         dsum, dg, dbeta, dcol = layernorm_bwd_raw(dh.reshape(s.shape).contiguous(), s, None, None, g, mean, rstd, dadd,
                                                   b2dt is not None)
         with torch.autocast('cuda', enabled=False):
-            du, db1 = linear_tn_raw(dsum, w2t, None, C.EPI_QUICKGELU_BWD, aux_in=u)
+            du, db1 = linear_tn_raw(dsum, w2t, None, C.EPI_MUL_AUX_COLSUM if ctx.deriv else C.EPI_QUICKGELU_BWD,
+                                    aux_in=u)
             dw2 = _wgrad(dsum, a, w2dt) if ctx.needs_input_grad[3] else None
             dx = linear_tn_raw(du, w1t, None, C.EPI_BIAS).reshape(xshape) if ctx.needs_input_grad[0] else None
             dw1 = _wgrad(du, x2, w1dt) if ctx.needs_input_grad[1] else None

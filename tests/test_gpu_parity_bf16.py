@@ -147,6 +147,53 @@ def test_linear_tn_residual_epilogue_exact_on_integer_operands(M, N, K):
     assert (got - ref).norm() <= (two - ref).norm() * 1.0001
 
 
+@pytest.mark.parametrize('M,N,K', [(1000, 768, 768), (70001, 256, 192), (513, 3072, 768), (1, 256, 64)])
+def test_linear_tn_quickgelu_derivative_epilogues(M, N, K):
+    """LVL_EPI_BIAS_QUICKGELU_DERIV / LVL_EPI_MUL_AUX_COLSUM (the training pair of Mlp.fc1 + QuickGELU, timesformer.py:52-54,
+    and of its backward): y = u sigmoid(1.702 u) and aux_out = d quickgelu(u) from the f32 accumulator, each rounded once;
+    y = acc * aux_in exact on small integers, column sums in f32 (tail tiles and one-row problems included)."""
+    from lavila_amd import _cabi as C
+    from lavila_amd import ops
+    g = torch.Generator().manual_seed(M + 2)
+    xr = torch.randn(M, K, generator=g).to(DEV).bfloat16()
+    wr = (torch.randn(N, K, generator=g) * 2 * K ** -0.5).to(DEV).bfloat16()
+    b = torch.randn(N, generator=g).to(DEV)
+    u = xr.double() @ wr.double().t() + b.double()
+    sg = torch.sigmoid(1.702 * u)
+    y, d = ops.linear_tn_raw(xr, wr, b, C.EPI_BIAS_QUICKGELU_DERIV)
+    assert y.dtype == torch.bfloat16 and d.dtype == torch.bfloat16
+    want_y, want_d = u * sg, sg * (1 + 1.702 * u * (1 - sg))
+    # one bf16 rounding (2^-9 relative) of a value computed in f32 from an f32 accumulator (|u| <~ 10)
+    assert (y.double() - want_y).abs().max() <= 2.0 ** -8 * want_y.abs().max() + 1e-6
+    assert ((y.double() - want_y).abs() <= 2.0 ** -8 * want_y.abs() + 2e-5).all()
+    assert ((d.double() - want_d).abs() <= 2.0 ** -8 * want_d.abs() + 2e-5).all()
+    # against the pre-activation form of the same kernel: the activation there sees bf16(u)
+    y1, u1 = ops.linear_tn_raw(xr, wr, b, C.EPI_BIAS_QUICKGELU)
+    assert (u1.double() - u).abs().max() <= 2.0 ** -8 * u.abs().max()
+    assert (y1.double() - y.double()).abs().max() <= 2.0 ** -6 * want_y.abs().max()
+    # backward form, exact: integer operands, integer 'derivatives'
+    x = torch.randint(-2, 3, (M, K), generator=g).float()
+    w = torch.randint(-1, 2, (N, K), generator=g).float() * (torch.rand(N, K, generator=g) < 0.08)
+    a = torch.randint(-2, 3, (M, N), generator=g).float()
+    want = (x @ w.t()) * a
+    assert want.abs().max() < 256
+    got, cs = ops.linear_tn_raw(x.to(DEV).bfloat16(), w.to(DEV).bfloat16(), None, C.EPI_MUL_AUX_COLSUM, aux_in=a.to(DEV).bfloat16())
+    assert torch.equal(got.float().cpu(), want)
+    assert torch.equal(cs.cpu(), want.sum(0))             # integers < 2^24: exact in any order
+    # the two backward forms agree on random data to the rounding of the stored derivative
+    dy = torch.randn(M, K, generator=g).to(DEV).bfloat16()
+    du5, cs5 = ops.linear_tn_raw(dy, wr, None, C.EPI_MUL_AUX_COLSUM, aux_in=d)
+    du2, cs2 = ops.linear_tn_raw(dy, wr, None, C.EPI_QUICKGELU_BWD, aux_in=u1)
+    ref = (dy.double() @ wr.double().t()) * want_d
+    scale = ref.abs().max()
+    assert (du5.double() - ref).abs().max() <= 2.0 ** -7 * scale
+    assert (du2.double() - ref).abs().max() <= 2.0 ** -6 * scale
+    assert (cs5.double() - ref.sum(0)).abs().max() <= 2.0 ** -7 * ref.abs().sum(0).max() + 1e-3
+    # no f32-class instantiation: refused loudly
+    with pytest.raises(C.HipExtensionError):
+        ops.linear_tn_raw(ops.split3(xr.float(), 0), ops.split3(wr.float(), 1), b, C.EPI_BIAS_QUICKGELU_DERIV, f32=True)
+
+
 @pytest.mark.parametrize('M,N,K', [(4096, 768, 768), (20000, 384, 192), (33, 2304, 768)])
 def test_linear_wgrad_exact_on_integer_operands(M, N, K):
     from lavila_amd import ops
@@ -188,9 +235,9 @@ def _tn_call(x, w, bias, epi, sched, aux_in=None):
     M, K = x.shape
     N = w.shape[0]
     y = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
-    aux_out = torch.empty_like(y) if epi == C.EPI_BIAS_QUICKGELU else None
-    colsum = torch.empty(N, dtype=torch.float32, device=DEV) if epi == C.EPI_QUICKGELU_BWD else None
-    ws = C.workspace('linear_tn', M, N, DEV) if epi == C.EPI_QUICKGELU_BWD else None
+    aux_out = torch.empty_like(y) if epi in (C.EPI_BIAS_QUICKGELU, C.EPI_BIAS_QUICKGELU_DERIV) else None
+    colsum = torch.empty(N, dtype=torch.float32, device=DEV) if epi in (C.EPI_QUICKGELU_BWD, C.EPI_MUL_AUX_COLSUM) else None
+    ws = C.workspace('linear_tn', M, N, DEV) if epi in (C.EPI_QUICKGELU_BWD, C.EPI_MUL_AUX_COLSUM) else None
     C.check(C.lib().lvl_linear_tn(C.ptr(x), C.ptr(w), C.ptr(bias), C.ptr(y), C.ptr(aux_out), C.ptr(aux_in), C.ptr(colsum),
                                   C.ptr(ws), C.ptr(sched), M, N, K, epi, C.LVL_BF16, C.stream_ptr()), 'lvl_linear_tn')
     return y, aux_out, colsum
@@ -199,7 +246,7 @@ def _tn_call(x, w, bias, epi, sched, aux_in=None):
 @pytest.mark.parametrize('M,N,K', [(70001, 768, 768), (9000, 2304, 768), (5000, 768, 3072), (200, 256, 320), (3000, 512, 256)])
 def test_dynamic_tile_schedule_equals_static_and_resets_its_counters(M, N, K):
     """include/lavila_hip.h, lvl_linear_tn `sched`: with a tile-counter block the persistent workgroups take their
-    tiles from per-XCD device counters; every tile's arithmetic is unchanged (bit-equal outputs for all three
+    tiles from per-XCD device counters; every tile's arithmetic is unchanged (bit-equal outputs for all six
     epilogues, column sums included), the block is zero again when the launch has drained (so the next launch can
     reuse it), and K < 5 blocks of 64 silently keeps the static ranges."""
     from lavila_amd import _cabi as C
@@ -210,7 +257,8 @@ def test_dynamic_tile_schedule_equals_static_and_resets_its_counters(M, N, K):
     u = torch.randn(M, N, device=DEV, generator=g).bfloat16()
     sched = torch.zeros(16, dtype=torch.int32, device=DEV)
     for epi, bias, aux in ((C.EPI_BIAS, b, None), (C.EPI_BIAS, None, None), (C.EPI_BIAS_QUICKGELU, b, None),
-                           (C.EPI_QUICKGELU_BWD, None, u)):
+                           (C.EPI_QUICKGELU_BWD, None, u), (C.EPI_BIAS_RESIDUAL, b, u), (C.EPI_BIAS_QUICKGELU_DERIV, b, None),
+                           (C.EPI_MUL_AUX_COLSUM, None, u)):
         want = _tn_call(x, w, bias, epi, None, aux)
         for rep in range(3):                       # the same block, back to back: it must come back zeroed
             got = _tn_call(x, w, bias, epi, sched, aux)

@@ -7,7 +7,8 @@
 #                            tools/ab_library_swap.sh run <out-file> [bench args...]
 #       alternates base / new / base / new: copies the library over lavila_amd/lib/liblavila_hip.so (the C ABI must be the
 #       same on both sides), runs `python bench.py --no-cpu-baseline --no-events <bench args>` and appends
-#       "<which> <pairs/s> <ms per step>" to <out-file>; restores the new library at the end.
+#       "<which> <pairs/s> <ms per step>" to <out-file>; restores the new library at the end. AB_BASE_ENV="VAR=value ..."
+#       is added to the environment of the base runs (a switch the host side needs for an older C ABI).
 # The base library is git-ignored (*.so) but travels with the gpurun snapshot; delete tools/probes/ab afterwards.
 set -u
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
@@ -34,7 +35,8 @@ case "${1:-}" in
     cp "$L" /tmp/lavila_new.so
     for v in base new base new; do
       if [ $v = base ]; then cp "$ROOT/tools/probes/ab/liblavila_hip_base.so" "$L"; else cp /tmp/lavila_new.so "$L"; fi
-      echo "$v $(cd "$ROOT" && timeout 300 python bench.py --no-cpu-baseline --no-events "$@" 2>/dev/null | grep '^{' | \
+      extra_env=""; [ $v = base ] && extra_env="${AB_BASE_ENV:-}"
+      echo "$v $(cd "$ROOT" && env $extra_env timeout 300 python bench.py --no-cpu-baseline --no-events "$@" 2>/dev/null | grep '^{' | \
         python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["ms_per_step"])')" >> "$out"
     done
     cp /tmp/lavila_new.so "$L"
