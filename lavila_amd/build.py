@@ -17,13 +17,18 @@ LIB = os.path.join(LIBDIR, 'liblavila_hip.so')
 ARCH = 'gfx950'
 
 
-# Per-file flags. -fno-honor-nans for the MFMA attention kernels: without it every fmaxf on an MFMA result gets a
-# canonicalising v_max x,x in front (a quarter of the softmax's VALU instructions); their scores are never NaN (finite
-# operands, -inf only through the masks, every inf - inf guarded by a select) -- attn_mfma_common.h, max3_raw.
-# -fno-slp-vectorize for the TN GEMM: the SLP vectoriser turns pairs of f32 multiplies / adds of the epilogues into v_pk_*_f32,
-# which run at half the rate of the scalar instructions on gfx950 (tools/probes/valu_gelu.hip; round 6).
+# Per-file flags.
+# -fno-honor-nans for the MFMA attention kernels: without it every fmaxf on an MFMA result gets a canonicalising v_max x,x in
+# front (a quarter of the softmax's VALU instructions); their scores are never NaN (finite operands, -inf only through the
+# masks, every inf - inf guarded by a select) -- attn_mfma_common.h, max3_raw.
+# -fno-slp-vectorize where it measured faster (round 6, profiles/r06_valu_rates.txt): the SLP vectoriser pairs f32 multiplies /
+# adds / fmas into v_pk_{mul,add,fma}_f32. Their THROUGHPUT is fine (2.7-3.4 cycles per pair against 1.6-2.2 per scalar
+# instruction) but in the dependent chains of a two-waves-per-SIMD kernel they are slower than the scalar forms: the TN GEMM's
+# QuickGELU epilogues (+30 % in tools/probes/valu_gelu.hip) and the fused space-attention backward (-3.2 % without them);
+# LayerNorm forward (+20 % WITHOUT them), the time attention and the streaming kernels keep the default.
+_NO_SLP = ['-fno-slp-vectorize']
 EXTRA_FLAGS = {'attn_space_mfma.hip': ['-fno-honor-nans'], 'attn_space_stream.hip': ['-fno-honor-nans'],
-               'gemm_tn_mfma.hip': ['-fno-slp-vectorize']}
+               'gemm_tn_mfma.hip': _NO_SLP, 'attn_space_bwd.hip': _NO_SLP}
 
 
 def _hipcc():

@@ -641,10 +641,14 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
   // vector-memory operations" with N = the operations issued after that slot's fills (10 / 8 / 10 / 10 for P0..P3;
   // the bias image and the epilogue's stores only make the wait stricter). The barrier is the bare s_barrier: a
   // fence would drain the run-ahead fills.
+  // GM_EXP (timing experiments only, results are WRONG): 1 = no s_barrier, 2 = no vmcnt wait, 3 = neither
+#ifndef GM_EXP
+#define GM_EXP 0
+#endif
 #define GM_BAR(N)                                                     \
   do {                                                                \
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");          \
-    __builtin_amdgcn_s_barrier();                                     \
+    if (!(GM_EXP & 2)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");          \
+    if (!(GM_EXP & 1)) __builtin_amdgcn_s_barrier();                  \
     asm volatile("" ::: "memory");                                    \
     __builtin_amdgcn_sched_barrier(0);                                \
   } while (0)

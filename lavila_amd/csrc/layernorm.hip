@@ -35,9 +35,11 @@ __device__ __forceinline__ void load_sum(const T* __restrict__ x, const T* __res
   }
 }
 
-template <typename T, int VPL, int W>
+// X2: the row is x + x2 (compile time: the plain LayerNorm then carries no registers for the second operand's two rows in
+// flight -- 76 -> 64 VGPRs for 768 columns = 8 instead of 6 waves per SIMD, round 6)
+template <typename T, int VPL, int W, bool X2>
 struct LnFwdRow {
-  RawVec<T, W> x[VPL], x2[VPL];
+  RawVec<T, W> x[VPL], x2[X2 ? VPL : 1];
   __device__ __forceinline__ void load(const T* __restrict__ px, const T* __restrict__ px2, int64_t row, int cols,
                                        int lane, int nvec) {
 #pragma unroll
@@ -45,14 +47,14 @@ struct LnFwdRow {
       const int c = lane + i * 64;
       if (c < nvec) {
         x[i].load(px + row * cols + c * W);
-        if (px2 != nullptr) x2[i].load(px2 + row * cols + c * W);
+        if constexpr (X2) x2[i].load(px2 + row * cols + c * W);
       }
     }
   }
 };
 
 // software-pipelined like the backward: the next row's packed operands are requested before this row is reduced
-template <typename T, int VPL, int W>
+template <typename T, int VPL, int W, bool X2>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(
     const T* __restrict__ x, const T* __restrict__ x2, const float* __restrict__ bias,
     const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ s_out,
@@ -63,7 +65,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(
   const float inv_cols = 1.0f / (float)cols;
   const int64_t stride = (int64_t)gridDim.x * kRowsPerBlock;
   int64_t row = (int64_t)blockIdx.x * kRowsPerBlock + wave;
-  LnFwdRow<T, VPL, W> cur, nxt;
+  LnFwdRow<T, VPL, W, X2> cur, nxt;
   if (row < rows) cur.load(x, x2, row, cols, lane, nvec);
   for (; row < rows; row += stride) {
     if (row + stride < rows) nxt.load(x, x2, row + stride, cols, lane, nvec);
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(
       const int c = lane + i * 64;
       if (c < nvec) {
         cur.x[i].unpack(v[i]);
-        if (x2 != nullptr) {
+        if constexpr (X2) {
           float w[W];
           cur.x2[i].unpack(w);
 #pragma unroll
@@ -433,14 +435,24 @@ extern "C" int lvl_layernorm_fwd(const void* x, const void* x2, const float* xbi
               "layernorm_fwd: pointers must be 16-byte aligned");
   if (rows == 0) return LVL_OK;
   int64_t blocks = (rows + kRowsPerBlock - 1) / kRowsPerBlock;
-  if (blocks > 3072) blocks = 3072;     // 2 x the resident workgroups at 6 waves/SIMD: long per-wave row chains
-#define LN_FWD_T(TT, VPL, W)                                                                                  \
-  hipLaunchKernelGGL((ln_fwd_kernel<TT, VPL, W>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,   \
+  // long per-wave row chains: 2 x the resident workgroups at 6 waves/SIMD for the two-operand form (76 VGPRs); the plain form
+  // (56 VGPRs, 8 waves/SIMD) measured best with 4 x its resident workgroups (0.136 ms at 8192 against 0.142 at 3072 and 0.176
+  // at 2048 for 200 960 rows of 768: profiles/r06_rowops_ln_fwd.txt)
+  const int64_t cap = x2 == nullptr ? 8192 : 3072;
+  if (blocks > cap) blocks = cap;
+#define LN_FWD_X(TT, VPL, W, X2)                                                                                \
+  hipLaunchKernelGGL((ln_fwd_kernel<TT, VPL, W, X2>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, \
                      (const TT*)x, (const TT*)x2, xbias, gamma, beta, (TT*)s_out, (TT*)y, mean, rstd, rows, cols, eps)
+#define LN_FWD_T(TT, VPL, W)                 \
+  do {                                       \
+    if (x2 != nullptr) LN_FWD_X(TT, VPL, W, true); \
+    else LN_FWD_X(TT, VPL, W, false);        \
+  } while (0)
 #define LN_FWD(VPL, W) LN_FWD_T(T, VPL, W)
   LVL_DISPATCH_DTYPE(dtype, LN_DISPATCH(cols, LN_FWD));
 #undef LN_FWD
 #undef LN_FWD_T
+#undef LN_FWD_X
   LVL_CHECK_LAUNCH("layernorm_fwd");
   return LVL_OK;
 }

@@ -17,11 +17,12 @@ case "${1:-}" in
   build)
     commit=${2:?commit}
     tmp=$(mktemp -d)
-    git -C "$ROOT" archive "$commit" lavila_amd/csrc include | tar -x -C "$tmp"
+    git -C "$ROOT" archive "$commit" lavila_amd/csrc lavila_amd/build.py include | tar -x -C "$tmp"
+    touch "$tmp/lavila_amd/__init__.py"
     mkdir -p "$ROOT/tools/probes/ab"
     for f in "$tmp"/lavila_amd/csrc/*.hip; do
-      extra=""
-      case $(basename "$f") in attn_space_mfma.hip|attn_space_stream.hip) extra="-fno-honor-nans";; esac
+      # that commit's own per-file flags (lavila_amd/build.py EXTRA_FLAGS)
+      extra=$(cd "$tmp" && python -c "import sys; sys.path.insert(0, '.'); from lavila_amd.build import EXTRA_FLAGS as E; print(' '.join(E.get('$(basename "$f")', [])))")
       /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-gpu-rdc -fvisibility=hidden $extra -c "$f" \
         -o "$tmp/$(basename "$f" .hip).o" 2>/dev/null &
     done
