@@ -215,8 +215,12 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
       asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_write_b32 %1, %2\n\ts_mov_b64 exec, %0"
                    : "=&s"(exec_save) : "v"((uint32_t)(uintptr_t)smem + MBOX_OFF), "v"(pend) : "memory");
   };
+  // (an LDS read in asm: through a volatile C++ pointer the compiler emits a FLAT load and waits vmcnt(0) for it -- a
+  // full drain of the run-ahead fills once per tile, 2-4 % of a launch on the dynamic schedule until round 6)
   auto mailbox = [&]() -> int {
-    return __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(smem + MBOX_OFF));
+    uint32_t v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((uint32_t)(uintptr_t)smem + MBOX_OFF) : "memory");
+    return __builtin_amdgcn_readfirstlane(v);
   };
   const bool late = dyn && late_mod > 0 && bid % late_mod == 1;      // test hook (lvl_debug_late_workgroups)
   // first tile: the one synchronous hand-out of a launch. Requested here, consumed behind the address set-up below

@@ -173,7 +173,10 @@ __global__ __launch_bounds__(64 * WN * WK) void wgrad_kernel(const uint16_t* __r
   auto collect = [&](int stage) -> int {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    const int v = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int*>(smem + stage * G::STAGE + G::TN));
+    // (asm LDS read: a volatile C++ read becomes a flat load with a vmcnt(0) drain of every wave's run-ahead fills)
+    uint32_t raw;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(raw) : "v"(mbox_addr(stage)) : "memory");
+    const int v = __builtin_amdgcn_readfirstlane(raw);
     __builtin_amdgcn_s_barrier();
     return v;
   };
