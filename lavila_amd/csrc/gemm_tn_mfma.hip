@@ -152,6 +152,12 @@ __device__ __forceinline__ void gm_store16(void* p, uint4 v) {
 #endif
 }
 
+// GM_EXP (timing experiments only, results are WRONG; tools/probe_gemm_variants.py): 1 = no s_barrier in the K loop, 2 = no vmcnt
+// wait in front of the barriers, 4 = epilogues 1 / 4 skip their second result store, 8 = epilogue 4 skips the QuickGELU arithmetic
+#ifndef GM_EXP
+#define GM_EXP 0
+#endif
+
 // build-time shape of the aux_in epilogues (see `epilogue`): row groups requested up front, re-read of xA / wA
 #ifndef GM_UPFRONT_RES
 #define GM_UPFRONT_RES 4
@@ -477,7 +483,7 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
           for (int jj = 0; jj < 2; ++jj) {
             const int64_t o = m * (int64_t)N + n0 + wn * 64 + i * 32 + 16 * jj + 8 * hi;
             gm_store16(Y + o, y4[i][jj]);
-            if (TWO_OUT) gm_store16(aux_out + o, uv[i][jj]);
+            if (TWO_OUT && !(GM_EXP & 4)) gm_store16(aux_out + o, uv[i][jj]);      // (GM_EXP 4: timing experiment)
           }
       }
     };
@@ -510,8 +516,8 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               float y, r;
-              qgelu1(v[e], y, r);
-              g[e] = qgelu_grad1(y, r);
+              if (GM_EXP & 8) { y = v[e]; r = v[e]; } else qgelu1(v[e], y, r);      // (GM_EXP 8: timing experiment)
+              g[e] = (GM_EXP & 8) ? r : qgelu_grad1(y, r);
               v[e] = y;
             }
             upk[rq] = make_uint2(f32x2_to_bf16x2(g[0], g[1]), f32x2_to_bf16x2(g[2], g[3]));
@@ -645,10 +651,6 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
   // vector-memory operations" with N = the operations issued after that slot's fills (10 / 8 / 10 / 10 for P0..P3;
   // the bias image and the epilogue's stores only make the wait stricter). The barrier is the bare s_barrier: a
   // fence would drain the run-ahead fills.
-  // GM_EXP (timing experiments only, results are WRONG): 1 = no s_barrier, 2 = no vmcnt wait, 3 = neither
-#ifndef GM_EXP
-#define GM_EXP 0
-#endif
 #define GM_BAR(N)                                                     \
   do {                                                                \
     if (!(GM_EXP & 2)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");          \

@@ -23,7 +23,8 @@ for name, p in [('tree', C.LIB_PATH)] + [(t, os.path.join(ROOT, 'tools', 'probes
     fns[name] = f
 M = 256 * 785
 dev = torch.device('cuda', 0)
-SHAPES = {'qkv': (2304, 768), 'proj': (768, 768), 'fc1': (3072, 768), 'fc2': (768, 3072)}
+EPI = int(os.environ.get('PROBE_EPI', '0'))      # 0 plain; 4 QuickGELU + derivative (two result tensors)
+SHAPES = {'qkv': (2304, 768), 'proj': (768, 768), 'fc1': (3072, 768), 'fc2': (768, 3072)} if EPI == 0 else {'fc1': (3072, 768)}
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 P = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
 random.seed(0)
@@ -32,6 +33,9 @@ for name, (N, K) in SHAPES.items():
     w = (torch.randn(N, K, device=dev) * K ** -0.5).bfloat16()
     b = torch.randn(N, device=dev)
     y = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    aux = torch.empty_like(y) if EPI in (1, 4) else None
+    if os.environ.get('PROBE_AUX_IS_Y') and aux is not None:
+        aux = y          # timing experiment: the second tensor's stores hit the first tensor's lines (no extra bytes to HBM)
     times = {k: [] for k in fns}
     for rep in range(10):
         order = list(fns)
@@ -40,7 +44,7 @@ for name, (N, K) in SHAPES.items():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(3):
-                rc = fns[k](P(x), P(w), P(b), P(y), None, None, None, None, None, M, N, K, 0, C.LVL_BF16, st)
+                rc = fns[k](P(x), P(w), P(b), P(y), P(aux), None, None, None, None, M, N, K, EPI, C.LVL_BF16, st)
                 assert rc == 0
             e1.record()
             torch.cuda.synchronize()
