@@ -174,11 +174,17 @@ template <int W> struct RawVec<float, W> {
 #pragma unroll
     for (int k = 0; k < W; ++k) v[k] = w[k];
   }
+  // an (empty) use the compiler has to have the registers loaded for: puts the wait for a pending load HERE
+  __device__ __forceinline__ void pin() {
+#pragma unroll
+    for (int k = 0; k < W; ++k) asm volatile("" : "+v"(w[k]));
+  }
 };
 template <> struct RawVec<bf16_t, 4> {
   uint2 w;
   __device__ __forceinline__ void load(const bf16_t* p) { w = *reinterpret_cast<const uint2*>(p); }
   __device__ __forceinline__ void zero() { w = make_uint2(0, 0); }
+  __device__ __forceinline__ void pin() { asm volatile("" : "+v"(w.x), "+v"(w.y)); }
   __device__ __forceinline__ void unpack(float (&v)[4]) const {
     v[0] = __uint_as_float(w.x << 16); v[1] = __uint_as_float(w.x & 0xffff0000u);
     v[2] = __uint_as_float(w.y << 16); v[3] = __uint_as_float(w.y & 0xffff0000u);
@@ -188,6 +194,7 @@ template <> struct RawVec<bf16_t, 8> {
   uint4 w;
   __device__ __forceinline__ void load(const bf16_t* p) { w = *reinterpret_cast<const uint4*>(p); }
   __device__ __forceinline__ void zero() { w = make_uint4(0, 0, 0, 0); }
+  __device__ __forceinline__ void pin() { asm volatile("" : "+v"(w.x), "+v"(w.y), "+v"(w.z), "+v"(w.w)); }
   __device__ __forceinline__ void unpack(float (&v)[8]) const {
     v[0] = __uint_as_float(w.x << 16); v[1] = __uint_as_float(w.x & 0xffff0000u);
     v[2] = __uint_as_float(w.y << 16); v[3] = __uint_as_float(w.y & 0xffff0000u);

@@ -6,7 +6,13 @@
 // Two vector widths: W = 4 when cols is a multiple of 256 (768 -> exactly 3 vectors per lane, no idle lanes,
 // 25 % fewer registers than 2 x 8 -> one more wave per SIMD in the backward), W = 8 otherwise.
 // Algorithmic bytes per row (E = element size): fwd cols*E*(n_in + n_out), bwd cols*E*(1 + n_in + 1).
+#include <stdlib.h>
+
 #include "common.h"
+
+// The general and the exact-width kernels must agree to the bit (activation checkpointing recomputes a forward that may take
+// the other instantiation): no implicit contraction in this file, every fused multiply-add is written as one.
+#pragma clang fp contract(off)
 
 namespace {
 
@@ -104,7 +110,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(
     for (int i = 0; i < VPL; ++i) {
       if (lane + i * 64 < nvec) {
 #pragma unroll
-        for (int j = 0; j < W; ++j) { const float d = v[i][j] - mu; sq += d * d; }
+        for (int j = 0; j < W; ++j) { const float d = v[i][j] - mu; sq = fmaf(d, d, sq); }
       }
     }
     const float rs = rsqrtf(wave_sum(sq) * inv_cols + eps);
@@ -116,7 +122,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(
         load_f32<W>(gamma + c * W, g);
         load_f32<W>(beta + c * W, b);
 #pragma unroll
-        for (int j = 0; j < W; ++j) o[j] = (v[i][j] - mu) * rs * g[j] + b[j];
+        for (int j = 0; j < W; ++j) o[j] = fmaf((v[i][j] - mu) * rs, g[j], b[j]);
         VecIO<T, W>::store(out + row * cols + c * W, o);
       }
     }
@@ -125,6 +131,98 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(
       if (rstd) rstd[row] = rs;
     }
     cur = nxt;
+  }
+}
+
+// EXACT-WIDTH forward (cols == VPL * 64 * W, no s_out; round 6): the same arithmetic as ln_fwd_kernel with NO conditional
+// vector-memory instruction in the row loop. Why it exists: the compiler's s_waitcnt insertion merges its counters
+// conservatively over branches, and ln_fwd_kernel's per-chunk `c < nvec` / `row + stride < rows` / nullable-pointer branches
+// left the row loop with `s_waitcnt vmcnt(0)` in front of the reductions (the prefetched NEXT row was waited for too) and
+// behind each per-row reload of gamma / beta (three dependent L2 round trips per row). Here gamma, beta (and the optional
+// bias) live in registers, the prefetch is unconditional (the last rows re-read row `rows - 1`), mean / rstd are stored by every
+// lane (one address), and every wait the compiler places is a counted one: the next row's loads and this row's stores stay in
+// flight across the reductions.
+template <typename T, int VPL, int W, bool X2, bool BIAS>
+__global__ __launch_bounds__(256) void ln_fwd_exact_kernel(
+    const T* __restrict__ x, const T* __restrict__ x2, const float* __restrict__ bias,
+    const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ out, float* __restrict__ mean,
+    float* __restrict__ rstd, int64_t rows, float eps) {
+  constexpr int cols = VPL * 64 * W;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float inv_cols = 1.0f / (float)cols;
+  const int64_t stride = (int64_t)gridDim.x * kRowsPerBlock;
+  int64_t row = (int64_t)blockIdx.x * kRowsPerBlock + wave;
+  if (row >= rows) return;
+  float g[VPL][W], b[VPL][W], bb[BIAS ? VPL : 1][W];
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    load_f32<W>(gamma + (lane + i * 64) * W, g[i]);
+    load_f32<W>(beta + (lane + i * 64) * W, b[i]);
+    if constexpr (BIAS) load_f32<W>(bias + (lane + i * 64) * W, bb[i]);
+  }
+  RawVec<T, W> cur[VPL], cur2[X2 ? VPL : 1], nxt[VPL], nxt2[X2 ? VPL : 1];
+  auto load_row = [&](int64_t r, RawVec<T, W> (&a)[VPL], RawVec<T, W> (&a2)[X2 ? VPL : 1]) {
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      a[i].load(x + r * cols + (lane + i * 64) * W);
+      if constexpr (X2) a2[i].load(x2 + r * cols + (lane + i * 64) * W);
+    }
+  };
+  load_row(row, cur, cur2);
+  // everything requested so far has landed before the loop is entered: the loop header then merges "nothing pending" with
+  // the back edge's counted state instead of a conservative vmcnt(0) on every iteration
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    cur[i].pin();
+    if constexpr (X2) cur2[i].pin();
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      asm volatile("" : "+v"(g[i][j]), "+v"(b[i][j]));
+      if constexpr (BIAS) asm volatile("" : "+v"(bb[i][j]));
+    }
+  }
+  for (; row < rows; row += stride) {
+    const int64_t rn = row + stride < rows ? row + stride : rows - 1;      // unconditional prefetch
+    load_row(rn, nxt, nxt2);
+    float v[VPL][W];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      cur[i].unpack(v[i]);
+      if constexpr (X2) {
+        float w[W];
+        cur2[i].unpack(w);
+#pragma unroll
+        for (int j = 0; j < W; ++j) v[i][j] += w[j];
+      }
+      if constexpr (BIAS) {
+#pragma unroll
+        for (int j = 0; j < W; ++j) v[i][j] += bb[i][j];
+      }
+#pragma unroll
+      for (int j = 0; j < W; ++j) sum += v[i][j];
+    }
+    const float mu = wave_sum(sum) * inv_cols;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i)
+#pragma unroll
+      for (int j = 0; j < W; ++j) { const float d = v[i][j] - mu; sq = fmaf(d, d, sq); }
+    const float rs = rsqrtf(wave_sum(sq) * inv_cols + eps);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      float o[W];
+#pragma unroll
+      for (int j = 0; j < W; ++j) o[j] = fmaf((v[i][j] - mu) * rs, g[i][j], b[i][j]);
+      VecIO<T, W>::store(out + row * cols + (lane + i * 64) * W, o);
+    }
+    mean[row] = mu;          // every lane, one address: no exec-masked (conditional) store in the loop; both non-null here
+    rstd[row] = rs;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      cur[i] = nxt[i];
+      if constexpr (X2) cur2[i] = nxt2[i];
+    }
   }
 }
 
@@ -156,6 +254,176 @@ struct LnBwdRow {
     }
   }
 };
+
+// the tail of both backward kernels: combine the 4 waves of a workgroup through LDS, then one partial slab per workgroup
+template <int VPL, int W>
+__device__ __forceinline__ void ln_bwd_combine(float* smem, float* __restrict__ part, float (&ag)[VPL][W], float (&ab)[VPL][W],
+                                               float (&ax)[VPL][W], int cols, int nvec, int lane, int wave) {
+  if (wave > 0) {
+    float* dst = smem + (size_t)(wave - 1) * 3 * cols;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int c = lane + i * 64;
+      if (c < nvec) {
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+          dst[c * W + j] = ag[i][j];
+          dst[cols + c * W + j] = ab[i][j];
+          dst[2 * cols + c * W + j] = ax[i][j];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (wave == 0) {
+    float* pg = part + (size_t)blockIdx.x * 3 * cols;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int c = lane + i * 64;
+      if (c < nvec) {
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+          float a = ag[i][j], b = ab[i][j], e = ax[i][j];
+          for (int w = 0; w < 3; ++w) {
+            a += smem[(size_t)w * 3 * cols + c * W + j];
+            b += smem[(size_t)w * 3 * cols + cols + c * W + j];
+            e += smem[(size_t)w * 3 * cols + 2 * cols + c * W + j];
+          }
+          pg[c * W + j] = a;
+          pg[cols + c * W + j] = b;
+          pg[2 * cols + c * W + j] = e;
+        }
+      }
+    }
+  }
+}
+
+// EXACT-WIDTH backward (cols == VPL * 64 * W; round 6): ln_bwd_kernel's arithmetic with no conditional vector-memory
+// instruction in the row loop (see ln_fwd_exact_kernel: the general kernel's loop waits vmcnt(0) -- for the prefetched next
+// row as well -- in front of every reduction). X2: the normalised row is x + x2 (+ bias, zeros when there is none);
+// DADD / PLAIN as in the general kernel. mean / rstd of the next row are prefetched with it.
+template <typename T, int VPL, int W, bool X2, bool DADD, bool PLAIN>
+__global__ __launch_bounds__(256, (VPL * W <= 12 ? (sizeof(T) == 2 ? 3 : 2) : 1)) void ln_bwd_exact_kernel(
+    const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ x2,
+    const float* __restrict__ bias, const float* __restrict__ gamma, const float* __restrict__ mean,
+    const float* __restrict__ rstd, const T* __restrict__ dadd, T* __restrict__ dx, T* __restrict__ dx_plain,
+    float* __restrict__ part, int64_t rows) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [3 waves][3][cols]
+  constexpr int cols = VPL * 64 * W, nvec = VPL * 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float inv_cols = 1.0f / (float)cols;
+  float g[VPL][W], ag[VPL][W], ab[VPL][W], ax[VPL][W], bb[X2 ? VPL : 1][W];
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+#pragma unroll
+    for (int j = 0; j < W; ++j) { ag[i][j] = 0.f; ab[i][j] = 0.f; ax[i][j] = 0.f; }
+    load_f32<W>(gamma + (lane + i * 64) * W, g[i]);
+    if constexpr (X2) {
+#pragma unroll
+      for (int j = 0; j < W; ++j) bb[i][j] = 0.f;
+    }
+  }
+  if constexpr (X2) {
+    if (bias != nullptr) {            // before the loop: a branch here costs nothing
+#pragma unroll
+      for (int i = 0; i < VPL; ++i) load_f32<W>(bias + (lane + i * 64) * W, bb[i]);
+    }
+  }
+  const int64_t stride = (int64_t)gridDim.x * kRowsPerBlock;
+  int64_t row = (int64_t)blockIdx.x * kRowsPerBlock + wave;
+  struct Row {
+    RawVec<T, W> dy[VPL], x[VPL], x2[X2 ? VPL : 1], dadd[DADD ? VPL : 1];
+    float mu, rs;
+  } cur, nxt;
+  auto load_row = [&](int64_t r, Row& q) {
+    q.mu = mean[r];
+    q.rs = rstd[r];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int64_t off = r * cols + (lane + i * 64) * W;
+      q.dy[i].load(dy + off);
+      q.x[i].load(x + off);
+      if constexpr (X2) q.x2[i].load(x2 + off);
+      if constexpr (DADD) q.dadd[i].load(dadd + off);
+    }
+  };
+  if (row < rows) {
+    load_row(row, cur);
+    // everything requested so far has landed before the loop is entered (see ln_fwd_exact_kernel)
+    asm volatile("" : "+v"(cur.mu), "+v"(cur.rs));
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      cur.dy[i].pin();
+      cur.x[i].pin();
+      if constexpr (X2) cur.x2[i].pin();
+      if constexpr (DADD) cur.dadd[i].pin();
+#pragma unroll
+      for (int j = 0; j < W; ++j) {
+        asm volatile("" : "+v"(g[i][j]));
+        if constexpr (X2) asm volatile("" : "+v"(bb[i][j]));
+      }
+    }
+  }
+  for (; row < rows; row += stride) {
+    const int64_t rn = row + stride < rows ? row + stride : rows - 1;      // unconditional prefetch
+    load_row(rn, nxt);
+    const float mu = cur.mu, rs = cur.rs;
+    auto xhat = [&](int i, float (&xh)[W]) {
+      cur.x[i].unpack(xh);
+      if constexpr (X2) {
+        float w[W];
+        cur.x2[i].unpack(w);
+#pragma unroll
+        for (int j = 0; j < W; ++j) xh[j] = (xh[j] + w[j]) + bb[i][j];      // the general kernel's order of additions
+      }
+#pragma unroll
+      for (int j = 0; j < W; ++j) xh[j] = (xh[j] - mu) * rs;
+    };
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      float xh[W], dv[W];
+      xhat(i, xh);
+      cur.dy[i].unpack(dv);
+#pragma unroll
+      for (int j = 0; j < W; ++j) {
+        const float dgj = dv[j] * g[i][j];
+        s1 += dgj;
+        s2 = fmaf(dgj, xh[j], s2);
+        ag[i][j] = fmaf(dv[j], xh[j], ag[i][j]);
+        ab[i][j] += dv[j];
+      }
+    }
+    const float c1 = wave_sum(s1) * inv_cols, c2 = wave_sum(s2) * inv_cols;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      float xh[W], dv[W], o[W];
+      xhat(i, xh);
+      cur.dy[i].unpack(dv);
+#pragma unroll
+      for (int j = 0; j < W; ++j) o[j] = rs * fmaf(-xh[j], c2, dv[j] * g[i][j] - c1);
+      const int64_t off = row * cols + (lane + i * 64) * W;
+      if constexpr (PLAIN) {           // the normalisation's own input gradient leaves separately
+#pragma unroll
+        for (int j = 0; j < W; ++j) ax[i][j] += Elem<T>::round(o[j]);
+        VecIO<T, W>::store(dx_plain + off, o);
+      }
+      if constexpr (DADD) {
+        float e[W];
+        cur.dadd[i].unpack(e);
+#pragma unroll
+        for (int j = 0; j < W; ++j) o[j] += e[j];
+      }
+      if constexpr (!PLAIN) {
+#pragma unroll
+        for (int j = 0; j < W; ++j) ax[i][j] += Elem<T>::round(o[j]);
+      }
+      VecIO<T, W>::store(dx + off, o);
+    }
+    cur = nxt;
+  }
+  ln_bwd_combine<VPL, W>(smem, part, ag, ab, ax, cols, nvec, lane, wave);
+}
 
 template <typename T, int VPL, int W>
 __global__ __launch_bounds__(256, (VPL * W <= 12 ? (sizeof(T) == 2 ? 3 : 2) : 1)) void ln_bwd_kernel(
@@ -220,8 +488,8 @@ __global__ __launch_bounds__(256, (VPL * W <= 12 ? (sizeof(T) == 2 ? 3 : 2) : 1)
         for (int j = 0; j < W; ++j) {
           const float dgj = dv[j] * g[i][j];
           s1 += dgj;
-          s2 += dgj * xh[j];
-          ag[i][j] += dv[j] * xh[j];
+          s2 = fmaf(dgj, xh[j], s2);
+          ag[i][j] = fmaf(dv[j], xh[j], ag[i][j]);
           ab[i][j] += dv[j];
         }
       }
@@ -235,7 +503,7 @@ __global__ __launch_bounds__(256, (VPL * W <= 12 ? (sizeof(T) == 2 ? 3 : 2) : 1)
         xhat(i, c, xh);
         cur.dy[i].unpack(dv);
 #pragma unroll
-        for (int j = 0; j < W; ++j) o[j] = rs * (dv[j] * g[i][j] - c1 - xh[j] * c2);
+        for (int j = 0; j < W; ++j) o[j] = rs * fmaf(-xh[j], c2, dv[j] * g[i][j] - c1);
         if (dx_plain != nullptr) {       // the normalisation's own input gradient leaves separately (see header)
 #pragma unroll
           for (int j = 0; j < W; ++j) ax[i][j] += Elem<T>::round(o[j]);
@@ -256,44 +524,7 @@ __global__ __launch_bounds__(256, (VPL * W <= 12 ? (sizeof(T) == 2 ? 3 : 2) : 1)
     }
     cur = nxt;
   }
-  // combine the 4 waves of this workgroup, then one partial slab per workgroup
-  if (wave > 0) {
-    float* dst = smem + (size_t)(wave - 1) * 3 * cols;
-#pragma unroll
-    for (int i = 0; i < VPL; ++i) {
-      const int c = lane + i * 64;
-      if (c < nvec) {
-#pragma unroll
-        for (int j = 0; j < W; ++j) {
-          dst[c * W + j] = ag[i][j];
-          dst[cols + c * W + j] = ab[i][j];
-          dst[2 * cols + c * W + j] = ax[i][j];
-        }
-      }
-    }
-  }
-  __syncthreads();
-  if (wave == 0) {
-    float* pg = part + (size_t)blockIdx.x * 3 * cols;
-#pragma unroll
-    for (int i = 0; i < VPL; ++i) {
-      const int c = lane + i * 64;
-      if (c < nvec) {
-#pragma unroll
-        for (int j = 0; j < W; ++j) {
-          float a = ag[i][j], b = ab[i][j], e = ax[i][j];
-          for (int w = 0; w < 3; ++w) {
-            a += smem[(size_t)w * 3 * cols + c * W + j];
-            b += smem[(size_t)w * 3 * cols + cols + c * W + j];
-            e += smem[(size_t)w * 3 * cols + 2 * cols + c * W + j];
-          }
-          pg[c * W + j] = a;
-          pg[cols + c * W + j] = b;
-          pg[2 * cols + c * W + j] = e;
-        }
-      }
-    }
-  }
+  ln_bwd_combine<VPL, W>(smem, part, ag, ab, ax, cols, nvec, lane, wave);
 }
 
 // Column sums of a partial slab part[nparts][width] (f32), deterministic, in two coalesced stages:
@@ -439,20 +670,29 @@ extern "C" int lvl_layernorm_fwd(const void* x, const void* x2, const float* xbi
   // (56 VGPRs, 8 waves/SIMD) measured best with 4 x its resident workgroups (0.136 ms at 8192 against 0.142 at 3072 and 0.176
   // at 2048 for 200 960 rows of 768: profiles/r06_rowops_ln_fwd.txt)
   const int64_t cap = x2 == nullptr ? 8192 : 3072;
+  static const bool exact_off = getenv("LAVILA_LN_EXACT") && atoi(getenv("LAVILA_LN_EXACT")) == 0;      // A/B switch
+  const bool exact = !exact_off && s_out == nullptr && mean != nullptr && rstd != nullptr;
   if (blocks > cap) blocks = cap;
 #define LN_FWD_X(TT, VPL, W, X2)                                                                                \
   hipLaunchKernelGGL((ln_fwd_kernel<TT, VPL, W, X2>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, \
                      (const TT*)x, (const TT*)x2, xbias, gamma, beta, (TT*)s_out, (TT*)y, mean, rstd, rows, cols, eps)
-#define LN_FWD_T(TT, VPL, W)                 \
-  do {                                       \
-    if (x2 != nullptr) LN_FWD_X(TT, VPL, W, true); \
-    else LN_FWD_X(TT, VPL, W, false);        \
+#define LN_FWD_E(TT, VPL, W, X2, BIAS)                                                                             \
+  hipLaunchKernelGGL((ln_fwd_exact_kernel<TT, VPL, W, X2, BIAS>), dim3((unsigned)blocks), dim3(256), 0,              \
+                     (hipStream_t)stream, (const TT*)x, (const TT*)x2, xbias, gamma, beta, (TT*)y, mean, rstd, rows, eps)
+#define LN_FWD_T(TT, VPL, W)                                                              \
+  do {                                                                                    \
+    if (exact && (VPL) * 64 * (W) == cols && x2 == nullptr && xbias == nullptr) LN_FWD_E(TT, VPL, W, false, false); \
+    else if (exact && (VPL) * 64 * (W) == cols && x2 != nullptr && xbias != nullptr) LN_FWD_E(TT, VPL, W, true, true); \
+    else if (exact && (VPL) * 64 * (W) == cols && x2 != nullptr) LN_FWD_E(TT, VPL, W, true, false); \
+    else if (x2 != nullptr) LN_FWD_X(TT, VPL, W, true);                                   \
+    else LN_FWD_X(TT, VPL, W, false);                                                     \
   } while (0)
 #define LN_FWD(VPL, W) LN_FWD_T(T, VPL, W)
   LVL_DISPATCH_DTYPE(dtype, LN_DISPATCH(cols, LN_FWD));
 #undef LN_FWD
 #undef LN_FWD_T
 #undef LN_FWD_X
+#undef LN_FWD_E
   LVL_CHECK_LAUNCH("layernorm_fwd");
   return LVL_OK;
 }
@@ -472,7 +712,17 @@ extern "C" int lvl_layernorm_bwd(const void* dy, const void* x, const void* x2, 
   if (blocks > kLnBwdParts) blocks = kLnBwdParts;
   if (blocks < 1) blocks = 1;
   const size_t shmem = (size_t)3 * 3 * cols * sizeof(float);
-#define LN_BWD_T(TT, VPL, W)                                                                                    \
+  static const bool exact_off = getenv("LAVILA_LN_EXACT") && atoi(getenv("LAVILA_LN_EXACT")) == 0;      // A/B switch
+  const bool exact = !exact_off;
+#define LN_BWD_E(TT, VPL, W, X2, DADD, PLAIN)                                                                      \
+  do {                                                                                                            \
+    if (shmem > 64 * 1024)                                                                                        \
+      if (int rc = lvl_allow_lds<ln_bwd_exact_kernel<TT, VPL, W, X2, DADD, PLAIN>>()) return rc;                  \
+    hipLaunchKernelGGL((ln_bwd_exact_kernel<TT, VPL, W, X2, DADD, PLAIN>), dim3((unsigned)blocks), dim3(256), shmem, \
+                       st, (const TT*)dy, (const TT*)x, (const TT*)x2, xbias, gamma, mean, rstd, (const TT*)dadd,  \
+                       (TT*)dx, (TT*)dx_plain, ws, rows);                                                         \
+  } while (0)
+#define LN_BWD_G(TT, VPL, W)                                                                                    \
   do {                                                                                                          \
     if (shmem > 64 * 1024)                                                                                      \
       if (int rc = lvl_allow_lds<ln_bwd_kernel<TT, VPL, W>>()) return rc;                                       \
@@ -481,10 +731,23 @@ extern "C" int lvl_layernorm_bwd(const void* dy, const void* x, const void* x2, 
                        (TT*)dx_plain, ws, rows,                                                                   \
                        cols);                                                                                   \
   } while (0)
+// the exact-width kernel for the operand combinations of the training step (bf16), the general kernel otherwise
+#define LN_BWD_T(TT, VPL, W)                                                                                    \
+  do {                                                                                                          \
+    constexpr bool kHalf = sizeof(TT) == 2;                                                                     \
+    const bool ex = kHalf && exact && (VPL) * 64 * (W) == cols && rows > 0;                                     \
+    if (ex && !x2 && !xbias && !dadd && !dx_plain) LN_BWD_E(TT, VPL, W, false, false, false);                   \
+    else if (ex && !x2 && !xbias && dadd && !dx_plain) LN_BWD_E(TT, VPL, W, false, true, false);                \
+    else if (ex && x2 && !dadd && !dx_plain) LN_BWD_E(TT, VPL, W, true, false, false);                          \
+    else if (ex && x2 && dadd && dx_plain) LN_BWD_E(TT, VPL, W, true, true, true);                              \
+    else LN_BWD_G(TT, VPL, W);                                                                                  \
+  } while (0)
 #define LN_BWD(VPL, W) LN_BWD_T(T, VPL, W)
   LVL_DISPATCH_DTYPE(dtype, LN_DISPATCH(cols, LN_BWD));
 #undef LN_BWD
 #undef LN_BWD_T
+#undef LN_BWD_G
+#undef LN_BWD_E
   LVL_CHECK_LAUNCH("layernorm_bwd");
   return lvl_launch_column_reduce(ws, (int)blocks, 3 * cols, cols, ws + (size_t)kLnBwdParts * 3 * cols, dgamma, dbeta,
                                   dxsum, st);

@@ -647,3 +647,44 @@ def test_tower_with_residual_epilogues_equals_the_composed_tower():
         d0 = (p0[n] - pr[n]).norm().item() / pr[n].norm().item()
         d1 = (p1[n] - pr[n]).norm().item() / pr[n].norm().item()
         assert d1 < 1.5 * d0 + 2e-3, (n, d0, d1)
+
+
+_LN_EXACT_PROBE = r"""
+import sys, torch
+from lavila_amd import ops
+torch.manual_seed(0)
+cols = int(sys.argv[2])
+x = torch.randn(3001, cols, device='cuda').bfloat16(); y = torch.randn_like(x)
+g = torch.randn(cols, device='cuda'); b = torch.randn(cols, device='cuda'); yb = torch.randn(cols, device='cuda')
+dy = torch.randn_like(x); dadd = torch.randn_like(x)
+outs = []
+h, _, mean, rstd = ops.layernorm_fwd_raw(x, None, None, g, b, 1e-5, False); outs += [h, mean, rstd]
+h2, _, m2, r2 = ops.layernorm_fwd_raw(x, y, yb, g, b, 1e-5, False); outs += [h2, m2, r2]
+h3, _, m3, r3 = ops.layernorm_fwd_raw(x, y, None, g, b, 1e-5, False); outs += [h3, m3, r3]
+outs += [t for t in ops.layernorm_bwd_raw(dy, x, None, None, g, mean, rstd, None, False) if t is not None]
+outs += [t for t in ops.layernorm_bwd_raw(dy, x, None, None, g, mean, rstd, dadd, True) if t is not None]
+outs += [t for t in ops.layernorm_bwd_raw(dy, x, y, yb, g, m2, r2, None, True) if t is not None]
+outs += [t for t in ops.layernorm_bwd_raw(dy, x, y, yb, g, m2, r2, dadd, True, True) if t is not None]
+torch.save([o.cpu() for o in outs], sys.argv[1])
+"""
+
+
+@pytest.mark.parametrize('cols', [768, 512, 1024])
+def test_exact_width_layernorm_kernels_equal_the_general_ones_bit_for_bit(cols, tmp_path):
+    """lvl_layernorm_fwd / bwd take branch-free exact-width instantiations (ln_fwd_exact_kernel / ln_bwd_exact_kernel) at
+    cols = VPL * 256 for the operand combinations of the training step, the general kernels otherwise -- and activation
+    checkpointing (timesformer.py:173-187) may recompute a forward through the other one. Both families write their fused
+    multiply-adds explicitly (no implicit contraction in layernorm.hip), so they agree to the bit: LAVILA_LN_EXACT=0 / 1."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for e in ('0', '1'):
+        out = str(tmp_path / f'ln_{e}.pt')
+        subprocess.run([sys.executable, '-c', _LN_EXACT_PROBE, out, str(cols)], check=True, cwd=root,
+                       env=dict(os.environ, LAVILA_LN_EXACT=e, PYTHONPATH=root), timeout=600)
+        res.append(torch.load(out))
+    assert len(res[0]) == len(res[1]) and len(res[0]) >= 20
+    for i, (a, b) in enumerate(zip(*res)):
+        assert torch.equal(a, b), (i, (a.float() - b.float()).abs().max().item())
