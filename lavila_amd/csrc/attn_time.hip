@@ -129,10 +129,14 @@ __global__ __launch_bounds__((DPL == 2 ? 512 : 256), (DPL == 2 || sizeof(E) == 4
   const int n_end = min(N, (chunk + 1) * NCH);
 #pragma unroll 1
   for (int n = chunk * NCH + n_sub; n < n_end; n += NPB) {
-    vec_t kk[F], vv[F];
+    // every row of the location is requested here, and nothing below is a CONDITIONAL vector-memory instruction (the lse
+    // store is issued by every lane of a group: one address) -- with a branch around a store in the loop the compiler's
+    // wait insertion falls back to vmcnt(0) in front of every query, i.e. one store acknowledgement per query (round 6)
+    vec_t kk[F], vv[F], qq[F];
 #pragma unroll
     for (int f = 0; f < F; ++f) {
       const E* p = base + (size_t)(1 + f * N + n) * ts;
+      qq[f] = *reinterpret_cast<const vec_t*>(p);
       kk[f] = *reinterpret_cast<const vec_t*>(p + D);
       vv[f] = *reinterpret_cast<const vec_t*>(p + 2 * D);
     }
@@ -160,7 +164,7 @@ __global__ __launch_bounds__((DPL == 2 ? 512 : 256), (DPL == 2 || sizeof(E) == 4
 #pragma unroll
     for (int fq = 0; fq < F; ++fq) {
       float q[DPL];
-      V::unpack(*reinterpret_cast<const vec_t*>(base + (size_t)(1 + fq * N + n) * ts), q);
+      V::unpack(qq[fq], q);
 #pragma unroll
       for (int i = 0; i < DPL; ++i) q[i] *= 0.125f * kLog2e;
       float s[F + 1];
@@ -186,7 +190,7 @@ __global__ __launch_bounds__((DPL == 2 ? 512 : 256), (DPL == 2 || sizeof(E) == 4
       for (int i = 0; i < DPL; ++i) o[i] *= linv;
       const int tok = 1 + fq * N + n;
       *reinterpret_cast<vec_t*>(obase + (size_t)tok * D) = V::pack(o);
-      if (dl == 0) lrow[tok] = (mx + __log2f(l)) * (1.0f / kLog2e);
+      lrow[tok] = (mx + __log2f(l)) * (1.0f / kLog2e);          // all lanes of the group, the same value
     }
   }
 
