@@ -681,19 +681,20 @@ def main():
                                 'avg_ms': round(bms, 4), 'launches': len(btimer.pairs), 'alg_bytes_per_launch': balg}
 
         def _by_epilogue(tm):
-            """The launches that carry the residual epilogue (LVL_EPI_BIAS_RESIDUAL = 3: +1 read of a [rows, N] tensor per
-            launch, the LayerNorm pass it replaces is gone from the step) priced apart from the others."""
-            if not any(t == 3 for t in tm.tags):
-                return {}
+            """The launches priced per epilogue of lvl_linear_tn (include/lavila_hip.h: 0 bias, 3 bias + residual -- +1 read
+            of a [rows, N] tensor, the LayerNorm pass it replaces is gone from the step --, 4 bias + QuickGELU writing the
+            activation AND its derivative, 5 multiply by the stored derivative + column sums)."""
+            names = {0: 'bias', 1: 'bias_quickgelu_preact', 2: 'quickgelu_bwd_preact', 3: 'bias_residual',
+                     4: 'bias_quickgelu_deriv', 5: 'mul_aux_colsum'}
             out = {}
-            for name, want in (('residual_epilogue_launches', True), ('other_launches', False)):
-                idx = [i for i, t in enumerate(tm.tags) if (t == 3) == want]
+            for code in sorted(set(tm.tags)):
+                idx = [i for i, t in enumerate(tm.tags) if t == code]
                 ms = sum(tm.pairs[i][0].elapsed_time(tm.pairs[i][1]) for i in idx)
                 fl = sum(tm.work[i] for i in idx)
                 if idx and ms > 0:
-                    out[name] = {'launches': len(idx), 'avg_ms': round(ms / len(idx), 4),
-                                 'frac': round(fl / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
-            return {'by_epilogue': out}
+                    out[names.get(code, str(code))] = {'launches': len(idx), 'avg_ms': round(ms / len(idx), 4),
+                                                       'frac': round(fl / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)}
+            return {'by_epilogue': out} if len(out) > 1 else {}
 
         def mfma_roofline(tm, kernel, tfile):
             if not tm.pairs:

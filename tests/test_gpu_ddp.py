@@ -215,7 +215,9 @@ def test_zero_step_then_forward_runs_on_the_updated_weights():
         p.join(timeout=120)
     for rank, lz, lp, lze, lpe, lb in got:
         assert abs(lz - lp) < 1e-5 and abs(lze - lpe) < 1e-5, (rank, lz, lp, lze, lpe)   # ZeRO == AdamW, next forward
-        assert abs(lp - lb) > 1e-3, (lp, lb)              # ... and the step did move the loss (lr 1e-2): not vacuous
+        # ... and the step did move the loss (lr 1e-2; 0.7e-3 ... 1.1e-3 depending on the build's last-bit numerics): not vacuous,
+        # 20x the agreement bound above
+        assert abs(lp - lb) > 2e-4, (lp, lb)
     assert got[0][1] == got[1][1]                         # both ranks: the same global loss
 
 
