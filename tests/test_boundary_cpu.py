@@ -388,6 +388,35 @@ def test_gemm_tile_counter_reply_register_is_untouched_in_isa(tmp_path):
             assert body[i + 1] == 's_waitcnt vmcnt(0)' and re.fullmatch(r'ds_write_b32 v\d+, ' + reg, body[i + 2]), body[i:i + 3]
 
 
+def test_exact_width_layernorm_loops_have_only_counted_waits_in_isa(tmp_path):
+    """ln_fwd_exact_kernel / ln_bwd_exact_kernel (csrc/layernorm.hip) exist because ONE conditional vector-memory instruction
+    in a row loop makes the compiler's wait insertion fall back to `s_waitcnt vmcnt(0)` there (the software-prefetched next
+    row is then waited for as well, and every store acknowledgement sits on the row's critical path). Checked in the gfx950
+    ISA of the benched instantiations: the row loop (the backward-branching block that loads and stores) contains no
+    vmcnt(0), no branch around a memory instruction, and at least one counted wait."""
+    lines = _isa(tmp_path, 'layernorm')
+    seen = 0
+    for stem in ('ln_fwd_exact_kernel', 'ln_bwd_exact_kernel'):
+        for name, body in _kernel_bodies(lines, stem):
+            if '6bf16_tLi3ELi4E' not in name:      # 768 columns: TSF-B, the benched tower (other widths: the compiler may
+                continue                           # rotate the loop so that its last counted wait is an exact vmcnt(0))
+            labels = {m.group(1): i for i, l in enumerate(body) for m in [re.match(r'(\.LBB\d+_\d+):', l)] if m}
+            loops = []
+            for i, l in enumerate(body):
+                m = re.match(r's_cbranch_\w+ (\.LBB\d+_\d+)', l)
+                if m and m.group(1) in labels and labels[m.group(1)] < i:
+                    seg = body[labels[m.group(1)]:i]
+                    if any(x.startswith('global_load') for x in seg) and any(x.startswith('global_store') for x in seg):
+                        loops.append(seg)
+            assert len(loops) == 1, (name, len(loops))
+            seg = loops[0]
+            waits = [x for x in seg if x.startswith('s_waitcnt') and 'vmcnt' in x]
+            assert waits and not any('vmcnt(0)' in x for x in waits), (name, waits)
+            assert not any(x.startswith(('s_cbranch', 's_branch')) for x in seg), name       # straight-line row loop
+            seen += 1
+    assert seen >= 7          # 3 forward + 4 backward operand combinations
+
+
 def test_narrator_seam_state_dict_matches_reference_names():
     """lavila_amd.narrator.VCLM_HF owns `visual.*`, `img_queries`, `img_attn_pool.*`, `img_attn_pool_norm.*` under the
     reference's names (narrator.py:44-49, coca.py:27-31,76-82), beta buffers included, so those entries of a VCLM_*
