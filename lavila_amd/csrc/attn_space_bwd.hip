@@ -22,6 +22,13 @@
 // float32 tensors, operands as hi/lo bf16 images, 3 MFMAs per product (f32-class: what the parity configuration runs).
 #include "attn_mfma_common.h"
 
+// SBW_PACKED 1: the fused kernel's score arithmetic on v_pk_fma / v_pk_mul_f32 pairs (default), 0: scalar -- measured 0.7 % SLOWER
+// in round 6 (0.8302 -> 0.8364 ms, profiles/r06_valu_rates.txt): here the pairs feed two transcendentals each and the
+// packed forms win, unlike the SLP vectoriser's pairs elsewhere in this file (-fno-slp-vectorize: -3.2 %)
+#ifndef SBW_PACKED
+#define SBW_PACKED 1
+#endif
+
 namespace {
 
 using namespace attn_mfma;
@@ -569,10 +576,17 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : 2)) void space_bwd_fused_kern
         p1 = mfma(vf[1][1], gf[t][1], p1);
         // score pairs: v_pk_fma_f32 for the exponent, v_pk_mul_f32 for dS = P (dP - delta)
         float d0[4], d1[4];
+#if SBW_PACKED
         const f32x2 k2 = {kExp2, kExp2}, nl2 = {-Lk[t], -Lk[t]};
+#endif
 #pragma unroll
         for (int r = 0; r < 4; r += 2) {
+#if SBW_PACKED
           const f32x2 a0 = f32x2{s0[r], s0[r + 1]} * k2 + nl2, a1 = f32x2{s1[r], s1[r + 1]} * k2 + nl2;
+#else
+          const float a0[2] = {fmaf(s0[r], kExp2, -Lk[t]), fmaf(s0[r + 1], kExp2, -Lk[t])};
+          const float a1[2] = {fmaf(s1[r], kExp2, -Lk[t]), fmaf(s1[r + 1], kExp2, -Lk[t])};
+#endif
           f32x2 e0 = {__builtin_amdgcn_exp2f(a0[0]), __builtin_amdgcn_exp2f(a0[1])};
           f32x2 e1 = {__builtin_amdgcn_exp2f(a1[0]), __builtin_amdgcn_exp2f(a1[1])};
           if (j == 0 && r == 0) e0[0] = kill0[t] ? 0.f : e0[0];
@@ -583,9 +597,14 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : 2)) void space_bwd_fused_kern
               e1[u] = (2 * j + 1) * 16 + g * 4 + r + u < nkeys ? e1[u] : 0.f;
             }
           }
+#if SBW_PACKED
           const f32x2 x0 = e0 * f32x2{p0[r], p0[r + 1]}, x1 = e1 * f32x2{p1[r], p1[r + 1]};
           d0[r] = x0[0]; d0[r + 1] = x0[1];
           d1[r] = x1[0]; d1[r + 1] = x1[1];
+#else
+          d0[r] = e0[0] * p0[r]; d0[r + 1] = e0[1] * p0[r + 1];
+          d1[r] = e1[0] * p1[r]; d1[r + 1] = e1[1] * p1[r + 1];
+#endif
         }
         pa[t] = P::pack(d0, d1);
       }
@@ -723,11 +742,18 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : 2)) void space_bwd_fused_kern
         p0 = mfma(ga[0][1], vv[t][1], p0);
         p1 = mfma(ga[1][1], vv[t][1], p1);
         float e0[4], e1[4], d0[4], d1[4];
+#if SBW_PACKED
         const f32x2 k2 = {kExp2, kExp2};
+#endif
 #pragma unroll
-        for (int r = 0; r < 4; r += 2) {          // score pairs: packed multiply-add / multiply
+        for (int r = 0; r < 4; r += 2) {          // score pairs
+#if SBW_PACKED
           const f32x2 a0 = f32x2{s0[r], s0[r + 1]} * k2 - f32x2{lsa[r], lsa[r + 1]};
           const f32x2 a1 = f32x2{s1[r], s1[r + 1]} * k2 - f32x2{lsa[4 + r], lsa[5 + r]};
+#else
+          const float a0[2] = {fmaf(s0[r], kExp2, -lsa[r]), fmaf(s0[r + 1], kExp2, -lsa[r + 1])};
+          const float a1[2] = {fmaf(s1[r], kExp2, -lsa[4 + r]), fmaf(s1[r + 1], kExp2, -lsa[5 + r])};
+#endif
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
             e0[r + u] = __builtin_amdgcn_exp2f(a0[u]);
@@ -737,10 +763,15 @@ __global__ __launch_bounds__(256, (P::kSplit ? 1 : 2)) void space_bwd_fused_kern
               e1[r + u] = (kill_pair && 16 + g * 4 + r + u == cls_sub) ? 0.f : e1[r + u];
             }
           }
+#if SBW_PACKED
           const f32x2 x0 = f32x2{e0[r], e0[r + 1]} * f32x2{p0[r], p0[r + 1]};
           const f32x2 x1 = f32x2{e1[r], e1[r + 1]} * f32x2{p1[r], p1[r + 1]};
           d0[r] = x0[0]; d0[r + 1] = x0[1];
           d1[r] = x1[0]; d1[r + 1] = x1[1];
+#else
+          d0[r] = e0[r] * p0[r]; d0[r + 1] = e0[r + 1] * p0[r + 1];
+          d1[r] = e1[r] * p1[r]; d1[r + 1] = e1[r + 1] * p1[r + 1];
+#endif
         }
         pa[t] = P::pack(e0, e1);
         da[t] = P::pack(d0, d1);
