@@ -430,6 +430,11 @@ int lvl_vec_mat_f32(const float* v, const float* W, float* out, int N, int K, vo
  * (main_pretrain.py:491 `amp.autocast`) plus the transposed copy the input-gradient GEMM wants, in one pass.
  * src: [N,K] f32; dst: [N,K] bf16; dst_t: [K,N] bf16. */
 int lvl_cast_transpose(const float* src, void* dst, void* dst_t, int N, int K, void* stream);
+/* The same for MANY weights in one launch (every Linear weight of both towers is re-cast once per optimizer step:
+ * main_pretrain.py:520-533 `optimizer.step()` then the next `model(...)`): desc = DEVICE array of `count` records of 40 bytes
+ * { const float* src; void* dst; void* dst_t; uint32_t N; uint32_t K; int64_t tile0; }, tile0 = number of 64 x 64 tiles of
+ * the records in front (tile0 of record 0 = 0, ascending), total_tiles = their sum over all records. */
+int lvl_cast_transpose_multi(const void* desc, int count, int64_t total_tiles, void* stream);
 
 /* ---- f32-class operands for the MFMA GEMMs (parity configuration) ----------------------------------------------
  * Writes a float32 matrix src [rows, cols] (row stride src_row_stride elements) as three bf16 TERM images:

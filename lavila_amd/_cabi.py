@@ -51,6 +51,7 @@ SIGNATURES = {
     'lvl_linear_tn': (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
     'lvl_linear_wgrad': (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P]),
     'lvl_cast_transpose': (_I, [_P, _P, _P, _I, _I, _P]),
+    'lvl_cast_transpose_multi': (_I, [_P, _I, _L, _P]),
     'lvl_split_bf16x3': (_I, [_P, _P, _L, _I, _L, _L, _L, _I, _P]),
     'lvl_cls_attn_fwd': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     'lvl_cls_attn_bwd': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

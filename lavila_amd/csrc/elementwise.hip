@@ -315,11 +315,10 @@ __global__ __launch_bounds__(128) void qkv_bias_partial_kernel(const T* __restri
 // input-gradient GEMM (both contraction-contiguous). One launch instead of a cast plus a strided transpose copy.
 // 64 x 64 tiles, 16-byte loads, 8-byte stores both ways (the 32 x 32 scalar version ran at 0.6 TB/s -- 3 ms per step
 // once every weight is re-cast every optimizer step); any N, K (edges masked element-wise).
-__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst,
-                                                             uint16_t* __restrict__ dst_t, int N, int K) {
-  __shared__ float tile[64][65];
+__device__ __forceinline__ void cast_transpose_tile(const float* __restrict__ src, uint16_t* __restrict__ dst,
+                                                    uint16_t* __restrict__ dst_t, int N, int K, int n0, int k0,
+                                                    float (&tile)[64][65]) {
   const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;      // 16 column groups of 4 x 16 rows
-  const int n0 = blockIdx.y * 64, k0 = blockIdx.x * 64;
   const bool vec = (K % 4 == 0) && (N % 4 == 0);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -358,6 +357,30 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
       }
     }
   }
+}
+
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst,
+                                                             uint16_t* __restrict__ dst_t, int N, int K) {
+  __shared__ float tile[64][65];
+  cast_transpose_tile(src, dst, dst_t, N, K, blockIdx.y * 64, blockIdx.x * 64, tile);
+}
+
+// Many weights in ONE launch (round 6: the training step re-casts every Linear weight once per optimizer step -- 121
+// launches of ~5 us each, one per weight at its first use; ops.refresh_weight_copies does them at the top of the forward).
+// desc[i] = {src, dst, dst_t, N | K << 32, first tile}: workgroup b finds its weight by bisection over the first-tile column.
+struct CastDesc { const float* src; uint16_t* dst; uint16_t* dst_t; unsigned N, K; long long tile0; };
+__global__ __launch_bounds__(256) void cast_transpose_multi_kernel(const CastDesc* __restrict__ desc, int count) {
+  __shared__ float tile[64][65];
+  const long long b = blockIdx.x;
+  int lo = 0, hi = count - 1;
+  while (lo < hi) {                         // last descriptor whose first tile is <= b
+    const int mid = (lo + hi + 1) >> 1;
+    if (desc[mid].tile0 <= b) lo = mid; else hi = mid - 1;
+  }
+  const CastDesc d = desc[lo];
+  const int tiles_k = ((int)d.K + 63) / 64;
+  const int t = (int)(b - d.tile0);
+  cast_transpose_tile(d.src, d.dst, d.dst_t, (int)d.N, (int)d.K, (t / tiles_k) * 64, (t % tiles_k) * 64, tile);
 }
 
 // f32-class operands of the MFMA GEMMs: a float32 matrix as three bf16 TERM images. x = h + l + O(2^-18 |x|) with
@@ -497,6 +520,15 @@ extern "C" int lvl_cast_transpose(const float* src, void* dst, void* dst_t, int 
   hipLaunchKernelGGL(cast_transpose_kernel, dim3((K + 63) / 64, (N + 63) / 64), dim3(256), 0, (hipStream_t)stream, src,
                      (uint16_t*)dst, (uint16_t*)dst_t, N, K);
   LVL_CHECK_LAUNCH("cast_transpose");
+  return LVL_OK;
+}
+
+extern "C" int lvl_cast_transpose_multi(const void* desc, int count, int64_t total_tiles, void* stream) {
+  LVL_REQUIRE(desc && count > 0 && total_tiles > 0 && total_tiles < (1ll << 31), "cast_transpose_multi: bad arguments");
+  LVL_REQUIRE((reinterpret_cast<uintptr_t>(desc) & 7) == 0, "cast_transpose_multi: descriptor table must be 8-byte aligned");
+  hipLaunchKernelGGL(cast_transpose_multi_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream,
+                     (const CastDesc*)desc, count);
+  LVL_CHECK_LAUNCH("cast_transpose_multi");
   return LVL_OK;
 }
 

@@ -88,6 +88,7 @@ def training_forward_begins():
     backward and activation checkpointing's recomputation (which re-enters the blocks, not the wrappers)."""
     if torch.is_grad_enabled():
         invalidate_weight_cache()
+        refresh_weight_copies()
 
 
 _forward_depth = __import__('threading').local()
@@ -187,8 +188,52 @@ def weight_copies(weight: torch.Tensor, f32: bool = False):
     if c is None:
         weakref.finalize(holder, _copies.pop, key, None)
     w, wt = make(src)
-    _copies[key] = (ver, w, wt, weight.data_ptr(), _generation)
+    # (the parameter itself, weakly, when it is one -- refresh_weight_copies re-casts those entries in one launch)
+    _copies[key] = (ver, w, wt, weight.data_ptr(), _generation, weakref.ref(weight) if weight._base is None else None)
     return w, wt
+
+
+# LAVILA_WEIGHT_REFRESH=1: every stale weight copy is re-cast by ONE launch at the top of the training forward instead of one
+# lvl_cast_transpose launch per weight at its first use. Off by default: measured neutral to slightly slower (same box,
+# alternating: 163.86 ms per step lazily, 164.21 with the refresh -- the ~120 five-microsecond launches already hide between the
+# step's kernels, the single 0.3-ms pass at the top does not; profiles/r06_weight_refresh.txt).
+WEIGHT_REFRESH = os.environ.get('LAVILA_WEIGHT_REFRESH', '0') == '1'
+
+
+def refresh_weight_copies():
+    """Re-cast, in ONE lvl_cast_transpose_multi launch per device, every cached (bf16, transposed bf16) pair that the new
+    cache generation made stale. Called at the top of a grad-enabled model forward (training_forward_begins), i.e. exactly
+    where the first use of each weight would otherwise re-cast it: the same values at the same point of the step, 1 launch
+    instead of ~120 (main_pretrain.py:520-533: optimizer.step(), then the next model(...)). Entries whose parameter is gone,
+    moved, not float32-contiguous, a view (the patch embedding's reshaped Conv2d weight) or an f32-class image pair keep the
+    lazy path; so does everything under hipGraph capture."""
+    if not WEIGHT_REFRESH or not _copies or not torch.cuda.is_available() or torch.cuda.is_current_stream_capturing():
+        return
+    by_dev = {}
+    for key, c in list(_copies.items()):
+        if key[3] or len(c) < 6 or c[5] is None or c[4] < _generation - 3:      # (not used by the last step: lazily)
+            continue
+        w = c[5]()
+        if (w is None or not w.is_cuda or w.dtype != torch.float32 or w.dim() != 2 or not w.is_contiguous()
+                or w.data_ptr() != c[3]):
+            continue
+        by_dev.setdefault(w.device, []).append((key, w))
+    for dev, items in by_dev.items():
+        if len(items) < 2 or dev != torch.device('cuda', torch.cuda.current_device()):
+            continue
+        rows, outs, tile0 = [], [], 0
+        for key, w in items:
+            src = w.detach()
+            n, k = src.shape
+            a = torch.empty_like(src, dtype=torch.bfloat16)
+            b = torch.empty(k, n, dtype=torch.bfloat16, device=dev)
+            rows.append([src.data_ptr(), a.data_ptr(), b.data_ptr(), n | (k << 32), tile0])
+            tile0 += ((n + 63) // 64) * ((k + 63) // 64)
+            outs.append((key, w, a, b))
+        table = torch.tensor(rows, dtype=torch.int64, device=dev)
+        C.check(C.lib().lvl_cast_transpose_multi(C.ptr(table), len(rows), tile0, C.stream_ptr()), 'lvl_cast_transpose_multi')
+        for key, w, a, b in outs:
+            _copies[key] = (w._version, a, b, w.data_ptr(), _generation, weakref.ref(w))
 
 
 def _tn_ok(rows: int, n_out: int, n_in: int) -> bool:

@@ -688,3 +688,50 @@ def test_exact_width_layernorm_kernels_equal_the_general_ones_bit_for_bit(cols, 
     assert len(res[0]) == len(res[1]) and len(res[0]) >= 20
     for i, (a, b) in enumerate(zip(*res)):
         assert torch.equal(a, b), (i, (a.float() - b.float()).abs().max().item())
+
+
+def test_cast_transpose_multi_equals_the_single_launches_and_refresh_follows_the_weights():
+    """lvl_cast_transpose_multi (every Linear weight's bf16 copy + transposed copy in one launch, what autocast's per-step weight
+    casts amount to: main_pretrain.py:491,520-533) against lvl_cast_transpose weight by weight, odd shapes included; and
+    ops.refresh_weight_copies: after an out-of-band `.data` write and the next training forward's generation bump the cached
+    pairs hold the new values (one launch), entries of dead parameters are skipped."""
+    from lavila_amd import _cabi as C
+    from lavila_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(3)
+    shapes = [(768, 768), (2304, 768), (70, 130), (1, 64), (513, 65), (3072, 768), (64, 64)]
+    ws = [torch.randn(n, k, device=DEV, generator=g) for n, k in shapes]
+    rows, outs, tile0 = [], [], 0
+    for w in ws:
+        n, k = w.shape
+        a = torch.empty(n, k, dtype=torch.bfloat16, device=DEV)
+        b = torch.empty(k, n, dtype=torch.bfloat16, device=DEV)
+        rows.append([w.data_ptr(), a.data_ptr(), b.data_ptr(), n | (k << 32), tile0])
+        tile0 += ((n + 63) // 64) * ((k + 63) // 64)
+        outs.append((a, b))
+    table = torch.tensor(rows, dtype=torch.int64, device=DEV)
+    C.check(C.lib().lvl_cast_transpose_multi(C.ptr(table), len(rows), tile0, C.stream_ptr()), 'lvl_cast_transpose_multi')
+    for w, (a, b) in zip(ws, outs):
+        assert torch.equal(a, w.bfloat16()) and torch.equal(b, w.t().contiguous().bfloat16())
+    # the cache: first use casts lazily, the next training forward refreshes in one go
+    p1 = torch.nn.Parameter(torch.randn(256, 128, device=DEV, generator=g))
+    p2 = torch.nn.Parameter(torch.randn(512, 256, device=DEV, generator=g))
+    with ops.model_forward():
+        ops.weight_copies(p1), ops.weight_copies(p2)
+    p1.data.mul_(2.0)                      # behind the version counter's back
+    p2.data.add_(1.0)
+    del_me = torch.nn.Parameter(torch.randn(64, 64, device=DEV, generator=g))
+    with ops.model_forward():
+        ops.weight_copies(del_me)
+    del del_me
+    was = ops.WEIGHT_REFRESH
+    ops.WEIGHT_REFRESH = True              # (opt-in: LAVILA_WEIGHT_REFRESH=1)
+    try:
+        with ops.model_forward():          # generation bump + refresh (one launch for everything recently used)
+            entries = [v for v in ops._copies.values() if v[5] is not None and any(v[5]() is q for q in (p1, p2))]
+            assert len(entries) == 2 and all(v[4] == ops._generation for v in entries)
+            a1, t1 = ops.weight_copies(p1)
+            a2, t2 = ops.weight_copies(p2)
+    finally:
+        ops.WEIGHT_REFRESH = was
+    assert torch.equal(a1, p1.detach().bfloat16()) and torch.equal(t1, p1.detach().t().contiguous().bfloat16())
+    assert torch.equal(a2, p2.detach().bfloat16()) and torch.equal(t2, p2.detach().t().contiguous().bfloat16())
