@@ -194,6 +194,34 @@ def test_linear_tn_quickgelu_derivative_epilogues(M, N, K):
         ops.linear_tn_raw(ops.split3(xr.float(), 0), ops.split3(wr.float(), 1), b, C.EPI_BIAS_QUICKGELU_DERIV, f32=True)
 
 
+def test_quickgelu_derivative_pair_at_the_benched_size_by_properties():
+    """BASELINE configs[1] size (M = 256 * 785 rows, fc1 768 -> 3072): size-independent properties of the training pair of
+    epilogues. (1) the activation of LVL_EPI_BIAS_QUICKGELU_DERIV equals the pre-activation form's up to the rounding of u it
+    skips; (2) the stored derivative lies in QuickGELU's derivative range [-0.1, 1.1]; (3) LVL_EPI_MUL_AUX_COLSUM: the column
+    sums equal the column sums of its own result rows (a checksum of checksums; the kernel sums before the bf16 rounding);
+    (4) linearity in the upstream gradient: du(2 dy) == 2 du(dy) bit for bit (power-of-two scaling is exact)."""
+    from lavila_amd import _cabi as C
+    from lavila_amd import ops
+    M, K, N = 256 * 785, 768, 3072
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn(M, K, device=DEV, generator=g).bfloat16()
+    w1 = (torch.randn(N, K, device=DEV, generator=g) * K ** -0.5).bfloat16()
+    b1 = torch.randn(N, device=DEV, generator=g) * 0.1
+    y, d = ops.linear_tn_raw(x, w1, b1, C.EPI_BIAS_QUICKGELU_DERIV)
+    y1, u1 = ops.linear_tn_raw(x, w1, b1, C.EPI_BIAS_QUICKGELU)
+    assert (y.float() - y1.float()).abs().max().item() <= 2.0 ** -6 * y1.float().abs().max().item()
+    assert d.float().min().item() >= -0.11 and d.float().max().item() <= 1.11
+    del y1, u1
+    dy = torch.randn(M, K, device=DEV, generator=g).bfloat16()        # stands for the upstream gradient times W2 (any [M, K])
+    wt = (torch.randn(N, K, device=DEV, generator=g) * K ** -0.5).bfloat16()
+    du, cs = ops.linear_tn_raw(dy, wt, None, C.EPI_MUL_AUX_COLSUM, aux_in=d)
+    want = du.double().sum(0)
+    bound = 2.0 ** -8 * du.double().abs().sum(0) + 1e-3
+    assert ((cs.double() - want).abs() <= bound).all(), float(((cs.double() - want).abs() / bound).max())
+    du2, cs2 = ops.linear_tn_raw((dy.float() * 2).bfloat16(), wt, None, C.EPI_MUL_AUX_COLSUM, aux_in=d)
+    assert torch.equal(du2.float(), du.float() * 2) and torch.equal(cs2, cs * 2)
+
+
 @pytest.mark.parametrize('M,N,K', [(4096, 768, 768), (20000, 384, 192), (33, 2304, 768)])
 def test_linear_wgrad_exact_on_integer_operands(M, N, K):
     from lavila_amd import ops
