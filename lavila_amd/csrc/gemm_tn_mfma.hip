@@ -440,7 +440,8 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
         }
       }
     } else {
-    // bf16 results. The hardware's vmcnt counts result stores, the compiler's wait insertion counts loads only: a wait it
+    // bf16 results. The hardware's vmcnt counts result stores; the compiler's wait insertion does not count stores that sit
+    // under a branch (the `m < M` guard: its counters are merged conservatively across it): a wait it
     // places for an aux_in load (residual stream / QuickGELU derivative / pre-activation rows) BEHIND a group's stores is
     // too strict by the number of those stores and waits for their acknowledgement -- one store drain per row group, +10 us
     // per tile with the loads one group ahead of the stores (round 6: proj + residual 0.34 ms against 0.23 ms for the plain
