@@ -109,9 +109,11 @@ __device__ __forceinline__ float quick_gelu_grad(float u) {
   return s * (1.f + 1.702f * u * (1.f - s));
 }
 
-// QuickGELU pieces of the bf16 epilogues, scalar f32 on purpose: v_pk_mul / v_pk_add / v_pk_fma_f32 run at HALF the rate
-// of their scalar forms on this part (tools/probes/valu_gelu.hip, profiles/r06_gemm_epilogues.txt: ~8 cycles per wave64
-// instruction against ~2) -- the file is compiled with -fno-slp-vectorize so that the compiler does not form them either.
+// QuickGELU pieces of the bf16 epilogues, scalar f32 on purpose: inside this dependent chain (cvt -> mul -> exp2 -> add -> rcp ->
+// mul, two waves per SIMD) the packed forms v_pk_mul / v_pk_add / v_pk_fma_f32 are SLOWER than the scalar ones (3.87 us scalar,
+// 5.03 us packed for the same arithmetic: tools/probes/valu_gelu.hip, profiles/r06_gemm_epilogues.txt; their throughput with
+// independent operands is fine, profiles/r06_valu_rates.txt) -- the file is compiled with -fno-slp-vectorize so that the
+// compiler does not form them either.
 // quickgelu(u) = u r, r = sigmoid(1.702 u) = 1 / (1 + 2^(-1.702 log2(e) u)); quickgelu'(u) = r (1 + 1.702 u (1 - r))
 // = r + 1.702 (u r)(1 - r).
 __device__ __forceinline__ float bf16_lo(uint32_t p) { return __uint_as_float(p << 16); }
