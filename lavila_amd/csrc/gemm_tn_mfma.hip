@@ -604,7 +604,9 @@ __global__ __launch_bounds__(512) void gemm_tn_kernel(const uint16_t* __restrict
 
 #ifdef GM_TRACE
   // debug build only (tools/probe_gemm_trace.py): wall-clock stamps (100 MHz) of wave 0 and wave 4 of every workgroup
-  unsigned long long* trace = reinterpret_cast<unsigned long long*>(colpart) + ((size_t)bid * 2 + wm) * 128;
+  // (the column-sum epilogues keep their partial slab in front of the stamps: [2 * tiles_m][N] floats)
+  unsigned long long* trace = reinterpret_cast<unsigned long long*>(colpart + ((EPI == 2 || EPI == 5) ? (size_t)2 * (ntiles / tiles_n) * N : 0)) +
+                              ((size_t)bid * 2 + wm) * 128;
   int tpos = 0;
 #define GM_STAMP()                                                          \
   do {                                                                      \
@@ -807,6 +809,19 @@ int64_t lvl_linear_tn_workspace_floats(int64_t M, int64_t N) {
 extern "C" int lvl_linear_tn_trace(const void* x, const void* w, const float* bias, void* y, void* trace, int64_t M,
                                    int N, int K, void* stream) {
   return launch_tn<0>(x, w, bias, y, nullptr, nullptr, (float*)trace, M, N, K, nullptr, (hipStream_t)stream);
+}
+// the same with an epilogue (0, 1, 3, 4, 5); epilogue 5: `trace` starts with room for the column partials
+extern "C" int lvl_linear_tn_trace_epi(const void* x, const void* w, const float* bias, void* y, void* aux_out,
+                                       const void* aux_in, void* trace, int64_t M, int N, int K, int epilogue, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  switch (epilogue) {
+    case 0: return launch_tn<0>(x, w, bias, y, nullptr, nullptr, (float*)trace, M, N, K, nullptr, st);
+    case 1: return launch_tn<1>(x, w, bias, y, aux_out, nullptr, (float*)trace, M, N, K, nullptr, st);
+    case 3: return launch_tn<3>(x, w, bias, y, nullptr, aux_in, (float*)trace, M, N, K, nullptr, st);
+    case 4: return launch_tn<4>(x, w, bias, y, aux_out, nullptr, (float*)trace, M, N, K, nullptr, st);
+    case 5: return launch_tn<5>(x, w, nullptr, y, nullptr, aux_in, (float*)trace, M, N, K, nullptr, st);
+  }
+  return -1;
 }
 #endif
 

@@ -1,5 +1,6 @@
 """Debug probe: builds gemm_tn_mfma.hip with -DGM_TRACE into a scratch .so and prints per-tile timelines
-(wall-clock stamps of wave 0 / wave 4 of every persistent workgroup)."""
+(wall-clock stamps of wave 0 / wave 4 of every persistent workgroup).
+    python tools/probe_gemm_trace.py --build ; python tools/probe_gemm_trace.py <shape> [epilogue 0|1|3|4|5]"""
 import ctypes
 import os
 import subprocess
@@ -11,7 +12,7 @@ SO = os.path.join(ROOT, 'tools', 'probes', 'libgemm_trace%s.so' % os.environ.get
 if '--build' in sys.argv:
     src = os.path.join(ROOT, 'lavila_amd', 'csrc')
     subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared',
-                           '-DGM_TRACE', *[a for a in sys.argv[1:] if a.startswith('-D')], os.path.join(src, 'gemm_tn_mfma.hip'), os.path.join(ROOT, 'tools', 'probes', 'trace_stub.hip'),
+                           '-DGM_TRACE', '-fno-slp-vectorize', *[a for a in sys.argv[1:] if a.startswith('-D')], os.path.join(src, 'gemm_tn_mfma.hip'), os.path.join(ROOT, 'tools', 'probes', 'trace_stub.hip'),
                            '-o', SO])
     print('built', SO)
     sys.exit(0)
@@ -20,22 +21,27 @@ import torch  # noqa: E402
 lib = ctypes.CDLL(SO)
 SHAPES = {'qkv': (2304, 768), 'proj': (768, 768), 'fc1': (3072, 768), 'fc2': (768, 3072), 'dqkv': (768, 2304)}
 name = sys.argv[1] if len(sys.argv) > 1 else 'qkv'
+EPI = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 N, K = SHAPES[name]
-M = 256 * 785
+M = int(os.environ.get('PROBE_M', 256 * 785))
 x = torch.randn(M, K, device='cuda').bfloat16()
 w = (torch.randn(N, K, device='cuda') * K ** -0.5).bfloat16()
 b = torch.randn(N, device='cuda')
 y = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
-trace = torch.zeros(256 * 2 * 128 + 8 * 2 * 256, dtype=torch.int64, device='cuda')
+slab = 2 * ((M + 255) // 256) * N // 2 if EPI == 5 else 0          # int64 words of column partials in front of the stamps
+trace = torch.zeros(slab + 256 * 2 * 128 + 8 * 2 * 256, dtype=torch.int64, device='cuda')
+aux_out = torch.empty(M, N, device='cuda', dtype=torch.bfloat16) if EPI in (1, 4) else None
+aux_in = torch.randn(M, N, device='cuda').bfloat16() if EPI in (3, 5) else None
 P = ctypes.c_void_p
+PN = lambda t: P(t.data_ptr()) if t is not None else None
 for _ in range(3):
     trace.zero_()
-    rc = lib.lvl_linear_tn_trace(P(x.data_ptr()), P(w.data_ptr()), P(b.data_ptr()), P(y.data_ptr()), P(trace.data_ptr()),
-                                 ctypes.c_int64(M), N, K, P(torch.cuda.current_stream().cuda_stream))
+    rc = lib.lvl_linear_tn_trace_epi(P(x.data_ptr()), P(w.data_ptr()), P(b.data_ptr()), P(y.data_ptr()), PN(aux_out), PN(aux_in),
+                                     P(trace.data_ptr()), ctypes.c_int64(M), N, K, EPI, P(torch.cuda.current_stream().cuda_stream))
     assert rc == 0
 torch.cuda.synchronize()
-fine = trace.cpu()[256 * 2 * 128:].view(8, 2, 256)
-raw = trace.cpu()[:256 * 2 * 128].view(256, 2, 128)
+fine = trace.cpu()[slab + 256 * 2 * 128:].view(8, 2, 256)
+raw = trace.cpu()[slab:slab + 256 * 2 * 128].view(256, 2, 128)
 cyc = raw[:, :, 64:].double()
 t = raw[:, :, :64].double() * 10e-3      # 100 MHz ticks -> us
 t0 = t[t > 0].min()
